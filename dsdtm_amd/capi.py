@@ -1,0 +1,225 @@
+"""ctypes binding of the C ABI in include/dsdtm_amd.h (the drop-in boundary).
+
+The shared library is built in-tree by `dsdtm_amd/csrc/build.py` (hipcc, gfx950) and is
+the ONLY compute path: there is no CPU fallback. Loading fails loudly when the library
+is missing; compute calls fail with DSDTM_ERR_NO_DEVICE when no MI355X is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+MAX_LEVELS = 8
+OK, ERR_NO_DEVICE, ERR_INVALID, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
+
+u8p = C.POINTER(C.c_uint8)
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("f", C.c_float), ("width", C.c_int), ("height", C.c_int)]
+
+
+class Pyramid(C.Structure):
+    _fields_ = [("levels", C.c_int), ("data", C.c_void_p * MAX_LEVELS),
+                ("width", C.c_int * MAX_LEVELS), ("height", C.c_int * MAX_LEVELS),
+                ("stride", C.c_int * MAX_LEVELS)]
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("max_level", C.c_int), ("min_level", C.c_int), ("max_iters", C.c_int),
+                ("min_fts", C.c_int)]
+
+
+class AlignStats(C.Structure):
+    _fields_ = [("iters", C.c_int32 * MAX_LEVELS), ("n_ref", C.c_int32 * MAX_LEVELS),
+                ("n_vis", C.c_int32 * MAX_LEVELS), ("exit_code", C.c_int32 * MAX_LEVELS),
+                ("chi2", C.c_double * MAX_LEVELS)]
+
+    def as_dict(self):
+        return {k: list(getattr(self, k)) for k, _ in self._fields_}
+
+
+STATS_DTYPE = np.dtype([("iters", "<i4", MAX_LEVELS), ("n_ref", "<i4", MAX_LEVELS),
+                        ("n_vis", "<i4", MAX_LEVELS), ("exit_code", "<i4", MAX_LEVELS),
+                        ("chi2", "<f8", MAX_LEVELS)])
+assert STATS_DTYPE.itemsize == C.sizeof(AlignStats)
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("n_pairs", C.c_int), ("max_features", C.c_int), ("levels", C.c_int),
+                ("width", C.c_int * MAX_LEVELS), ("height", C.c_int * MAX_LEVELS),
+                ("stride", C.c_int * MAX_LEVELS), ("level_offset", C.c_size_t * MAX_LEVELS),
+                ("pyr_pitch", C.c_size_t),
+                ("ref_pyr", C.c_void_p), ("cur_pyr", C.c_void_p), ("px_xy", C.c_void_p),
+                ("bearing", C.c_void_p), ("p_world", C.c_void_p), ("initial", C.c_void_p),
+                ("n_features", C.c_void_p), ("T_ref_w", C.c_void_p), ("T_cur_w", C.c_void_p),
+                ("n_tracked", C.c_void_p), ("stats", C.c_void_p)]
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [("levels", C.c_int), ("width", C.c_int * MAX_LEVELS),
+                ("height", C.c_int * MAX_LEVELS), ("stride", C.c_int * MAX_LEVELS),
+                ("level_offset", C.c_size_t * MAX_LEVELS), ("bytes", C.c_size_t),
+                ("data", C.c_void_p)]
+
+
+def camera_struct(cam) -> Camera:
+    return Camera(cam.fx, cam.fy, cam.cx, cam.cy, cam.f, cam.width, cam.height)
+
+
+def pyramid_struct(levels) -> tuple[Pyramid, list]:
+    """levels: list of 2-D uint8 arrays (rows may be strided). Returns (struct, keepalive)."""
+    p = Pyramid()
+    p.levels = len(levels)
+    keep = []
+    for i, a in enumerate(levels):
+        if a.dtype != np.uint8 or a.ndim != 2 or a.strides[1] != 1:
+            a = np.ascontiguousarray(a, dtype=np.uint8)
+        keep.append(a)
+        p.data[i] = a.ctypes.data
+        p.width[i] = a.shape[1]
+        p.height[i] = a.shape[0]
+        p.stride[i] = a.strides[0]
+    return p, keep
+
+
+def pyramid_layout(width: int, height: int, levels: int, align: int = 64):
+    """Packed-pyramid geometry used by the *_device entry points: per level
+    (w, h, stride=w, offset); offsets aligned to `align` bytes, pitch too."""
+    ws, hs, offs = [], [], []
+    off = 0
+    w, h = width, height
+    for _ in range(levels):
+        ws.append(w)
+        hs.append(h)
+        offs.append(off)
+        off += (w * h + align - 1) // align * align
+        w, h = (w + 1) // 2, (h + 1) // 2
+    return ws, hs, list(ws), offs, off
+
+
+def declare_signatures(lib, prefix: str, with_ctx: bool):
+    """Attach argtypes for the entry points shared by the product library (prefix 'dsdtm_',
+    ctx first) and the oracle (prefix 'oracle_', no ctx)."""
+    ctx = [C.c_void_p] if with_ctx else []
+    dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    f = getattr(lib, prefix + "sparse_align")
+    f.restype = C.c_int
+    f.argtypes = ctx + [C.POINTER(Pyramid), C.POINTER(Pyramid), C.POINTER(Camera), fp, dp, dp, u8p,
+                        C.c_int, dp, dp, C.POINTER(AlignParams), C.POINTER(C.c_int),
+                        C.POINTER(AlignStats)]
+    f = getattr(lib, prefix + "align2d_batch")
+    f.restype = C.c_int
+    f.argtypes = ctx + [C.POINTER(Pyramid), u8p, u8p, ip, dp, u8p, C.c_int, C.c_int]
+    f = getattr(lib, prefix + "warp_patches")
+    f.restype = C.c_int
+    f.argtypes = ctx + [C.POINTER(Pyramid), C.c_int, C.POINTER(Camera), dp, dp, ip, fp, ip, dp, dp,
+                        C.c_int, C.c_int, dp, ip, u8p, u8p]
+
+
+# every symbol include/dsdtm_amd.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "dsdtm_create", "dsdtm_destroy", "dsdtm_last_error", "dsdtm_version", "dsdtm_device_count",
+    "dsdtm_sparse_align", "dsdtm_sparse_align_batch_device", "dsdtm_sparse_align_workspace_bytes",
+    "dsdtm_reserve", "dsdtm_align2d_batch", "dsdtm_align2d_batch_device",
+    "dsdtm_pyrdown_batch_device", "dsdtm_pyrdown", "dsdtm_warp_patches",
+]
+
+_LIB = None
+LIB_NAME = "libdsdtm_amd.so"
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
+
+
+class DsdtmError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"dsdtm_amd status {status}: {msg}")
+        self.status = status
+
+
+def load():
+    """Load libdsdtm_amd.so (no fallback: raises if it has not been built)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "dsdtm_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    declare_signatures(lib, "dsdtm_", with_ctx=True)
+    lib.dsdtm_create.restype = C.c_int
+    lib.dsdtm_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.dsdtm_destroy.restype = None
+    lib.dsdtm_destroy.argtypes = [C.c_void_p]
+    lib.dsdtm_last_error.restype = C.c_char_p
+    lib.dsdtm_last_error.argtypes = [C.c_void_p]
+    lib.dsdtm_version.restype = C.c_char_p
+    lib.dsdtm_device_count.restype = C.c_int
+    lib.dsdtm_sparse_align_batch_device.restype = C.c_int
+    lib.dsdtm_sparse_align_batch_device.argtypes = [C.c_void_p, C.POINTER(BatchDesc), C.POINTER(Camera),
+                                                    C.POINTER(AlignParams), C.c_void_p]
+    lib.dsdtm_sparse_align_workspace_bytes.restype = C.c_size_t
+    lib.dsdtm_sparse_align_workspace_bytes.argtypes = [C.POINTER(BatchDesc)]
+    lib.dsdtm_reserve.restype = C.c_int
+    lib.dsdtm_reserve.argtypes = [C.c_void_p, C.c_size_t]
+    lib.dsdtm_align2d_batch_device.restype = C.c_int
+    lib.dsdtm_align2d_batch_device.argtypes = [C.c_void_p, C.POINTER(ImageDesc), C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_void_p]
+    lib.dsdtm_pyrdown_batch_device.restype = C.c_int
+    lib.dsdtm_pyrdown_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_size_t), C.c_void_p]
+    lib.dsdtm_pyrdown.restype = C.c_int
+    lib.dsdtm_pyrdown.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    _LIB = lib
+    return lib
+
+
+class Context:
+    """Owns one dsdtm_ctx (one per calling thread, as the reference classes are single-threaded)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        st = self.lib.dsdtm_create(device, C.byref(h))
+        if st != OK:
+            msg = self.lib.dsdtm_last_error(None)
+            raise DsdtmError(st, msg.decode() if msg else "dsdtm_create failed")
+        self.handle = h
+        self.device = device
+
+    def check(self, st: int):
+        if st != OK:
+            msg = self.lib.dsdtm_last_error(self.handle)
+            raise DsdtmError(st, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.dsdtm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT_CTX = {}
+
+
+def default_context(device: int = 0) -> Context:
+    ctx = _DEFAULT_CTX.get(device)
+    if ctx is None:
+        ctx = _DEFAULT_CTX[device] = Context(device)
+    return ctx

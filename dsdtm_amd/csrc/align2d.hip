@@ -1,0 +1,126 @@
+// align2d.hip — Feature_Alignment::Align2DGaussNewton, one wavefront per feature (gfx950).
+//
+// Replaces reference src/Feature_alignment.cpp:318-417. lane = one pixel of the 8x8 patch:
+// the lane owns its reference intensity and the gradients derived from the 10x10 bordered
+// patch (:330-343), samples the current image bilinearly each iteration (:381-392) and the three
+// Jres sums are reduced across the wavefront with DPP (no LDS). The 3x3 inverse, the update
+// and the convergence test (:345, :395-411) are evaluated redundantly by all lanes.
+// float32 throughout, as the reference (Matrix3f, float u,v) — including its float/double mixing
+// in the bilinear weights (:373-376).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace dsdtm {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// wavefront sum; every lane of row 3 (lanes 48..63) holds the total, broadcast from lane 63
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f32<0x128, 0xf>(v);  // row_ror:8
+    v += dpp_f32<0x124, 0xf>(v);  // row_ror:4
+    v += dpp_f32<0x122, 0xf>(v);  // row_ror:2
+    v += dpp_f32<0x121, 0xf>(v);  // row_ror:1
+    v += dpp_f32<0x142, 0xa>(v);  // row_bcast:15
+    v += dpp_f32<0x143, 0xc>(v);  // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
+    // no FMA contraction: the reference build has none (CMakeLists.txt:5-8, SSE only) and the
+    // 0.03^2 convergence threshold (:400) is compared on float values
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform
+    if (f >= a.m) return;
+    const int lvl = a.level[f];
+    if (lvl < 0 || lvl >= a.levels) {                    // invalid level: report "not converged"
+        if (lane == 0) a.converged[f] = 0;
+        return;
+    }
+    const LevelGeom lg = a.lv[lvl];
+    const uint8_t* __restrict__ img = a.cur_pyr + lg.off;
+    const int img_size = lg.stride * lg.h;
+
+    const int r = lane >> 3, c = lane & 7;
+    const uint8_t* __restrict__ bp = a.patch_border + (size_t)f * 100 + (r + 1) * 10 + (c + 1);
+    // :336-337  0.5*(it[1]-it[-1]) is exact in float
+    const float dx = 0.5f * (float)((int)bp[1] - (int)bp[-1]);
+    const float dy = 0.5f * (float)((int)bp[10] - (int)bp[-10]);
+    const float ref = (float)a.patch[(size_t)f * 64 + lane];
+
+    // H = sum J J^T, J = [dx, dy, 1]  (:341)
+    const float h00 = wave_sum_f32(dx * dx);
+    const float h01 = wave_sum_f32(dx * dy);
+    const float h02 = wave_sum_f32(dx);
+    const float h11 = wave_sum_f32(dy * dy);
+    const float h12 = wave_sum_f32(dy);
+    const float h22 = 64.0f;
+    // Matrix3f::inverse() (:345): Eigen cofactor formula, no conditioning check (quirk A2)
+    const float m00 = h00, m01 = h01, m02 = h02, m10 = h01, m11 = h11, m12 = h12, m20 = h02, m21 = h12, m22 = h22;
+    const float c00 = m11 * m22 - m12 * m21;
+    const float c10 = m21 * m02 - m22 * m01;   // cofactor_3x3<1,0>
+    const float c20 = m01 * m12 - m02 * m11;   // cofactor_3x3<2,0>
+    const float det = c00 * m00 + (c10 * m10 + c20 * m20);
+    const float invdet = 1.0f / det;
+    const float i00 = c00 * invdet, i01 = c10 * invdet, i02 = c20 * invdet;
+    const float i10 = (m12 * m20 - m10 * m22) * invdet;   // cofactor<0,1>
+    const float i11 = (m22 * m00 - m20 * m02) * invdet;   // cofactor<1,1>
+    const float i12 = (m02 * m10 - m00 * m12) * invdet;   // cofactor<2,1>
+    const float i20 = (m10 * m21 - m11 * m20) * invdet;   // cofactor<0,2>
+    const float i21 = (m20 * m01 - m21 * m00) * invdet;   // cofactor<1,2>
+    const float i22 = (m00 * m11 - m01 * m10) * invdet;   // cofactor<2,2>
+
+    float u = (float)a.px_xy[2 * (size_t)f];
+    float v = (float)a.px_xy[2 * (size_t)f + 1];
+    float mean_diff = 0.0f;
+    const float min_update_squared = (float)(0.03 * 0.03);
+    bool converged = false;
+    for (int it = 0; it < a.max_iters; ++it) {
+        if (u != u || v != v) break;                                         // :368 isnan
+        const float fu = floorf(u), fv = floorf(v);
+        // compare as floats: the int conversion of a huge float would be undefined
+        if (fu < 4.0f || fv < 4.0f || fu > (float)(lg.w - 4) || fv > (float)(lg.h - 4)) break;   // :367-368
+        const int u_r = (int)fu, v_r = (int)fv;
+        const float sx = u - (float)u_r, sy = v - (float)v_r;
+        const float wTL = (float)((1.0 - (double)sx) * (1.0 - (double)sy));  // :373 (double arithmetic)
+        const float wTR = sx * (1.0f - sy);                                   // :374 (float arithmetic)
+        const float wBL = (float)((1.0 - (double)sx) * (double)sy);          // :375
+        const float wBR = sx * sy;                                            // :376
+        const int o = (v_r + r - 4) * lg.stride + (u_r + c - 4);             // :383
+        // quirk A3: offsets past the level image read as 0 (undefined in the reference)
+        const float p00 = (o < img_size) ? (float)img[o] : 0.0f;
+        const float p01 = (o + 1 < img_size) ? (float)img[o + 1] : 0.0f;
+        const float p10 = (o + lg.stride < img_size) ? (float)img[o + lg.stride] : 0.0f;
+        const float p11 = (o + lg.stride + 1 < img_size) ? (float)img[o + lg.stride + 1] : 0.0f;
+        const float search = wTL * p00 + wTR * p01 + wBL * p10 + wBR * p11;  // :386
+        const float res = search - ref + mean_diff;                          // :387
+        const float j0 = -wave_sum_f32(res * dx);                            // :389-391
+        const float j1 = -wave_sum_f32(res * dy);
+        const float j2 = -wave_sum_f32(res);
+        const float up0 = (i00 * j0 + i01 * j1) + i02 * j2;                  // :395
+        const float up1 = (i10 * j0 + i11 * j1) + i12 * j2;
+        const float up2 = (i20 * j0 + i21 * j1) + i22 * j2;
+        u += up0;
+        v += up1;
+        mean_diff += up2;
+        if (up0 * up0 + up1 * up1 < min_update_squared) { converged = true; break; }   // :400
+    }
+    if (lane == 0) {
+        a.px_xy[2 * (size_t)f] = (double)u;                                  // :414 always written back
+        a.px_xy[2 * (size_t)f + 1] = (double)v;
+        a.converged[f] = converged ? 1 : 0;
+    }
+}
+
+hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream) {
+    if (args.m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(align2d_kernel, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace dsdtm

@@ -1,0 +1,517 @@
+// api.cpp — the C ABI of include/dsdtm_amd.h: context, host staging, launches.
+//
+// Host entry points pack their inputs into one pinned buffer, move it with a single
+// hipMemcpyAsync, launch on the context's stream and copy the (small) results back. Device
+// entry points only enqueue kernels. There is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/dsdtm_amd.h"
+#include "kernels.h"
+
+using namespace dsdtm;
+
+struct dsdtm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // staging
+    void* h_pinned = nullptr;
+    size_t h_cap = 0;
+    void* d_stage = nullptr;
+    size_t d_cap = 0;
+    // workspace for the generic sparse-align kernel
+    void* d_ws = nullptr;
+    size_t ws_cap = 0;
+};
+
+static thread_local char g_create_err[512] = "";
+
+static void set_err(dsdtm_ctx* ctx, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_err(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return DSDTM_ERR_HIP;                                                            \
+        }                                                                                    \
+    } while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" {
+
+const char* dsdtm_version(void) { return "dsdtm_amd 0.1 (gfx950, HIP; grid=" DSDTM_STR(SA_GRID_T) ")"; }
+
+int dsdtm_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return DSDTM_ERR_NO_DEVICE;
+    return n;
+}
+
+const char* dsdtm_last_error(const dsdtm_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+int dsdtm_create(int device, dsdtm_ctx** out) {
+    if (!out) return DSDTM_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_err(nullptr, "no HIP device visible (%s); dsdtm_amd has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return DSDTM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_err(nullptr, "device %d out of range (%d visible)", device, n);
+        return DSDTM_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        set_err(nullptr, "hipGetDeviceProperties(%d) failed", device);
+        return DSDTM_ERR_NO_DEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(nullptr, "device %d is %s; this library contains gfx950 (MI355X) code objects only", device,
+                prop.gcnArchName);
+        return DSDTM_ERR_NO_DEVICE;
+    }
+    dsdtm_ctx* ctx = new (std::nothrow) dsdtm_ctx();
+    if (!ctx) return DSDTM_ERR_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_err(nullptr, "hipSetDevice/hipStreamCreate failed on device %d", device);
+        delete ctx;
+        return DSDTM_ERR_HIP;
+    }
+    *out = ctx;
+    return DSDTM_OK;
+}
+
+void dsdtm_destroy(dsdtm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    delete ctx;
+}
+
+}  // extern "C"
+
+static int ensure_stage(dsdtm_ctx* ctx, size_t bytes) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bytes > ctx->h_cap) {
+        if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+        ctx->h_pinned = nullptr; ctx->h_cap = 0;
+        const size_t cap = align_up(bytes + bytes / 4, 1 << 16);
+        HIP_TRY(ctx, hipHostMalloc(&ctx->h_pinned, cap, hipHostMallocDefault));
+        ctx->h_cap = cap;
+    }
+    if (bytes > ctx->d_cap) {
+        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr; ctx->d_cap = 0;
+        const size_t cap = align_up(bytes + bytes / 4, 1 << 16);
+        HIP_TRY(ctx, hipMalloc(&ctx->d_stage, cap));
+        ctx->d_cap = cap;
+    }
+    return DSDTM_OK;
+}
+
+extern "C" int dsdtm_reserve(dsdtm_ctx* ctx, size_t workspace_bytes) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (workspace_bytes > ctx->ws_cap) {
+        if (ctx->d_ws) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_ws); }
+        ctx->d_ws = nullptr; ctx->ws_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_ws, workspace_bytes));
+        ctx->ws_cap = workspace_bytes;
+    }
+    return DSDTM_OK;
+}
+
+extern "C" size_t dsdtm_sparse_align_workspace_bytes(const dsdtm_batch_desc* b) {
+    if (!b) return 0;
+    return sparse_align_workspace_bytes(b->n_pairs, b->max_features);
+}
+
+static int validate_params(dsdtm_ctx* ctx, const dsdtm_align_params* p, int levels) {
+    if (!p) { set_err(ctx, "params is NULL"); return DSDTM_ERR_INVALID; }
+    if (p->max_level > levels || p->max_level > DSDTM_MAX_LEVELS || p->min_level < 0) {
+        set_err(ctx, "level range [%d,%d) does not fit a %d-level pyramid", p->min_level, p->max_level, levels);
+        return DSDTM_ERR_INVALID;
+    }
+    return DSDTM_OK;
+}
+
+extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam,
+                                               const dsdtm_align_params* prm, void* hip_stream) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!b || !cam) { set_err(ctx, "batch/cam is NULL"); return DSDTM_ERR_INVALID; }
+    if (int rc = validate_params(ctx, prm, b->levels)) return rc;
+    if (b->n_pairs < 0 || b->max_features < 0 || b->levels <= 0 || b->levels > DSDTM_MAX_LEVELS) {
+        set_err(ctx, "bad batch geometry"); return DSDTM_ERR_INVALID;
+    }
+    if (b->n_pairs == 0) return DSDTM_OK;
+    if (!b->ref_pyr || !b->cur_pyr || !b->T_ref_w || !b->T_cur_w || !b->n_tracked ||
+        (b->max_features > 0 && (!b->px_xy || !b->bearing || !b->p_world || !b->initial))) {
+        set_err(ctx, "batch descriptor has NULL device pointers"); return DSDTM_ERR_INVALID;
+    }
+    if ((b->pyr_pitch & 3) || b->pyr_pitch == 0 || b->pyr_pitch > 0xffffffffull ||
+        (((size_t)b->ref_pyr) & 3) || (((size_t)b->cur_pyr) & 3)) {
+        set_err(ctx, "pyramid base/pitch must be 4-byte aligned and pitch < 4 GiB"); return DSDTM_ERR_INVALID;
+    }
+    SAKernelArgs a;
+    memset(&a, 0, sizeof a);
+    for (int l = 0; l < b->levels; ++l) {
+        const size_t end = b->level_offset[l] + (size_t)b->stride[l] * b->height[l];
+        if (b->width[l] <= 0 || b->height[l] <= 0 || b->stride[l] < b->width[l] || end > b->pyr_pitch) {
+            set_err(ctx, "level %d does not fit inside pyr_pitch", l); return DSDTM_ERR_INVALID;
+        }
+        a.lv[l].w = b->width[l]; a.lv[l].h = b->height[l]; a.lv[l].stride = b->stride[l];
+        a.lv[l].off = (uint32_t)b->level_offset[l];
+    }
+    a.ref_pyr = b->ref_pyr; a.cur_pyr = b->cur_pyr; a.px_xy = b->px_xy; a.bearing = b->bearing;
+    a.p_world = b->p_world; a.initial = b->initial; a.n_features = b->n_features;
+    a.T_ref_w = b->T_ref_w; a.T_cur_w = b->T_cur_w; a.n_tracked = b->n_tracked; a.stats = b->stats;
+    a.pyr_pitch = b->pyr_pitch; a.n_pairs = b->n_pairs; a.max_features = b->max_features;
+    a.max_level = prm->max_level; a.min_level = prm->min_level; a.max_iters = prm->max_iters; a.min_fts = prm->min_fts;
+    a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy; a.f = cam->f;
+    const SAVariant v = sparse_align_pick_variant(b->max_features);
+    const size_t ws = sparse_align_workspace_bytes(b->n_pairs, b->max_features);
+    if (ws) {
+        if (ws > ctx->ws_cap) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hip_stream && hipStreamIsCapturing((hipStream_t)hip_stream, &cs) == hipSuccess &&
+                cs != hipStreamCaptureStatusNone) {
+                set_err(ctx, "workspace of %zu bytes needed: call dsdtm_reserve before capturing", ws);
+                return DSDTM_ERR_INVALID;
+            }
+            if (int rc = dsdtm_reserve(ctx, ws)) return rc;
+        }
+        a.workspace = (double*)ctx->d_ws;
+    }
+    HIP_TRY(ctx, sparse_align_launch(a, v, (hipStream_t)hip_stream));
+    return DSDTM_OK;
+}
+
+// ---- host staging helpers ---------------------------------------------------------------
+struct PackedPyr {
+    int levels;
+    int w[DSDTM_MAX_LEVELS], h[DSDTM_MAX_LEVELS];
+    size_t off[DSDTM_MAX_LEVELS];
+    size_t bytes;
+};
+
+static int plan_pyramid(dsdtm_ctx* ctx, const dsdtm_pyramid* p, PackedPyr* out) {
+    if (!p || p->levels <= 0 || p->levels > DSDTM_MAX_LEVELS) { set_err(ctx, "bad pyramid"); return DSDTM_ERR_INVALID; }
+    size_t off = 0;
+    out->levels = p->levels;
+    for (int l = 0; l < p->levels; ++l) {
+        if (!p->data[l] || p->width[l] <= 0 || p->height[l] <= 0 || p->stride[l] < p->width[l]) {
+            set_err(ctx, "bad pyramid level %d", l); return DSDTM_ERR_INVALID;
+        }
+        out->w[l] = p->width[l]; out->h[l] = p->height[l]; out->off[l] = off;
+        off += align_up((size_t)p->width[l] * p->height[l], 64);
+    }
+    out->bytes = off;
+    return DSDTM_OK;
+}
+
+static void pack_pyramid(const dsdtm_pyramid* p, const PackedPyr& pl, uint8_t* dst) {
+    for (int l = 0; l < pl.levels; ++l) {
+        uint8_t* d = dst + pl.off[l];
+        const uint8_t* s = p->data[l];
+        if (p->stride[l] == pl.w[l]) memcpy(d, s, (size_t)pl.w[l] * pl.h[l]);
+        else for (int y = 0; y < pl.h[l]; ++y) memcpy(d + (size_t)y * pl.w[l], s + (size_t)y * p->stride[l], pl.w[l]);
+    }
+}
+
+extern "C" int dsdtm_sparse_align(dsdtm_ctx* ctx, const dsdtm_pyramid* ref, const dsdtm_pyramid* cur,
+                                  const dsdtm_camera* cam, const float* px_xy, const double* bearing,
+                                  const double* p_world, const uint8_t* initial, int n_features,
+                                  const double T_ref_w[12], double T_cur_w[12], const dsdtm_align_params* prm,
+                                  int* n_tracked, dsdtm_align_stats* stats) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!ref || !cur || !cam || !T_ref_w || !T_cur_w || !n_tracked || n_features < 0 ||
+        (n_features > 0 && (!px_xy || !bearing || !p_world || !initial))) {
+        set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID;
+    }
+    PackedPyr pr, pc;
+    if (int rc = plan_pyramid(ctx, ref, &pr)) return rc;
+    if (int rc = plan_pyramid(ctx, cur, &pc)) return rc;
+    if (pr.levels != pc.levels) { set_err(ctx, "ref/cur pyramids differ in level count"); return DSDTM_ERR_INVALID; }
+    for (int l = 0; l < pr.levels; ++l)
+        if (pr.w[l] != pc.w[l] || pr.h[l] != pc.h[l]) { set_err(ctx, "ref/cur level %d differ in size", l); return DSDTM_ERR_INVALID; }
+    if (int rc = validate_params(ctx, prm, pr.levels)) return rc;
+    // Run() (:34-38): too few features -> 0, pose untouched. Decided on the host: no launch needed.
+    if (stats) memset(stats, 0, sizeof *stats);
+    *n_tracked = 0;
+    if (n_features < prm->min_fts || prm->max_level - 1 < prm->min_level) return DSDTM_OK;
+
+    const size_t nf = (size_t)n_features;
+    const size_t pitch = align_up(pr.bytes, 256);
+    size_t o = 0;
+    const size_t o_ref = o; o += pitch;
+    const size_t o_cur = o; o += pitch;
+    const size_t o_bear = o; o += align_up(nf * 24, 256);
+    const size_t o_pw = o; o += align_up(nf * 24, 256);
+    const size_t o_tr = o; o += 256;
+    const size_t o_px = o; o += align_up(nf * 8, 256);
+    const size_t o_ini = o; o += align_up(nf, 256);
+    const size_t in_bytes = o;
+    const size_t o_tc = o; o += 256;          // in (seed) and out
+    const size_t o_nt = o; o += 256;
+    const size_t o_st = o; o += align_up(sizeof(dsdtm_align_stats), 256);
+    const size_t total = o;
+    if (int rc = ensure_stage(ctx, total)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    pack_pyramid(ref, pr, h + o_ref);
+    pack_pyramid(cur, pc, h + o_cur);
+    memcpy(h + o_bear, bearing, nf * 24);
+    memcpy(h + o_pw, p_world, nf * 24);
+    memcpy(h + o_tr, T_ref_w, 96);
+    memcpy(h + o_px, px_xy, nf * 8);
+    memcpy(h + o_ini, initial, nf);
+    memcpy(h + o_tc, T_cur_w, 96);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes + 256, hipMemcpyHostToDevice, ctx->stream));
+
+    dsdtm_batch_desc b;
+    memset(&b, 0, sizeof b);
+    b.n_pairs = 1; b.max_features = n_features; b.levels = pr.levels;
+    for (int l = 0; l < pr.levels; ++l) { b.width[l] = pr.w[l]; b.height[l] = pr.h[l]; b.stride[l] = pr.w[l]; b.level_offset[l] = pr.off[l]; }
+    b.pyr_pitch = pitch;
+    b.ref_pyr = d + o_ref; b.cur_pyr = d + o_cur; b.px_xy = (const float*)(d + o_px);
+    b.bearing = (const double*)(d + o_bear); b.p_world = (const double*)(d + o_pw); b.initial = d + o_ini;
+    b.n_features = nullptr; b.T_ref_w = (const double*)(d + o_tr); b.T_cur_w = (double*)(d + o_tc);
+    b.n_tracked = (int32_t*)(d + o_nt); b.stats = (dsdtm_align_stats*)(d + o_st);
+    if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, ctx->stream)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(T_cur_w, h + o_tc, 96);
+    *n_tracked = *(const int32_t*)(h + o_nt);
+    if (stats) memcpy(stats, h + o_st, sizeof *stats);
+    return DSDTM_OK;
+}
+
+// ---- Align2D ------------------------------------------------------------------------------
+extern "C" int dsdtm_align2d_batch_device(dsdtm_ctx* ctx, const dsdtm_image_desc* cur, const uint8_t* patch_border,
+                                          const uint8_t* patch, const int32_t* level, double* px_xy,
+                                          uint8_t* converged, int max_iters, int m, void* hip_stream) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!cur || m < 0 || cur->levels <= 0 || cur->levels > DSDTM_MAX_LEVELS) { set_err(ctx, "bad image descriptor"); return DSDTM_ERR_INVALID; }
+    if (m == 0) return DSDTM_OK;
+    if (!cur->data || !patch_border || !patch || !level || !px_xy || !converged) { set_err(ctx, "NULL device pointer"); return DSDTM_ERR_INVALID; }
+    A2DKernelArgs a;
+    memset(&a, 0, sizeof a);
+    for (int l = 0; l < cur->levels; ++l) {
+        const size_t end = cur->level_offset[l] + (size_t)cur->stride[l] * cur->height[l];
+        if (cur->width[l] <= 0 || cur->height[l] <= 0 || cur->stride[l] < cur->width[l] || end > cur->bytes) {
+            set_err(ctx, "level %d does not fit inside the packed pyramid", l); return DSDTM_ERR_INVALID;
+        }
+        a.lv[l].w = cur->width[l]; a.lv[l].h = cur->height[l]; a.lv[l].stride = cur->stride[l];
+        a.lv[l].off = (uint32_t)cur->level_offset[l];
+    }
+    a.cur_pyr = cur->data; a.patch_border = patch_border; a.patch = patch; a.level = level;
+    a.px_xy = px_xy; a.converged = converged; a.m = m; a.max_iters = max_iters; a.levels = cur->levels;
+    HIP_TRY(ctx, align2d_launch(a, (hipStream_t)hip_stream));
+    return DSDTM_OK;
+}
+
+extern "C" int dsdtm_align2d_batch(dsdtm_ctx* ctx, const dsdtm_pyramid* cur, const uint8_t* patch_border,
+                                   const uint8_t* patch, const int32_t* level, double* px_xy, uint8_t* converged,
+                                   int max_iters, int m) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (m < 0 || (m > 0 && (!patch_border || !patch || !level || !px_xy || !converged))) { set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID; }
+    PackedPyr pc;
+    if (int rc = plan_pyramid(ctx, cur, &pc)) return rc;
+    if (m == 0) return DSDTM_OK;
+    for (int i = 0; i < m; ++i)
+        if (level[i] < 0 || level[i] >= pc.levels) { set_err(ctx, "level[%d]=%d outside the pyramid", i, level[i]); return DSDTM_ERR_INVALID; }
+    const size_t M = (size_t)m;
+    size_t o = 0;
+    const size_t o_pyr = o; o += align_up(pc.bytes, 256);
+    const size_t o_pb = o; o += align_up(M * 100, 256);
+    const size_t o_p = o; o += align_up(M * 64, 256);
+    const size_t o_lv = o; o += align_up(M * 4, 256);
+    const size_t o_px = o; o += align_up(M * 16, 256);
+    const size_t in_bytes = o;
+    const size_t o_cv = o; o += align_up(M, 256);
+    const size_t total = o;
+    if (int rc = ensure_stage(ctx, total)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    pack_pyramid(cur, pc, h + o_pyr);
+    memcpy(h + o_pb, patch_border, M * 100);
+    memcpy(h + o_p, patch, M * 64);
+    memcpy(h + o_lv, level, M * 4);
+    memcpy(h + o_px, px_xy, M * 16);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    dsdtm_image_desc img;
+    memset(&img, 0, sizeof img);
+    img.levels = pc.levels;
+    for (int l = 0; l < pc.levels; ++l) { img.width[l] = pc.w[l]; img.height[l] = pc.h[l]; img.stride[l] = pc.w[l]; img.level_offset[l] = pc.off[l]; }
+    img.bytes = pc.bytes; img.data = d + o_pyr;
+    if (int rc = dsdtm_align2d_batch_device(ctx, &img, d + o_pb, d + o_p, (const int32_t*)(d + o_lv),
+                                            (double*)(d + o_px), d + o_cv, max_iters, m, ctx->stream)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h + o_px, d + o_px, total - o_px, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(px_xy, h + o_px, M * 16);
+    memcpy(converged, h + o_cv, M);
+    return DSDTM_OK;
+}
+
+// ---- pyrDown ------------------------------------------------------------------------------
+extern "C" int dsdtm_pyrdown_batch_device(dsdtm_ctx* ctx, uint8_t* pyr, size_t pyr_pitch, int n_images, int levels,
+                                          const int* width, const int* height, const int* stride,
+                                          const size_t* level_offset, void* hip_stream) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!pyr || !width || !height || !stride || !level_offset || levels <= 0 || levels > DSDTM_MAX_LEVELS || n_images < 0) {
+        set_err(ctx, "bad argument"); return DSDTM_ERR_INVALID;
+    }
+    for (int l = 0; l < levels; ++l) {
+        if (width[l] <= 0 || height[l] <= 0 || stride[l] < width[l] ||
+            level_offset[l] + (size_t)stride[l] * height[l] > pyr_pitch) { set_err(ctx, "level %d does not fit", l); return DSDTM_ERR_INVALID; }
+        if (l > 0 && (width[l] != (width[l - 1] + 1) / 2 || height[l] != (height[l - 1] + 1) / 2)) {
+            set_err(ctx, "level %d is not ((w+1)/2,(h+1)/2) of level %d", l, l - 1); return DSDTM_ERR_INVALID;
+        }
+    }
+    for (int l = 1; l < levels; ++l)
+        HIP_TRY(ctx, pyrdown_launch(pyr, pyr_pitch, n_images, width[l - 1], height[l - 1], stride[l - 1],
+                                    level_offset[l - 1], stride[l], level_offset[l], (hipStream_t)hip_stream));
+    return DSDTM_OK;
+}
+
+extern "C" int dsdtm_pyrdown(dsdtm_ctx* ctx, const uint8_t* level0, int width, int height, int stride, int levels,
+                             uint8_t* const* out_levels, const int* out_stride) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!level0 || width <= 0 || height <= 0 || stride < width || levels <= 0 || levels > DSDTM_MAX_LEVELS ||
+        (levels > 1 && (!out_levels || !out_stride))) { set_err(ctx, "bad argument"); return DSDTM_ERR_INVALID; }
+    int w[DSDTM_MAX_LEVELS], h[DSDTM_MAX_LEVELS], st[DSDTM_MAX_LEVELS];
+    size_t off[DSDTM_MAX_LEVELS];
+    size_t o = 0;
+    for (int l = 0; l < levels; ++l) {
+        w[l] = l ? (w[l - 1] + 1) / 2 : width; h[l] = l ? (h[l - 1] + 1) / 2 : height; st[l] = w[l];
+        off[l] = o; o += align_up((size_t)w[l] * h[l], 64);
+    }
+    const size_t pitch = align_up(o, 256);
+    if (int rc = ensure_stage(ctx, pitch)) return rc;
+    uint8_t* hp = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    for (int y = 0; y < height; ++y) memcpy(hp + (size_t)y * width, level0 + (size_t)y * stride, width);
+    HIP_TRY(ctx, hipMemcpyAsync(d, hp, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = dsdtm_pyrdown_batch_device(ctx, d, pitch, 1, levels, w, h, st, off, ctx->stream)) return rc;
+    if (levels > 1) HIP_TRY(ctx, hipMemcpyAsync(hp + off[1], d + off[1], o - off[1], hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 1; l < levels; ++l) {
+        if (!out_levels[l] || out_stride[l] < w[l]) { set_err(ctx, "bad output level %d", l); return DSDTM_ERR_INVALID; }
+        for (int y = 0; y < h[l]; ++y) memcpy(out_levels[l] + (size_t)y * out_stride[l], hp + off[l] + (size_t)y * w[l], w[l]);
+    }
+    return DSDTM_OK;
+}
+
+// ---- warp prelude ---------------------------------------------------------------------------
+extern "C" int dsdtm_warp_patches(dsdtm_ctx* ctx, const dsdtm_pyramid* kf_pyr, int n_kf, const dsdtm_camera* cam,
+                                  const double* T_kf_w, const double T_cur_w[12], const int32_t* cand_kf,
+                                  const float* ref_px, const int32_t* ref_level, const double* ref_bearing,
+                                  const double* p_world, int max_search_level, int m, double* affine,
+                                  int32_t* search_level, uint8_t* patch_border, uint8_t* patch) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!kf_pyr || n_kf <= 0 || !cam || !T_kf_w || !T_cur_w || m < 0 ||
+        (m > 0 && (!cand_kf || !ref_px || !ref_level || !ref_bearing || !p_world || !search_level || !patch_border || !patch))) {
+        set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID;
+    }
+    if (m == 0) return DSDTM_OK;
+    PackedPyr p0;
+    if (int rc = plan_pyramid(ctx, &kf_pyr[0], &p0)) return rc;
+    for (int k = 1; k < n_kf; ++k) {
+        PackedPyr pk;
+        if (int rc = plan_pyramid(ctx, &kf_pyr[k], &pk)) return rc;
+        if (pk.levels != p0.levels || memcmp(pk.w, p0.w, sizeof(int) * p0.levels) || memcmp(pk.h, p0.h, sizeof(int) * p0.levels)) {
+            set_err(ctx, "keyframe %d pyramid geometry differs from keyframe 0", k); return DSDTM_ERR_INVALID;
+        }
+    }
+    for (int i = 0; i < m; ++i) {
+        if (cand_kf[i] < 0 || cand_kf[i] >= n_kf || ref_level[i] < 0 || ref_level[i] >= p0.levels) {
+            set_err(ctx, "candidate %d: keyframe %d / level %d out of range", i, cand_kf[i], ref_level[i]); return DSDTM_ERR_INVALID;
+        }
+    }
+    const size_t M = (size_t)m;
+    const size_t pitch = align_up(p0.bytes, 256);
+    size_t o = 0;
+    const size_t o_pyr = o; o += pitch * (size_t)n_kf;
+    const size_t o_tk = o; o += align_up((size_t)n_kf * 96, 256);
+    const size_t o_rb = o; o += align_up(M * 24, 256);
+    const size_t o_pw = o; o += align_up(M * 24, 256);
+    const size_t o_ck = o; o += align_up(M * 4, 256);
+    const size_t o_rl = o; o += align_up(M * 4, 256);
+    const size_t o_rp = o; o += align_up(M * 8, 256);
+    const size_t in_bytes = o;
+    const size_t o_af = o; o += align_up(M * 32, 256);
+    const size_t o_sl = o; o += align_up(M * 4, 256);
+    const size_t o_pb = o; o += align_up(M * 100, 256);
+    const size_t o_pp = o; o += align_up(M * 64, 256);
+    const size_t total = o;
+    if (int rc = ensure_stage(ctx, total)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    for (int k = 0; k < n_kf; ++k) pack_pyramid(&kf_pyr[k], p0, h + o_pyr + pitch * (size_t)k);
+    memcpy(h + o_tk, T_kf_w, (size_t)n_kf * 96);
+    memcpy(h + o_rb, ref_bearing, M * 24);
+    memcpy(h + o_pw, p_world, M * 24);
+    memcpy(h + o_ck, cand_kf, M * 4);
+    memcpy(h + o_rl, ref_level, M * 4);
+    memcpy(h + o_rp, ref_px, M * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    WarpKernelArgs a;
+    memset(&a, 0, sizeof a);
+    a.kf_pyr = d + o_pyr; a.kf_pitch = pitch; a.T_kf_w = (const double*)(d + o_tk);
+    a.cand_kf = (const int32_t*)(d + o_ck); a.ref_px = (const float*)(d + o_rp);
+    a.ref_level = (const int32_t*)(d + o_rl); a.ref_bearing = (const double*)(d + o_rb);
+    a.p_world = (const double*)(d + o_pw); a.affine = (double*)(d + o_af);
+    a.search_level = (int32_t*)(d + o_sl); a.patch_border = d + o_pb; a.patch = d + o_pp;
+    memcpy(a.T_cur_w, T_cur_w, 96);
+    a.m = m; a.n_kf = n_kf; a.max_search_level = max_search_level; a.levels = p0.levels;
+    a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy;
+    for (int l = 0; l < p0.levels; ++l) { a.lv[l].w = p0.w[l]; a.lv[l].h = p0.h[l]; a.lv[l].stride = p0.w[l]; a.lv[l].off = (uint32_t)p0.off[l]; }
+    HIP_TRY(ctx, warp_launch(a, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + o_af, d + o_af, total - o_af, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (affine) memcpy(affine, h + o_af, M * 32);
+    memcpy(search_level, h + o_sl, M * 4);
+    memcpy(patch_border, h + o_pb, M * 100);
+    memcpy(patch, h + o_pp, M * 64);
+    return DSDTM_OK;
+}
+
+// ---- debug: device self-test of the FP64 building blocks (not in the public header) ------------
+extern "C" int dsdtm_debug_selftest(dsdtm_ctx* ctx, const double* in, double* out, int n_cases) {
+    if (!ctx || !in || !out || n_cases < 0) return DSDTM_ERR_INVALID;
+    if (n_cases == 0) return DSDTM_OK;
+    const size_t ib = align_up((size_t)n_cases * 33 * 8, 256), ob = (size_t)n_cases * 34 * 8;
+    if (int rc = ensure_stage(ctx, ib + ob)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    memcpy(h, in, (size_t)n_cases * 33 * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, ib, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, selftest_launch((const double*)d, (double*)(d + ib), n_cases, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + ib, d + ib, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, h + ib, ob);
+    return DSDTM_OK;
+}

@@ -1,0 +1,335 @@
+// device_math.h — FP64 building blocks shared by the gfx950 kernels.
+//
+// SE(3) arithmetic follows Sophus' non-templated SE3/SO3 (unit quaternion + translation)
+// because that is what the reference composes poses with (reference
+// src/Sprase_ImageAlign.cpp:43,57,254,335); the 6x6 solve follows Eigen 3.2's
+// LDLT (diagonal pivoting, rank cutoff, pseudo-inverse of D) used at :318, so that
+// degenerate systems (no visible patch, rank-deficient H) behave as in the reference.
+// Everything is written for static register indexing: no runtime-indexed private arrays.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsdtm {
+
+struct SE3d {
+    double qw, qx, qy, qz;
+    double tx, ty, tz;
+};
+
+__device__ __forceinline__ void quat_normalize(SE3d& T) {
+    const double n = sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
+    T.qw /= n; T.qx /= n; T.qy /= n; T.qz /= n;
+}
+
+__device__ __forceinline__ void quat_rotate(const SE3d& T, double vx, double vy, double vz,
+                                            double& ox, double& oy, double& oz) {
+    double ux = T.qy * vz - T.qz * vy;
+    double uy = T.qz * vx - T.qx * vz;
+    double uz = T.qx * vy - T.qy * vx;
+    ux += ux; uy += uy; uz += uz;
+    const double cx = T.qy * uz - T.qz * uy;
+    const double cy = T.qz * ux - T.qx * uz;
+    const double cz = T.qx * uy - T.qy * ux;
+    ox = vx + T.qw * ux + cx;
+    oy = vy + T.qw * uy + cy;
+    oz = vz + T.qw * uz + cz;
+}
+
+// [R|t] 3x4 row-major -> SE3 (Eigen rotation-matrix -> quaternion, then normalise)
+__device__ inline SE3d se3_from_rt(const double* __restrict__ T) {
+    const double m00 = T[0], m01 = T[1], m02 = T[2];
+    const double m10 = T[4], m11 = T[5], m12 = T[6];
+    const double m20 = T[8], m21 = T[9], m22 = T[10];
+    SE3d o;
+    double t = m00 + m11 + m22;
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        o.qw = 0.5 * t;
+        t = 0.5 / t;
+        o.qx = (m21 - m12) * t;
+        o.qy = (m02 - m20) * t;
+        o.qz = (m10 - m01) * t;
+    } else if (m00 >= m11 && m00 >= m22) {          // i = 0, j = 1, k = 2
+        t = sqrt(m00 - m11 - m22 + 1.0);
+        o.qx = 0.5 * t;
+        t = 0.5 / t;
+        o.qw = (m21 - m12) * t;
+        o.qy = (m10 + m01) * t;
+        o.qz = (m20 + m02) * t;
+    } else if (m11 > m00 && m11 >= m22) {           // i = 1, j = 2, k = 0
+        t = sqrt(m11 - m22 - m00 + 1.0);
+        o.qy = 0.5 * t;
+        t = 0.5 / t;
+        o.qw = (m02 - m20) * t;
+        o.qz = (m21 + m12) * t;
+        o.qx = (m01 + m10) * t;
+    } else {                                        // i = 2, j = 0, k = 1
+        t = sqrt(m22 - m00 - m11 + 1.0);
+        o.qz = 0.5 * t;
+        t = 0.5 / t;
+        o.qw = (m10 - m01) * t;
+        o.qx = (m02 + m20) * t;
+        o.qy = (m12 + m21) * t;
+    }
+    quat_normalize(o);
+    o.tx = T[3]; o.ty = T[7]; o.tz = T[11];
+    return o;
+}
+
+// quaternion -> rotation matrix (Eigen toRotationMatrix), row-major R[9]
+__device__ __forceinline__ void quat_to_matrix(const SE3d& q, double* R) {
+    const double tx = 2.0 * q.qx, ty = 2.0 * q.qy, tz = 2.0 * q.qz;
+    const double twx = tx * q.qw, twy = ty * q.qw, twz = tz * q.qw;
+    const double txx = tx * q.qx, txy = ty * q.qx, txz = tz * q.qx;
+    const double tyy = ty * q.qy, tyz = tz * q.qy, tzz = tz * q.qz;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+__device__ inline SE3d se3_mul(const SE3d& a, const SE3d& b) {
+    SE3d r;
+    double rx, ry, rz;
+    quat_rotate(a, b.tx, b.ty, b.tz, rx, ry, rz);
+    r.tx = a.tx + rx; r.ty = a.ty + ry; r.tz = a.tz + rz;
+    r.qw = a.qw * b.qw - a.qx * b.qx - a.qy * b.qy - a.qz * b.qz;
+    r.qx = a.qw * b.qx + a.qx * b.qw + a.qy * b.qz - a.qz * b.qy;
+    r.qy = a.qw * b.qy + a.qy * b.qw + a.qz * b.qx - a.qx * b.qz;
+    r.qz = a.qw * b.qz + a.qz * b.qw + a.qx * b.qy - a.qy * b.qx;
+    quat_normalize(r);
+    return r;
+}
+
+__device__ inline SE3d se3_inverse(const SE3d& a) {
+    SE3d r;
+    r.qw = a.qw; r.qx = -a.qx; r.qy = -a.qy; r.qz = -a.qz;
+    quat_rotate(r, -a.tx, -a.ty, -a.tz, r.tx, r.ty, r.tz);
+    return r;
+}
+
+// SE3::exp([upsilon, omega]) — Sophus: quaternion from half angle, V matrix for the translation
+__device__ inline SE3d se3_exp(const double* x) {
+    const double ux = x[0], uy = x[1], uz = x[2];
+    const double wx = x[3], wy = x[4], wz = x[5];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double half_theta = 0.5 * theta;
+    double imag_factor;
+    const double real_factor = cos(half_theta);
+    const bool small = theta < 1e-10;
+    if (small) {
+        const double theta_sq = theta * theta;
+        const double theta_po4 = theta_sq * theta_sq;
+        imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+    } else {
+        imag_factor = sin(half_theta) / theta;
+    }
+    SE3d o;
+    o.qw = real_factor;
+    o.qx = imag_factor * wx;
+    o.qy = imag_factor * wy;
+    o.qz = imag_factor * wz;
+    quat_normalize(o);
+    double V[9];
+    if (small) {
+        quat_to_matrix(o, V);
+    } else {
+        const double theta_sq = theta * theta;
+        const double a = (1.0 - cos(theta)) / theta_sq;
+        const double b = (theta - sin(theta)) / (theta_sq * theta);
+        // Omega = hat(omega); Omega^2 = omega omega^T - |omega|^2 I, written out as the matrix product
+        const double o00 = -wz * wz - wy * wy, o01 = wy * wx, o02 = wz * wx;
+        const double o10 = wx * wy, o11 = -wz * wz - wx * wx, o12 = wz * wy;
+        const double o20 = wx * wz, o21 = wy * wz, o22 = -wy * wy - wx * wx;
+        V[0] = 1.0 + b * o00;          V[1] = a * (-wz) + b * o01;   V[2] = a * wy + b * o02;
+        V[3] = a * wz + b * o10;       V[4] = 1.0 + b * o11;          V[5] = a * (-wx) + b * o12;
+        V[6] = a * (-wy) + b * o20;    V[7] = a * wx + b * o21;       V[8] = 1.0 + b * o22;
+    }
+    o.tx = V[0] * ux + V[1] * uy + V[2] * uz;
+    o.ty = V[3] * ux + V[4] * uy + V[5] * uz;
+    o.tz = V[6] * ux + V[7] * uy + V[8] * uz;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------
+// Eigen 3.2 LDLT<Matrix<double,6,6>,Lower>::compute + solve, fully unrolled so that every
+// matrix index is a compile-time constant (the matrix stays in VGPRs). The pivot row is a
+// wave-uniform value; `if (piv == P)` selects the statically indexed swap.
+// H is given as its 21 upper-triangular entries, row-major: (0,0),(0,1)..(0,5),(1,1)...
+// ---------------------------------------------------------------------------------------
+// lower-triangular packed storage: only (i >= j) is ever addressed
+#define DSDTM_M(i, j) m[((i) * ((i) + 1)) / 2 + (j)]
+
+template <int K, int P>
+__device__ __forceinline__ void ldlt_swap(double* m) {
+    // symmetric transposition K <-> P (P > K) on the lower triangle
+#pragma unroll
+    for (int j = 0; j < K; ++j) { double t = DSDTM_M(K, j); DSDTM_M(K, j) = DSDTM_M(P, j); DSDTM_M(P, j) = t; }
+#pragma unroll
+    for (int i = P + 1; i < 6; ++i) { double t = DSDTM_M(i, K); DSDTM_M(i, K) = DSDTM_M(i, P); DSDTM_M(i, P) = t; }
+    { double t = DSDTM_M(K, K); DSDTM_M(K, K) = DSDTM_M(P, P); DSDTM_M(P, P) = t; }
+#pragma unroll
+    for (int i = K + 1; i < P; ++i) { double t = DSDTM_M(i, K); DSDTM_M(i, K) = DSDTM_M(P, i); DSDTM_M(P, i) = t; }
+}
+
+template <int K, int P>
+__device__ __forceinline__ void ldlt_pivot_case(double* m, double* d, int piv) {
+    if constexpr (P < 6) {
+        const bool sw = (piv == P);
+        if (sw) ldlt_swap<K, P>(m);
+        // builds P*b incrementally; written as selects so that d[] keeps static indices (an
+        // if-cascade over the pivot is turned into a runtime-indexed scratch array by LLVM)
+        const double dk = d[K], dp = d[P];
+        d[K] = sw ? dp : dk;
+        d[P] = sw ? dk : dp;
+    }
+}
+
+// One elimination step; returns the chosen pivot row (K itself once the rank cutoff hit).
+template <int K>
+__device__ __forceinline__ int ldlt_step(double* m, double* d, double& cutoff, bool& done) {
+    if (done) return K;
+    int piv = K;
+    double big = fabs(DSDTM_M(K, K));
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) {
+        const double a = fabs(DSDTM_M(i, i));
+        if (a > big) { big = a; piv = i; }
+    }
+    if (K == 0) cutoff = fabs(2.220446049250313e-16 * big);
+    if (big < cutoff) { done = true; return K; }   // not full rank: remaining transpositions are identity
+    piv = __builtin_amdgcn_readfirstlane(piv);     // wave-uniform by construction
+    ldlt_pivot_case<K, K + 1>(m, d, piv);
+    ldlt_pivot_case<K, K + 2>(m, d, piv);
+    ldlt_pivot_case<K, K + 3>(m, d, piv);
+    ldlt_pivot_case<K, K + 4>(m, d, piv);
+    ldlt_pivot_case<K, K + 5>(m, d, piv);
+    if (K > 0) {
+        double temp[6];
+#pragma unroll
+        for (int j = 0; j < K; ++j) temp[j] = DSDTM_M(j, j) * DSDTM_M(K, j);
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) s += DSDTM_M(K, j) * temp[j];
+        DSDTM_M(K, K) -= s;
+#pragma unroll
+        for (int i = K + 1; i < 6; ++i) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) a += DSDTM_M(i, j) * temp[j];
+            DSDTM_M(i, K) -= a;
+        }
+    }
+    if (K < 5 && fabs(DSDTM_M(K, K)) > cutoff) {
+        const double dk = DSDTM_M(K, K);
+#pragma unroll
+        for (int i = K + 1; i < 6; ++i) DSDTM_M(i, K) /= dk;
+    }
+    return piv;
+}
+
+template <int K>
+__device__ __forceinline__ void ldlt_unswap(double* d, int trk) {
+#pragma unroll
+    for (int p = K + 1; p < 6; ++p) {
+        const bool sw = (trk == p);
+        const double dk = d[K], dp = d[p];
+        d[K] = sw ? dp : dk;
+        d[p] = sw ? dk : dp;
+    }
+}
+
+// x = H^+ b. Swapping d[K] <-> d[piv] at step K is exactly Eigen's `dst = m_transpositions * rhs`
+// (the later steps never touch d), so P*b is built while factorising; P^T replays the recorded
+// pivots in reverse at the end.
+__device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x) {
+    double m[21];
+    {   // lower triangle from the 21 upper-triangular entries (H is symmetric)
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) { DSDTM_M(j, i) = Hu[q]; ++q; }
+    }
+    double d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = b[i];
+
+    double cutoff = 0.0;
+    bool done = false;
+    const int tr0 = ldlt_step<0>(m, d, cutoff, done);
+    const int tr1 = ldlt_step<1>(m, d, cutoff, done);
+    const int tr2 = ldlt_step<2>(m, d, cutoff, done);
+    const int tr3 = ldlt_step<3>(m, d, cutoff, done);
+    const int tr4 = ldlt_step<4>(m, d, cutoff, done);
+    (void)ldlt_step<5>(m, d, cutoff, done);
+
+    // L^-1
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) s += DSDTM_M(i, j) * d[j];
+        d[i] -= s;
+    }
+    // D^+ (pseudo-inverse of the diagonal)
+    double maxd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) maxd = fmax(maxd, fabs(DSDTM_M(i, i)));
+    double tol = maxd * 2.220446049250313e-16;
+    tol = fmax(tol, 1.0 / 1.7976931348623157e308);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (fabs(DSDTM_M(i, i)) > tol) d[i] /= DSDTM_M(i, i);
+        else d[i] = 0.0;
+    }
+    // L^-T
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s += DSDTM_M(j, i) * d[j];
+        d[i] -= s;
+    }
+    // P^T
+    ldlt_unswap<4>(d, tr4);
+    ldlt_unswap<3>(d, tr3);
+    ldlt_unswap<2>(d, tr2);
+    ldlt_unswap<1>(d, tr1);
+    ldlt_unswap<0>(d, tr0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = d[i];
+}
+#undef DSDTM_M
+
+// ---------------------------------------------------------------------------------------
+// Wavefront (64 lanes) sum of a double with DPP moves on the two 32-bit halves:
+// row_ror 8/4/2/1 leaves every lane of a 16-lane row holding the row sum, then
+// row_bcast15 (rows 1,3) and row_bcast31 (rows 2,3) fold the rows: lane 63 holds the total.
+// ---------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+    v += dpp_f64<0x128, 0xf>(v);  // row_ror:8
+    v += dpp_f64<0x124, 0xf>(v);  // row_ror:4
+    v += dpp_f64<0x122, 0xf>(v);  // row_ror:2
+    v += dpp_f64<0x121, 0xf>(v);  // row_ror:1
+    v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// reference implementation of the same sum through the LDS crossbar (used by the self-test)
+__device__ __forceinline__ double wave_sum_shfl(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace dsdtm

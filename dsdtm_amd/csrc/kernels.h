@@ -1,0 +1,89 @@
+// kernels.h — launch-side declarations shared by the .hip kernels and api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dsdtm_amd.h"
+
+namespace dsdtm {
+
+struct LevelGeom {
+    int w, h, stride;
+    uint32_t off;   // byte offset of the level inside one packed pyramid
+};
+
+// Arguments of the sparse-alignment kernels (passed by value; all pointers are device pointers).
+struct SAKernelArgs {
+    const uint8_t* ref_pyr;
+    const uint8_t* cur_pyr;
+    const float* px_xy;
+    const double* bearing;
+    const double* p_world;
+    const uint8_t* initial;
+    const int32_t* n_features;
+    const double* T_ref_w;
+    double* T_cur_w;
+    int32_t* n_tracked;
+    dsdtm_align_stats* stats;
+    double* workspace;
+    unsigned long long pyr_pitch;
+    int n_pairs, max_features;
+    int max_level, min_level, max_iters, min_fts;
+    float fx, fy, cx, cy, f;
+    LevelGeom lv[DSDTM_MAX_LEVELS];
+};
+
+// storage type of the cached reference grid in the register-resident kernels (see sparse_align.hip)
+#ifndef SA_GRID_T
+#define SA_GRID_T double
+#endif
+#define DSDTM_STR2(x) #x
+#define DSDTM_STR(x) DSDTM_STR2(x)
+enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2 };
+SAVariant sparse_align_pick_variant(int max_features);
+size_t sparse_align_workspace_bytes(int n_pairs, int max_features);
+hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, hipStream_t stream);
+
+// Align2D: one wavefront per feature.
+struct A2DKernelArgs {
+    const uint8_t* cur_pyr;       // packed pyramid (device)
+    const uint8_t* patch_border;  // M x 100
+    const uint8_t* patch;         // M x 64
+    const int32_t* level;         // M
+    double* px_xy;                // M x 2 (in/out)
+    uint8_t* converged;           // M
+    int m, max_iters, levels;
+    LevelGeom lv[DSDTM_MAX_LEVELS];
+};
+hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream);
+
+// pyrDown: one launch per level over n_images packed pyramids.
+hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, int sh, int sstride,
+                          size_t soff, int dstride, size_t doff, hipStream_t stream);
+
+// Warp prelude: one 128-thread group per candidate (100 sample lanes).
+struct WarpKernelArgs {
+    const uint8_t* kf_pyr;        // n_kf packed pyramids, pitch kf_pitch
+    size_t kf_pitch;
+    const double* T_kf_w;         // n_kf x 12
+    const int32_t* cand_kf;
+    const float* ref_px;
+    const int32_t* ref_level;
+    const double* ref_bearing;
+    const double* p_world;
+    double* affine;               // M x 4
+    int32_t* search_level;        // M
+    uint8_t* patch_border;        // M x 100
+    uint8_t* patch;               // M x 64
+    double T_cur_w[12];
+    int m, n_kf, max_search_level, levels;
+    float fx, fy, cx, cy;
+    LevelGeom lv[DSDTM_MAX_LEVELS];
+};
+hipError_t warp_launch(const WarpKernelArgs& args, hipStream_t stream);
+
+// device self-test of the FP64 building blocks (wave reduction, LDLT, SE3); see selftest.hip
+hipError_t selftest_launch(const double* in, double* out, int n_cases, hipStream_t stream);
+
+}  // namespace dsdtm

@@ -1,0 +1,733 @@
+// sparse_align.hip — Sprase_ImgAlign::Run as ONE persistent workgroup per frame pair (gfx950).
+//
+// Replaces reference src/Sprase_ImageAlign.cpp:29-60 (Run), :62-166 (GetJocabianMat),
+// :169-193 (GetJocabianBA), :240-299 (ComputeResiduals), :301-344 (GaussNewtonSolver).
+//
+// MI355X design (not a translation of the CPU loops):
+//  * lane = patch. A 4x4 patch needs the 6x6 grid of bilinearly interpolated reference
+//    intensities around it (reference intensity + the neighbours its central-difference
+//    gradients use, :147-158): 32 live doubles per patch. In the register-resident variant
+//    they stay in the lane's VGPRs for the whole pyramid level — the register file (512 KB
+//    per CU) is the largest on-chip memory, so the "reference patch + Jacobian cache" of the
+//    CPU code (896 B/patch in mRefPatch/mJocabianPatch) never exists in memory at all.
+//  * inverse-compositional structure: J_px = dx*A + dy*B with A,B per patch (:160), so
+//      sum_px J J^T = Sxx A A^T + Sxy (A B^T + B A^T) + Syy B B^T     (per level constants)
+//      sum_px J r   = A * sum(dx r) + B * sum(dy r)
+//    H changes between Gauss-Newton iterations only when the set of visible patches does:
+//    each wave caches its H partial together with the 64-bit visibility ballot it was built
+//    for, and re-reduces the 21 entries only when the ballot changes. Per pixel the loop is
+//    4 bilinear FMAs + residual + 3 accumulations instead of the CPU's 36+6 MACs.
+//  * the 5x5 (cur) / 7x7 (ref) u8 footprints are fetched as aligned dwords straight from
+//    the packed pyramid in HBM/L2 (gather; nothing is re-read from memory inside a pass).
+//  * reductions: DPP row rotates + row broadcasts per wave (no LDS traffic), one LDS slot
+//    per wave. A dedicated SOLVER wave (the last wave of the workgroup, which owns no patches)
+//    runs the 6x6 pivoted LDLT, SE(3) exp and the accept/revert logic while the patch waves
+//    sleep on the barrier (their SIMD slots go to co-resident workgroups). Giving the solver
+//    its own control flow keeps the patch registers out of its live ranges and vice versa.
+//  * no host round trip inside an alignment: levels and iterations all run in this launch.
+//  * all decision-carrying arithmetic is FP64 (chi2 accept/revert compares values that
+//    differ in the 5th digit).
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dsdtm_amd.h"
+#include "device_math.h"
+#include "kernels.h"
+
+namespace dsdtm {
+
+// per-wave partial slot in LDS
+struct WavePartial {
+    double b[6];
+    double chi2;
+    int cnt;
+    int h_changed;
+    int n_ref;
+    int pad;
+    double H[21];
+};
+static_assert(offsetof(WavePartial, chi2) == 48 && offsetof(WavePartial, H) == 72, "solver_step indexes WavePartial as doubles");
+
+struct BlockState {
+    // solver-private state
+    double q[4], t[3];          // T_c2r
+    double qo[4], to[3];        // T_c2r before the last accepted step (tT_c2rOld)
+    double chi2;
+    double qr[4], tr[3];        // T_ref_w
+    double Hsum[21];            // sum of the per-wave H partials (valid while no wave's ballot changed)
+    double bsum[7];             // b totals + chi2 total of the current iteration
+    // published to the patch waves
+    double R[9], tt[3];         // rotation matrix + translation of T_c2r for the residual pass
+    double Cref[3];             // reference camera centre in world (Frame::mOw)
+    int ctrl;                   // 0 continue, 1 level finished
+    int n_vis;
+};
+
+__device__ __forceinline__ void store_se3(double* q, double* t, const SE3d& T) {
+    q[0] = T.qw; q[1] = T.qx; q[2] = T.qy; q[3] = T.qz;
+    t[0] = T.tx; t[1] = T.ty; t[2] = T.tz;
+}
+__device__ __forceinline__ SE3d load_se3(const double* q, const double* t) {
+    SE3d T;
+    T.qw = q[0]; T.qx = q[1]; T.qy = q[2]; T.qz = q[3];
+    T.tx = t[0]; T.ty = t[1]; T.tz = t[2];
+    return T;
+}
+
+// byte k (0..3) of a dword as double (v_cvt_f32_ubyteK + v_cvt_f64_f32; exact)
+__device__ __forceinline__ double ub(uint32_t w, int k) {
+    return (double)(float)((w >> (8 * k)) & 0xffu);
+}
+
+// Per-patch state that lives across the Gauss-Newton iterations of one level.
+// GT = storage type of the interpolated reference intensities (double = what the reference
+// caches in mRefPatch; float halves the register footprint, arithmetic stays FP64).
+template <typename GT>
+struct PatchRegs {
+    GT g[6][6];       // bilinear reference intensities on the 6x6 grid (corners unused)
+    double X[3];      // 3-D point in the reference camera: bearing * |P_w - C_ref| (:117-119)
+    bool valid;
+};
+
+// LLVM's LICM would hoist everything derived from the per-level patch state (the 32 gradient
+// differences, A/B, the 21 Hessian entries) out of the Gauss-Newton loop and keep it live in
+// VGPRs — several hundred bytes per lane, which is exactly the cache this kernel avoids. An empty
+// asm with a read-write VGPR operand makes the state opaque once per iteration (no instruction is
+// emitted), so derived values are recomputed where they are used.
+template <typename GT>
+__device__ __forceinline__ void pin_patch(PatchRegs<GT>& P) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if ((r == 0 || r == 5) && (c == 0 || c == 5)) continue;
+            asm volatile("" : "+v"(P.g[r][c]));
+        }
+    asm volatile("" : "+v"(P.X[0]), "+v"(P.X[1]), "+v"(P.X[2]));
+}
+
+// GetJocabianBA (:169-193) scaled by f*scale (:160; Camera.f, quirk Q1): the non-zero entries
+// of Jt.row(0)*fs = [a0,0,a1,a2,a3,a4] and Jt.row(1)*fs = [0,b0,b1,b2,b3,b4].
+__device__ __forceinline__ void patch_AB(double fs, const double* X, double* A, double* B) {
+    const double x = X[0], y = X[1];
+    const double z_inv = 1.0 / X[2];
+    const double z_inv2 = z_inv * z_inv;
+    const double j02 = x * z_inv2, j12 = y * z_inv2;
+    A[0] = -z_inv * fs;                  // J(0,0)
+    A[1] = j02 * fs;                     // J(0,2)
+    A[2] = y * j02 * fs;                 // J(0,3)
+    A[3] = -(1.0 + x * j02) * fs;        // J(0,4)
+    A[4] = y * z_inv * fs;               // J(0,5)
+    B[0] = -z_inv * fs;                  // J(1,1)
+    B[1] = j12 * fs;                     // J(1,2)
+    B[2] = (1.0 + y * j12) * fs;         // J(1,3)
+    B[3] = -x * j12 * fs;                // J(1,4)
+    B[4] = -x * z_inv * fs;              // J(1,5)
+}
+
+// GetJocabianMat for one feature (reference :84-162), producing the register-resident state.
+template <typename GT>
+__device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const LevelGeom& lg, int level,
+                                                 const uint8_t* __restrict__ ref_base,  // pair's ref pyramid
+                                                 size_t fidx, bool live, const double* Cref, PatchRegs<GT>& P) {
+    P.valid = false;
+    P.X[0] = P.X[1] = P.X[2] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) P.g[r][c] = (GT)0;
+    if (!live) return;
+    const float scale_f = 1.0f / (float)(1 << level);                  // :65 tScale (float)
+    const double scale = (double)scale_f;
+    if (!a.initial[fidx]) return;                                      // :86
+    const double px = (double)a.px_xy[2 * fidx] * scale;               // :89-91
+    const double py = (double)a.px_xy[2 * fidx + 1] * scale;
+    const double Pw0 = a.p_world[3 * fidx], Pw1 = a.p_world[3 * fidx + 1], Pw2 = a.p_world[3 * fidx + 2];
+    const bool is_zero = (Pw0 == 0.0 && Pw1 == 0.0 && Pw2 == 0.0);    // :95 isZero(0)
+    const double boarder = 3.0;                                        // :67 int(0.5*4+1)
+    if (is_zero || px - boarder < 0 || py - boarder < 0 || px + boarder >= (double)lg.w ||
+        py + boarder >= (double)lg.h || !(px == px) || !(py == py))
+        return;                                                        // :95-100
+    P.valid = true;
+    // :117-119
+    const double d0 = Pw0 - Cref[0], d1 = Pw1 - Cref[1], d2 = Pw2 - Cref[2];
+    const double depth = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    P.X[0] = a.bearing[3 * fidx] * depth;
+    P.X[1] = a.bearing[3 * fidx + 1] * depth;
+    P.X[2] = a.bearing[3 * fidx + 2] * depth;
+    // :123-132
+    const double fu_d = floor(px), fv_d = floor(py);
+    const int fu = (int)fu_d, fv = (int)fv_d;
+    const double su = px - fu_d, sv = py - fv_d;
+    const double omx = 1.0 - su, omy = 1.0 - sv;
+    const double w00 = omx * omy, w01 = su * omy, w10 = omx * sv, w11 = su * sv;
+
+    // 7x7 u8 footprint rows fv-3..fv+3, cols fu-3..fu+3, fetched as aligned dwords; the grid
+    // g[r][c] = bilinear value at pixel (fv-3+r, fu-3+c) + subpixel offset is built row by row.
+    // Patch pixel (i,k), i,k in 0..3, is g[i+1][k+1] (offsets -2..+1 from floor, quirk Q4); its
+    // gradient neighbours are g[i+1][k], g[i+1][k+2], g[i][k+1], g[i+2][k+1] (:150-158).
+    const uint32_t* __restrict__ img32 = (const uint32_t*)ref_base;
+    const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
+    double top[7], bot[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
+        const uint32_t dw = o >> 2;
+        const uint32_t sh = (o & 3u) * 8u;
+        const uint32_t w0 = img32[dw], w1 = img32[dw + 1];
+        const uint32_t w2 = img32[min(dw + 2, last_dw)];
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);     // bytes 0..3
+        const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);     // bytes 4..7
+        bot[0] = ub(lo, 0); bot[1] = ub(lo, 1); bot[2] = ub(lo, 2); bot[3] = ub(lo, 3);
+        bot[4] = ub(hi, 0); bot[5] = ub(hi, 1); bot[6] = ub(hi, 2);
+        if (r > 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                if ((r - 1 == 0 || r - 1 == 5) && (c == 0 || c == 5)) continue;
+                P.g[r - 1][c] = (GT)(w00 * top[c] + w01 * top[c + 1] + w10 * bot[c] + w11 * bot[c + 1]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 7; ++c) top[c] = bot[c];
+    }
+}
+
+// Per-patch Gauss-Newton matrix  Sxx A A^T + Sxy (A B^T + B A^T) + Syy B B^T  (upper triangle,
+// row-major index q). PatchHess holds the per-patch factors; entry<I,J>() evaluates one element so
+// that a caller can reduce the 21 entries one at a time without keeping all of them live.
+struct PatchHess {
+    double sxx, sxy, syy;
+    double A[6], B[6];
+    template <int I, int J>
+    __device__ __forceinline__ double entry() const {
+        return sxx * (A[I] * A[J]) + sxy * (A[I] * B[J] + B[I] * A[J]) + syy * (B[I] * B[J]);
+    }
+};
+
+template <typename GT>
+__device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs<GT>& P, double fs) {
+    PatchHess h;
+    double sxx = 0.0, sxy = 0.0, syy = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double dx = 0.5 * ((double)P.g[i + 1][k + 2] - (double)P.g[i + 1][k]);
+            const double dy = 0.5 * ((double)P.g[i + 2][k + 1] - (double)P.g[i][k + 1]);
+            sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+        }
+    h.sxx = sxx; h.sxy = sxy; h.syy = syy;
+    double A5[5], B5[5];
+    patch_AB(fs, P.X, A5, B5);
+    h.A[0] = A5[0]; h.A[1] = 0.0;   h.A[2] = A5[1]; h.A[3] = A5[2]; h.A[4] = A5[3]; h.A[5] = A5[4];
+    h.B[0] = 0.0;   h.B[1] = B5[0]; h.B[2] = B5[1]; h.B[3] = B5[2]; h.B[4] = B5[3]; h.B[5] = B5[4];
+    return h;
+}
+
+// calls f(q, value) for the 21 upper-triangular entries in row-major order
+template <int I, int J, typename F>
+__device__ __forceinline__ void patch_hess_foreach(const PatchHess& h, F&& f) {
+    f(I * 6 - (I * (I - 1)) / 2 + (J - I), h.entry<I, J>());
+    if constexpr (J < 5) patch_hess_foreach<I, J + 1>(h, f);
+    else if constexpr (I < 5) patch_hess_foreach<I + 1, I + 1>(h, f);
+}
+
+// ComputeResiduals for one patch (reference :252-296). Returns visibility; produces chi2 and
+// b = sum_px J*res (as A*gx + B*gy) of this patch.
+template <typename GT>
+__device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const LevelGeom& lg, double scale, double fs,
+                                               const uint8_t* __restrict__ cur_base, const PatchRegs<GT>& P,
+                                               const double* __restrict__ sR, const double* __restrict__ st,
+                                               double& chi2, double* b) {
+    chi2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = 0.0;
+    if (!P.valid) return false;
+    // :254 tT_c2r * X  (R, t are LDS broadcasts)
+    const double pxc = sR[0] * P.X[0] + sR[1] * P.X[1] + sR[2] * P.X[2] + st[0];
+    const double pyc = sR[3] * P.X[0] + sR[4] * P.X[1] + sR[5] * P.X[2] + st[1];
+    const double pzc = sR[6] * P.X[0] + sR[7] * P.X[1] + sR[8] * P.X[2] + st[2];
+    // Camera2Pixel (src/Camera.cpp:167-171), * tScale (:255)
+    const double u = ((double)a.fx * pxc / pzc + (double)a.cx) * scale;
+    const double v = ((double)a.fy * pyc / pzc + (double)a.cy) * scale;
+    // :262 with mnboarder = 3 on floored ints: floor(u) >= 3 && floor(u)+3 < cols (NaN fails)
+    if (!(u >= 3.0 && u < (double)(lg.w - 3) && v >= 3.0 && v < (double)(lg.h - 3))) return false;
+    const double fu_d = floor(u), fv_d = floor(v);
+    const int u_i = (int)fu_d, v_i = (int)fv_d;
+    const double su = u - fu_d, sv = v - fv_d;
+    const double tl = (1.0 - su) * (1.0 - sv);
+    const double trw = su * (1.0 - sv);
+    const double bl = (1.0 - su) * sv;
+    const double br = su * sv;
+
+    const uint32_t* __restrict__ img32 = (const uint32_t*)cur_base;
+    uint32_t wlo[5], whi[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const uint32_t o = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 2);
+        const uint32_t dw = o >> 2;
+        const uint32_t sh = (o & 3u) * 8u;
+        const uint32_t w0 = img32[dw], w1 = img32[dw + 1];
+        wlo[r] = __builtin_amdgcn_alignbit(w1, w0, sh);   // bytes 0..3 of the row
+        whi[r] = w1 >> sh;                                 // byte 4 in bits 0..7
+    }
+    double top[5], bot[5];
+    top[0] = ub(wlo[0], 0); top[1] = ub(wlo[0], 1); top[2] = ub(wlo[0], 2); top[3] = ub(wlo[0], 3); top[4] = ub(whi[0], 0);
+    double c2a = 0.0, c2b = 0.0, gxa = 0.0, gxb = 0.0, gya = 0.0, gyb = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bot[0] = ub(wlo[i + 1], 0); bot[1] = ub(wlo[i + 1], 1); bot[2] = ub(wlo[i + 1], 2);
+        bot[3] = ub(wlo[i + 1], 3); bot[4] = ub(whi[i + 1], 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double cur = tl * top[k] + trw * top[k + 1] + bl * bot[k] + br * bot[k + 1];   // :281
+            const double res = cur - (double)P.g[i + 1][k + 1];                                   // :282
+            const double ddx = (double)P.g[i + 1][k + 2] - (double)P.g[i + 1][k];      // 2*dx (:150)
+            const double ddy = (double)P.g[i + 2][k + 1] - (double)P.g[i][k + 1];      // 2*dy (:155)
+            if (k & 1) { c2b += res * res; gxb += ddx * res; gyb += ddy * res; }
+            else       { c2a += res * res; gxa += ddx * res; gya += ddy * res; }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) top[k] = bot[k];
+    }
+    chi2 = c2a + c2b;
+    // the 0.5 of the central difference commutes exactly with every rounding in the sums
+    const double gx = 0.5 * (gxa + gxb);
+    const double gy = 0.5 * (gya + gyb);
+    double A[5], B[5];
+    patch_AB(fs, P.X, A, B);
+    b[0] = A[0] * gx;                      // JRes += J*res (:291) with J = dx*A + dy*B
+    b[1] = B[0] * gy;
+    b[2] = A[1] * gx + B[1] * gy;
+    b[3] = A[2] * gx + B[2] * gy;
+    b[4] = A[3] * gx + B[3] * gy;
+    b[5] = A[4] * gx + B[4] * gy;
+    return true;
+}
+
+__device__ __forceinline__ void stats_clear(const SAKernelArgs& a, int pair) {
+    if (!a.stats) return;
+    dsdtm_align_stats* st = a.stats + pair;
+    for (int l = 0; l < DSDTM_MAX_LEVELS; ++l) {
+        st->iters[l] = 0; st->n_ref[l] = 0; st->n_vis[l] = 0; st->exit_code[l] = 0; st->chi2[l] = 0.0;
+    }
+}
+
+// Solver wave, prologue: mT_c2r = cur.pose * ref.pose^-1 (:43); C_ref = (T_ref_w^-1).translation
+// (Frame::Set_Pose, src/Frame.cpp:167-174).
+__device__ __forceinline__ void solver_init(const SAKernelArgs& a, int pair, BlockState& s, int lane) {
+    const SE3d Tc = se3_from_rt(a.T_cur_w + 12 * (size_t)pair);
+    const SE3d Tr = se3_from_rt(a.T_ref_w + 12 * (size_t)pair);
+    const SE3d Tri = se3_inverse(Tr);
+    const SE3d T = se3_mul(Tc, Tri);
+    double R[9];
+    quat_to_matrix(T, R);
+    if (lane == 0) {
+        store_se3(s.q, s.t, T);
+        store_se3(s.qo, s.to, T);
+        store_se3(s.qr, s.tr, Tr);
+        s.Cref[0] = Tri.tx; s.Cref[1] = Tri.ty; s.Cref[2] = Tri.tz;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s.R[i] = R[i];
+        s.tt[0] = T.tx; s.tt[1] = T.ty; s.tt[2] = T.tz;
+        s.chi2 = 0.0;
+        s.n_vis = 0;
+        s.ctrl = 0;
+        stats_clear(a, pair);
+    }
+}
+
+// Solver wave, one Gauss-Newton iteration (reference :310-343). Executed uniformly by all 64
+// lanes of the solver wave (same cost as one lane); lane 0 publishes. Returns ctrl.
+template <int NPW>
+__device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int level, int it,
+                                           const WavePartial* s_part, BlockState& s, int lane) {
+    // Cross-wave totals, lane-parallel: lane q<21 sums H[q], lanes 21..26 sum b, lane 27 chi2
+    // (fixed wave order -> deterministic). Totals go through LDS so that only the values the
+    // solve needs are ever live in registers.
+    int cnt = 0, changed = 0, n_ref = 0;
+#pragma unroll
+    for (int w = 0; w < NPW; ++w) {
+        cnt += s_part[w].cnt;
+        changed |= s_part[w].h_changed;
+        n_ref += s_part[w].n_ref;
+    }
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    changed = __builtin_amdgcn_readfirstlane(changed);
+    {
+        constexpr int WP = sizeof(WavePartial) / sizeof(double);
+        const double* base = (const double*)s_part;
+        // doubles inside WavePartial: b[0..5] at 0, chi2 at 6, H[] at 9 (after 4 ints)
+        const int off = lane < 21 ? (9 + lane) : (lane - 21);
+        if (lane < 28 && (changed || lane >= 21)) {
+            double acc = 0.0;
+#pragma unroll
+            for (int w = 0; w < NPW; ++w) acc += base[w * WP + off];
+            if (lane < 21) s.Hsum[lane] = acc;
+            else s.bsum[lane - 21] = acc;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double H[21], bs[6];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) H[i] = s.Hsum[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bs[i] = s.bsum[i];
+    const double chi2s = s.bsum[6];
+    const double chi2New = chi2s / (double)(16 * cnt);     // :298 (0/0 -> NaN)
+    double x[6];
+    ldlt6_solve(H, bs, x);                                 // :318
+    const bool stop = (x[0] != x[0]);                      // :321 isnan(x(0))
+    const double chi2_prev = s.chi2;
+    int ctrl = 0, exit_code = 0;
+    if ((it > 0 && chi2New > chi2_prev) || stop) {         // :328-332  tT_c2r = tT_c2rOld
+        const SE3d To = load_se3(s.qo, s.to);
+        double Rn[9];
+        quat_to_matrix(To, Rn);
+        if (lane == 0) {
+            store_se3(s.q, s.t, To);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s.R[i] = Rn[i];
+            s.tt[0] = To.tx; s.tt[1] = To.ty; s.tt[2] = To.tz;
+        }
+        ctrl = 1;
+        exit_code = stop ? 3 : 1;
+    } else {
+        const SE3d Tcur = load_se3(s.q, s.t);
+        const SE3d dT = se3_exp(x);
+        const SE3d Tn = se3_mul(Tcur, dT);                 // :335 right-multiply
+        double Rn[9];
+        quat_to_matrix(Tn, Rn);
+        double mx = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(x[i]));
+        if (lane == 0) {
+            store_se3(s.qo, s.to, Tcur);
+            store_se3(s.q, s.t, Tn);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s.R[i] = Rn[i];
+            s.tt[0] = Tn.tx; s.tt[1] = Tn.ty; s.tt[2] = Tn.tz;
+            s.chi2 = chi2New;
+        }
+        if (mx <= 1e-8) { ctrl = 1; exit_code = 2; }        // :341
+    }
+    ctrl = __builtin_amdgcn_readfirstlane(ctrl);
+    if (lane == 0) {
+        s.ctrl = ctrl;
+        s.n_vis = cnt;
+        if (a.stats && (ctrl || it == a.max_iters - 1)) {
+            dsdtm_align_stats* st = a.stats + pair;
+            st->iters[level] = it + 1;
+            st->n_ref[level] = n_ref;
+            st->n_vis[level] = cnt;
+            st->exit_code[level] = exit_code;
+            st->chi2[level] = (ctrl == 1 && exit_code != 2) ? chi2_prev : chi2New;
+        }
+    }
+    return ctrl;
+}
+
+// Solver wave, epilogue: tCurFrame->Set_Pose(mT_c2r * tRefFrame->Get_Pose()) (:57), return mnPts (:59)
+__device__ __forceinline__ void solver_finish(const SAKernelArgs& a, int pair, BlockState& s, int lane) {
+    const SE3d T = load_se3(s.q, s.t);
+    const SE3d Tr = load_se3(s.qr, s.tr);
+    const SE3d To = se3_mul(T, Tr);
+    double R[9];
+    quat_to_matrix(To, R);
+    if (lane == 0) {
+        double* out = a.T_cur_w + 12 * (size_t)pair;
+        out[0] = R[0]; out[1] = R[1]; out[2] = R[2];  out[3] = To.tx;
+        out[4] = R[3]; out[5] = R[4]; out[6] = R[5];  out[7] = To.ty;
+        out[8] = R[6]; out[9] = R[7]; out[10] = R[8]; out[11] = To.tz;
+        a.n_tracked[pair] = s.n_vis;
+    }
+}
+
+// Barrier protocol (every wave executes exactly the same number of s_barrier):
+//   B0                      after solver_init                      (patch waves may read Cref/R/t)
+//   per iteration: B1       partials of all patch waves are in LDS (solver may read them)
+//                  B2       solver has published R/t/ctrl           (patch waves may read them)
+// The solver rewrites R/t/ctrl only after the next B1, which every patch wave reaches only after
+// it has read them, so no further barriers are needed at level boundaries.
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident kernel: NPW patch waves (one patch per lane, NPW*64 >= n_features) + 1 solver
+// wave.
+// ---------------------------------------------------------------------------------------------
+template <int NPW, typename GT>
+__global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const SAKernelArgs a) {
+    __shared__ WavePartial s_part[NPW];
+    __shared__ BlockState s;
+
+    const int pair = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nf = a.n_features ? a.n_features[pair] : a.max_features;
+
+    // Run(): "Too few features to track" (:34-38) -> return 0, pose untouched
+    if (nf < a.min_fts || a.max_level - 1 < a.min_level) {
+        if (tid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
+        return;
+    }
+
+    if (wave == NPW) {
+        // ------------------------------ solver wave ------------------------------
+        solver_init(a, pair, s, lane);
+        __syncthreads();                                               // B0
+        for (int level = a.max_level - 1; level >= a.min_level; --level) {
+            if (lane == 0) {                                           // GaussNewtonSolver entry (:304-308)
+                s.chi2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.qo[i] = s.q[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) s.to[i] = s.t[i];
+            }
+            for (int it = 0; it < a.max_iters; ++it) {
+                __syncthreads();                                       // B1
+                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane);
+                __syncthreads();                                       // B2
+                if (ctrl) break;
+            }
+        }
+        solver_finish(a, pair, s, lane);
+        return;
+    }
+
+    // ---------------------------------- patch waves ----------------------------------
+    const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
+    const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
+    const size_t fidx = (size_t)pair * a.max_features + tid;
+    const bool live = tid < nf;
+    __syncthreads();                                                   // B0
+
+    for (int level = a.max_level - 1; level >= a.min_level; --level) {
+        const LevelGeom lg = a.lv[level];
+        const double scale = (double)(1.0f / (float)(1 << level));
+        const double fs = (double)a.f * scale;
+        PatchRegs<GT> P;
+        {
+            const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
+            precompute_patch<GT>(a, lg, level, ref_base, fidx, live, Cref, P);
+        }
+        const int n_ref_wave = __popcll(__ballot(P.valid));
+        unsigned long long cached_mask = 0ull;
+        bool first = true;   // forces the first H reduction of the level
+
+        for (int it = 0; it < a.max_iters; ++it) {
+            double chi2, b[6];
+            pin_patch(P);
+            const bool vis = residual_patch<GT>(a, lg, scale, fs, cur_base, P, s.R, s.tt, chi2, b);
+            const unsigned long long vmask = __ballot(vis);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b[i] = wave_sum_to_lane63(b[i]);
+            chi2 = wave_sum_to_lane63(chi2);
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s_part[wave].b[i] = b[i];
+                s_part[wave].chi2 = chi2;
+                s_part[wave].cnt = __popcll(vmask);
+                s_part[wave].n_ref = n_ref_wave;
+            }
+            const bool h_changed = first || (vmask != cached_mask);   // wave-uniform
+            if (h_changed) {
+                const PatchHess ph = patch_hess_factors<GT>(P, fs);
+                double* Hout = s_part[wave].H;
+                patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
+                    const double hs = wave_sum_to_lane63(vis ? v : 0.0);
+                    if (lane == 63) Hout[q] = hs;
+                    __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
+                });
+                cached_mask = vmask;
+                first = false;
+            }
+            if (lane == 63) s_part[wave].h_changed = h_changed ? 1 : 0;
+            __syncthreads();                                           // B1
+            __syncthreads();                                           // B2
+            if (s.ctrl) break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel for any feature count: each lane of the NPW patch waves loops over patches
+// p = tid, tid + NPW*64, ...; the per-patch state is parked in an HBM workspace laid out
+// [slot][patch] so that the lanes of a wave read consecutive doubles (coalesced 512-B rows).
+// ---------------------------------------------------------------------------------------------
+constexpr int WS_SLOTS = 35;   // 32 grid values + X3
+__host__ __device__ inline size_t ws_doubles_per_pair(int max_features) {
+    const size_t npad = ((size_t)max_features + 63) / 64 * 64;
+    return npad * WS_SLOTS;
+}
+
+__device__ __forceinline__ void ws_store(double* __restrict__ ws, size_t npad, int p, const PatchRegs<double>& P) {
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if ((r == 0 || r == 5) && (c == 0 || c == 5)) continue;
+            ws[(size_t)q * npad + p] = P.g[r][c];
+            ++q;
+        }
+    // invalid patches are parked with a NaN depth
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        ws[(size_t)(32 + i) * npad + p] = P.valid ? P.X[i] : __longlong_as_double(0x7ff8000000000000ll);
+}
+
+__device__ __forceinline__ void ws_load(const double* __restrict__ ws, size_t npad, int p, PatchRegs<double>& P) {
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if ((r == 0 || r == 5) && (c == 0 || c == 5)) { P.g[r][c] = 0.0; continue; }
+            P.g[r][c] = ws[(size_t)q * npad + p];
+            ++q;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P.X[i] = ws[(size_t)(32 + i) * npad + p];
+    P.valid = (P.X[2] == P.X[2]);
+}
+
+template <int NPW>
+__global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const SAKernelArgs a) {
+    constexpr int PT = NPW * 64;   // patch threads
+    __shared__ WavePartial s_part[NPW];
+    __shared__ BlockState s;
+
+    const int pair = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nf = a.n_features ? a.n_features[pair] : a.max_features;
+
+    if (nf < a.min_fts || a.max_level - 1 < a.min_level) {
+        if (tid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
+        return;
+    }
+
+    if (wave == NPW) {
+        solver_init(a, pair, s, lane);
+        __syncthreads();                                               // B0
+        for (int level = a.max_level - 1; level >= a.min_level; --level) {
+            if (lane == 0) {
+                s.chi2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.qo[i] = s.q[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) s.to[i] = s.t[i];
+            }
+            for (int it = 0; it < a.max_iters; ++it) {
+                __syncthreads();                                       // B1
+                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane);
+                __syncthreads();                                       // B2
+                if (ctrl) break;
+            }
+        }
+        solver_finish(a, pair, s, lane);
+        return;
+    }
+
+    const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
+    const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
+    const size_t npad = ((size_t)a.max_features + 63) / 64 * 64;
+    double* __restrict__ ws = a.workspace + (size_t)pair * ws_doubles_per_pair(a.max_features);
+    __syncthreads();                                                   // B0
+
+    for (int level = a.max_level - 1; level >= a.min_level; --level) {
+        const LevelGeom lg = a.lv[level];
+        const double scale = (double)(1.0f / (float)(1 << level));
+        const double fs = (double)a.f * scale;
+        int n_valid_lane = 0;
+        {
+            const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
+            for (int p = tid; p < (int)npad; p += PT) {
+                PatchRegs<double> P;
+                precompute_patch<double>(a, lg, level, ref_base, (size_t)pair * a.max_features + p, p < nf, Cref, P);
+                ws_store(ws, npad, p, P);          // read back only by this same thread
+                n_valid_lane += P.valid ? 1 : 0;
+            }
+        }
+        const int n_ref_wave = (int)wave_sum_to_lane63((double)n_valid_lane);   // valid in lane 63
+
+        for (int it = 0; it < a.max_iters; ++it) {
+            double b[6] = {0, 0, 0, 0, 0, 0};
+            double H[21];
+#pragma unroll
+            for (int i = 0; i < 21; ++i) H[i] = 0.0;
+            double chi2 = 0.0;
+            int cnt = 0;
+            for (int p = tid; p < (int)npad; p += PT) {
+                PatchRegs<double> P;
+                ws_load(ws, npad, p, P);
+                double c2, bp[6];
+                const bool vis = residual_patch<double>(a, lg, scale, fs, cur_base, P, s.R, s.tt, c2, bp);
+                if (vis) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) b[i] += bp[i];
+                    chi2 += c2;
+                    cnt += 1;
+                    const PatchHess ph = patch_hess_factors<double>(P, fs);
+                    patch_hess_foreach<0, 0>(ph, [&](int q, double v) { H[q] += v; });
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b[i] = wave_sum_to_lane63(b[i]);
+#pragma unroll
+            for (int i = 0; i < 21; ++i) H[i] = wave_sum_to_lane63(H[i]);
+            chi2 = wave_sum_to_lane63(chi2);
+            const double cntd = wave_sum_to_lane63((double)cnt);
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s_part[wave].b[i] = b[i];
+#pragma unroll
+                for (int i = 0; i < 21; ++i) s_part[wave].H[i] = H[i];
+                s_part[wave].chi2 = chi2;
+                s_part[wave].cnt = (int)cntd;
+                s_part[wave].n_ref = n_ref_wave;
+                s_part[wave].h_changed = 1;
+            }
+            __syncthreads();                                           // B1
+            __syncthreads();                                           // B2
+            if (s.ctrl) break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+SAVariant sparse_align_pick_variant(int max_features) {
+    if (max_features <= 320) return SA_REG320;
+    if (max_features <= 448) return SA_REG448;
+    return SA_WS;
+}
+
+size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
+    if (sparse_align_pick_variant(max_features) != SA_WS) return 0;
+    return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
+}
+
+hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, hipStream_t stream) {
+    if (args.n_pairs <= 0) return hipSuccess;
+    const dim3 grid((unsigned)args.n_pairs);
+    switch (variant) {
+        case SA_REG320:
+            hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T>), grid, dim3(6 * 64), 0, stream, args);
+            break;
+        case SA_REG448:
+            hipLaunchKernelGGL((sparse_align_reg_kernel<7, SA_GRID_T>), grid, dim3(8 * 64), 0, stream, args);
+            break;
+        case SA_WS:
+            hipLaunchKernelGGL((sparse_align_ws_kernel<7>), grid, dim3(8 * 64), 0, stream, args);
+            break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dsdtm

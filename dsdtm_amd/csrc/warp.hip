@@ -1,0 +1,124 @@
+// warp.hip — warp prelude of Feature_Alignment::FindMatchDirect for M candidates at once.
+//
+// Replaces reference src/Feature_alignment.cpp:160-190 (SolveAffineMatrix), :192-204
+// (GetBestSearchLevel), :206-259 (WarpAffine), :261-275 (GetPatchNoBoarder), including the
+// integer-division quirk W1 (`1/(1<<lvl)` is 0 for lvl>=1, :231) and the float->u8 truncation.
+// One 128-thread group per candidate: the 2x2 affine is evaluated in FP64 by every lane
+// (wave-uniform), lanes 0..99 each produce one sample of the 10x10 bordered patch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+#include "kernels.h"
+
+namespace dsdtm {
+
+__device__ __forceinline__ void cam2px(const WarpKernelArgs& a, double x, double y, double z, double& u, double& v) {
+    u = (double)a.fx * x / z + (double)a.cx;          // src/Camera.cpp:167-171
+    v = (double)a.fy * y / z + (double)a.cy;
+}
+
+__global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.x;
+    if (c >= a.m) return;
+    const int j = threadIdx.x;
+    const int k = a.cand_kf[c];
+    const int tLevel = a.ref_level[c];
+    if (k < 0 || k >= a.n_kf || tLevel < 0 || tLevel >= a.levels) {
+        if (j == 0) a.search_level[c] = -1;
+        if (j < 100) a.patch_border[(size_t)c * 100 + j] = 0;
+        if (j < 64) a.patch[(size_t)c * 64 + j] = 0;
+        return;
+    }
+    // ---- SolveAffineMatrix (:160-190) ----
+    const SE3d Tcur = se3_from_rt(a.T_cur_w);
+    const SE3d Tkf = se3_from_rt(a.T_kf_w + 12 * (size_t)k);
+    const SE3d Tki = se3_inverse(Tkf);
+    const double* P = a.p_world + 3 * (size_t)c;
+    const double* nb = a.ref_bearing + 3 * (size_t)c;
+    const double d0 = Tki.tx - P[0], d1 = Tki.ty - P[1], d2 = Tki.tz - P[2];
+    const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    const double rp0 = dist * nb[0], rp1 = dist * nb[1], rp2 = dist * nb[2];          // :167
+    const float rx = a.ref_px[2 * (size_t)c], ry = a.ref_px[2 * (size_t)c + 1];
+    const int HPL = 5;
+    const double pxU0 = (double)(rx + (float)(HPL * (1 << tLevel))), pxU1 = (double)ry;   // :171
+    const double pxV0 = (double)rx, pxV1 = (double)(ry + (float)(HPL * (1 << tLevel)));  // :172
+    // Pixel2Camera(Vector2d, 1.0f) (src/Camera.cpp:180-185), normalise, rescale to the ref depth
+    double U0 = 1.0f * (pxU0 - (double)a.cx) / (double)a.fx, U1 = 1.0f * (pxU1 - (double)a.cy) / (double)a.fy, U2 = 1.0;
+    double V0 = 1.0f * (pxV0 - (double)a.cx) / (double)a.fx, V1 = 1.0f * (pxV1 - (double)a.cy) / (double)a.fy, V2 = 1.0;
+    {
+        const double nU = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
+        U0 /= nU; U1 /= nU; U2 /= nU;
+        const double nV = sqrt(V0 * V0 + V1 * V1 + V2 * V2);
+        V0 /= nV; V1 /= nV; V2 /= nV;
+        const double sU = rp2 / U2, sV = rp2 / V2;
+        U0 *= sU; U1 *= sU; U2 *= sU;
+        V0 *= sV; V1 *= sV; V2 *= sV;
+    }
+    const SE3d Tc2r = se3_mul(Tcur, Tki);                                              // :181
+    double q0x, q0y, q0z, qUx, qUy, qUz, qVx, qVy, qVz;
+    quat_rotate(Tc2r, rp0, rp1, rp2, q0x, q0y, q0z); q0x += Tc2r.tx; q0y += Tc2r.ty; q0z += Tc2r.tz;
+    quat_rotate(Tc2r, U0, U1, U2, qUx, qUy, qUz);    qUx += Tc2r.tx; qUy += Tc2r.ty; qUz += Tc2r.tz;
+    quat_rotate(Tc2r, V0, V1, V2, qVx, qVy, qVz);    qVx += Tc2r.tx; qVy += Tc2r.ty; qVz += Tc2r.tz;
+    double c0u, c0v, cUu, cUv, cVu, cVv;
+    cam2px(a, q0x, q0y, q0z, c0u, c0v);
+    cam2px(a, qUx, qUy, qUz, cUu, cUv);
+    cam2px(a, qVx, qVy, qVz, cVu, cVv);
+    const double A00 = (cUu - c0u) / HPL, A10 = (cUv - c0v) / HPL;                     // :186
+    const double A01 = (cVu - c0u) / HPL, A11 = (cVv - c0v) / HPL;                     // :187
+    // ---- GetBestSearchLevel (:192-204) ----
+    int sl = 0;
+    double D = A00 * A11 - A01 * A10;
+    while (D > 3.0 && sl < a.max_search_level) { sl++; D = D * 0.25; }
+    if (j == 0) {
+        if (a.affine) {
+            double* o = a.affine + 4 * (size_t)c;
+            o[0] = A00; o[1] = A01; o[2] = A10; o[3] = A11;
+        }
+        a.search_level[c] = sl;
+    }
+    if (j >= 100) return;
+    // ---- WarpAffine (:206-259) ----
+    const double det = A00 * A11 - A01 * A10;
+    const double invdet = 1.0 / det;
+    const float Ai0 = (float)(A11 * invdet), Ai1 = (float)(-A01 * invdet);
+    const float Ai2 = (float)(-A10 * invdet), Ai3 = (float)(A00 * invdet);
+    const LevelGeom lg = a.lv[tLevel];
+    const uint8_t* __restrict__ img = a.kf_pyr + (size_t)k * a.kf_pitch + lg.off;
+    const float refx = rx / (float)(1 << tLevel), refy = ry / (float)(1 << tLevel);     // :215-216
+    const int int_scale = 1 / (1 << sl);                                                // :231 quirk W1
+    const int ix = (j % 10) - 5, iy = (j / 10) - 5;
+    const float gx = (Ai0 * (float)ix + Ai1 * (float)iy) * (float)int_scale;
+    const float gy = (Ai2 * (float)ix + Ai3 * (float)iy) * (float)int_scale;
+    const float wx = gx + refx, wy = gy + refy;                                         // :232
+    uint8_t outv = 0;
+    if (!(wx != wx) && !(wy != wy) && !(wx < 0) && !(wy < 0) && !(wx > (float)(lg.w - 1)) && !(wy > (float)(lg.h - 1))) {
+        const int fx_ = (int)floor((double)wx), fy_ = (int)floor((double)wy);
+        const float sx = wx - (float)fx_, sy = wy - (float)fy_;
+        const float omx = 1.0f - sx, omy = 1.0f - sy;
+        const float w00 = omx * omy;
+        const float w01 = omx * sy;                                                     // :242
+        const float w10 = sx * omy;                                                     // :243
+        const float w11 = 1.0f - w00 - w01 - w10;                                       // :244
+        const int sz = lg.stride * lg.h, o = lg.stride * fy_ + fx_;
+        const float p00 = (float)img[o];
+        const float p01 = (o + lg.stride < sz) ? (float)img[o + lg.stride] : 0.0f;
+        const float p10 = (o + 1 < sz) ? (float)img[o + 1] : 0.0f;
+        const float p11 = (o + lg.stride + 1 < sz) ? (float)img[o + lg.stride + 1] : 0.0f;
+        const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;                // :254
+        outv = (uint8_t)(int)val;                                                       // truncation
+    }
+    a.patch_border[(size_t)c * 100 + j] = outv;
+    // ---- GetPatchNoBoarder (:261-275) ----
+    const int r = j / 10, cc = j % 10;
+    if (r >= 1 && r <= 8 && cc >= 1 && cc <= 8) a.patch[(size_t)c * 64 + (r - 1) * 8 + (cc - 1)] = outv;
+}
+
+hipError_t warp_launch(const WarpKernelArgs& args, hipStream_t stream) {
+    if (args.m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)args.m), dim3(128), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace dsdtm

@@ -1,0 +1,259 @@
+/*
+ * dsdtm_amd.h — C ABI of the MI355X (gfx950) sparse photometric alignment path.
+ *
+ * This is the drop-in boundary for ONE hot path of gaochq/DSDTM:
+ *   - DSDTM::Sprase_ImgAlign::Run            (reference src/Sprase_ImageAlign.cpp:29-60)
+ *   - DSDTM::Feature_Alignment::Align2DGaussNewton (reference src/Feature_alignment.cpp:318-417)
+ *   - the producers/consumers either side of it that SURVEY.md §8(f) marks "next":
+ *     Frame::ComputeImagePyramid (src/Frame.cpp:74-81) and the warp prelude of
+ *     Feature_Alignment::FindMatchDirect (src/Feature_alignment.cpp:128-275).
+ *
+ * The reference has no FFI layer: the boundary there is two C++ classes used by
+ * Tracking through raw pointers (include/Tracking.h:149-150).  A maintainer binds these
+ * entry points from thin adapter classes that keep the reference signatures
+ * (INTEGRATION.md shows the adapter).  Everything here is POD: plain pointers and
+ * sizes, caller-owned memory, `int` status returns, no exceptions, no globals.
+ * Thread-compatible, not thread-safe: one dsdtm_ctx per calling thread (the
+ * reference classes are only ever called from the tracking thread).
+ *
+ * All "host" entry points take host pointers, stage through pinned memory and run
+ * the HIP kernels; all "_device" entry points take device pointers that are already
+ * resident in HBM and only enqueue kernels on the given hipStream_t.
+ * There is NO CPU fallback: without a usable gfx950 device every compute entry
+ * point returns DSDTM_ERR_NO_DEVICE.
+ */
+#ifndef DSDTM_AMD_H
+#define DSDTM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSDTM_MAX_LEVELS 8
+
+/* status codes (the reference has no error codes: Run returns 0 on "too few
+ * features", src/Sprase_ImageAlign.cpp:34-38; that case is status DSDTM_OK with
+ * *n_tracked == 0 and the pose untouched) */
+enum {
+    DSDTM_OK = 0,
+    DSDTM_ERR_NO_DEVICE = -1, /* no HIP device / wrong arch / HIP runtime missing */
+    DSDTM_ERR_INVALID = -2,   /* bad argument (null pointer, bad level range, ...) */
+    DSDTM_ERR_HIP = -3,       /* a HIP call failed; see dsdtm_last_error()        */
+    DSDTM_ERR_NOMEM = -4
+};
+
+/* Pinhole intrinsics. The reference stores them as *float* members and promotes
+ * at use (include/Camera.h:138-142); `f` is the single focal `Camera.f` used for
+ * the Jacobian scale (src/Sprase_ImageAlign.cpp:70,160) while fx,fy project
+ * (src/Camera.cpp:167-171). width/height are the level-0 image size
+ * (Camera::IsInImage, src/Camera.cpp:187-193). */
+typedef struct dsdtm_camera {
+    float fx, fy, cx, cy, f;
+    int width, height;
+} dsdtm_camera;
+
+/* One image pyramid = Frame::mvImg_Pyr (include/Frame.h, src/Frame.cpp:74-81):
+ * u8 single channel, level 0 first. stride in bytes (cv::Mat::step). */
+typedef struct dsdtm_pyramid {
+    int levels;
+    const uint8_t* data[DSDTM_MAX_LEVELS];
+    int width[DSDTM_MAX_LEVELS];
+    int height[DSDTM_MAX_LEVELS];
+    int stride[DSDTM_MAX_LEVELS];
+} dsdtm_pyramid;
+
+/* Constructor arguments of Sprase_ImgAlign(int tMaxLevel,int tMinLevel,int tMaxIterators)
+ * (src/Sprase_ImageAlign.cpp:10-15) + Config "Camera.Min_fts" (:14).
+ * Levels max_level-1 ... min_level are processed coarse to fine (:45). */
+typedef struct dsdtm_align_params {
+    int max_level;
+    int min_level;
+    int max_iters;
+    int min_fts;
+} dsdtm_align_params;
+
+/* Optional per-alignment diagnostics (the reference only prints; these make the
+ * executed-iteration counts and the accept/revert decisions testable). Index = pyramid level. */
+typedef struct dsdtm_align_stats {
+    int32_t iters[DSDTM_MAX_LEVELS];    /* executed ComputeResiduals calls at that level          */
+    int32_t n_ref[DSDTM_MAX_LEVELS];    /* patches that passed the reference-side checks (:86-100) */
+    int32_t n_vis[DSDTM_MAX_LEVELS];    /* visible patches in the last ComputeResiduals call       */
+    int32_t exit_code[DSDTM_MAX_LEVELS];/* 0 cap reached, 1 chi2 increased -> revert, 2 |x|<=eps, 3 NaN guard */
+    double chi2[DSDTM_MAX_LEVELS];      /* chi2 of the last accepted step at that level            */
+} dsdtm_align_stats;
+
+typedef struct dsdtm_ctx dsdtm_ctx;
+
+/* ---- context ------------------------------------------------------------------- */
+/* device = HIP device ordinal. Fails with DSDTM_ERR_NO_DEVICE when none is usable. */
+int dsdtm_create(int device, dsdtm_ctx** out);
+void dsdtm_destroy(dsdtm_ctx* ctx);
+/* Last error text of this context (or of the failed dsdtm_create when ctx==NULL). */
+const char* dsdtm_last_error(const dsdtm_ctx* ctx);
+/* Library version / build info: "dsdtm_amd <ver> gfx950 ..." */
+const char* dsdtm_version(void);
+/* Number of visible HIP devices, or a negative status. Does not create a context. */
+int dsdtm_device_count(void);
+
+/* ---- Sprase_ImgAlign::Run ------------------------------------------------------ */
+/*
+ * Replaces: int Sprase_ImgAlign::Run(FramePtr tCurFrame, FramePtr tRefFrame)
+ *           (include/Sprase_ImageAlign.h:29, src/Sprase_ImageAlign.cpp:29-60), with its
+ *           callees GetJocabianMat :62-166, GetJocabianBA :169-193, ComputeResiduals
+ *           :240-299, GaussNewtonSolver :301-344.
+ *
+ * ref/cur     : pyramids of tRefFrame / tCurFrame (host memory)
+ * px_xy       : n_features x 2 float  — Feature::mpx        (include/Feature.h:19)
+ * bearing     : n_features x 3 double — Feature::mNormal    (include/Feature.h:24)
+ * p_world     : n_features x 3 double — Feature::Mpt->Get_Pose() (src/MapPoint.cpp:38-43);
+ *               ignored (may be anything) where initial[i]==0
+ * initial     : n_features x u8       — Feature::mbInitial  (include/Feature.h:23)
+ * T_ref_w     : tRefFrame->Get_Pose() as 3x4 row-major [R|t] (world -> ref camera)
+ * T_cur_w     : in: tCurFrame->Get_Pose() (the seed); out: the pose Run passes to
+ *               tCurFrame->Set_Pose (:57). Untouched when *n_tracked==0 by the Min_fts rule.
+ * n_tracked   : Run's return value (:59)
+ * stats       : optional (may be NULL)
+ */
+int dsdtm_sparse_align(dsdtm_ctx* ctx,
+                       const dsdtm_pyramid* ref, const dsdtm_pyramid* cur,
+                       const dsdtm_camera* cam,
+                       const float* px_xy, const double* bearing, const double* p_world,
+                       const uint8_t* initial, int n_features,
+                       const double T_ref_w[12], double T_cur_w[12],
+                       const dsdtm_align_params* params,
+                       int* n_tracked, dsdtm_align_stats* stats);
+
+/*
+ * Batched, device-resident form: n_pairs independent frame pairs that share camera,
+ * pyramid geometry and parameters (BASELINE config 4: embarrassingly parallel pairs).
+ * Every pointer is a DEVICE pointer. Pyramids are packed: pair i's reference pyramid
+ * starts at ref_pyr + i*pyr_pitch, level l at + level_offset[l], rows `stride[l]` bytes
+ * apart. pyr_pitch and every level_offset must be multiples of 4 and each pyramid
+ * allocation must extend to a multiple of 4 bytes (the kernels fetch aligned dwords).
+ * Features are padded to `max_features` per pair; n_features[i] (device, may be NULL
+ * => all pairs use max_features) gives the live count of pair i.
+ */
+typedef struct dsdtm_batch_desc {
+    int n_pairs;
+    int max_features;
+    int levels;
+    int width[DSDTM_MAX_LEVELS];
+    int height[DSDTM_MAX_LEVELS];
+    int stride[DSDTM_MAX_LEVELS];
+    size_t level_offset[DSDTM_MAX_LEVELS];
+    size_t pyr_pitch;
+    const uint8_t* ref_pyr;   /* n_pairs * pyr_pitch                    */
+    const uint8_t* cur_pyr;   /* n_pairs * pyr_pitch                    */
+    const float* px_xy;       /* n_pairs * max_features * 2             */
+    const double* bearing;    /* n_pairs * max_features * 3             */
+    const double* p_world;    /* n_pairs * max_features * 3             */
+    const uint8_t* initial;   /* n_pairs * max_features                 */
+    const int32_t* n_features;/* n_pairs, or NULL                       */
+    const double* T_ref_w;    /* n_pairs * 12                           */
+    double* T_cur_w;          /* n_pairs * 12, in: seed, out: result    */
+    int32_t* n_tracked;       /* n_pairs                                */
+    dsdtm_align_stats* stats; /* n_pairs, or NULL                       */
+} dsdtm_batch_desc;
+
+/* Enqueues the alignment of all pairs on `hip_stream` (a hipStream_t, NULL = default
+ * stream). Asynchronous: results are valid after the stream is synchronised. */
+int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* batch,
+                                    const dsdtm_camera* cam, const dsdtm_align_params* params,
+                                    void* hip_stream);
+
+/* Bytes of scratch HBM the batch call needs for `batch` (0 when the register-resident
+ * kernel applies). The context grows its own workspace on demand OUTSIDE stream capture;
+ * call dsdtm_reserve first when the launch is to be captured into a hipGraph. */
+size_t dsdtm_sparse_align_workspace_bytes(const dsdtm_batch_desc* batch);
+int dsdtm_reserve(dsdtm_ctx* ctx, size_t workspace_bytes);
+
+/* ---- Feature_Alignment::Align2DGaussNewton ------------------------------------- */
+/*
+ * Replaces: static bool Feature_Alignment::Align2DGaussNewton(const cv::Mat& tCurImg,
+ *           uchar* tPatch_WithBoarder, uchar* tPatch, int MaxIters, Eigen::Vector2d& tCurPx)
+ *           (include/Feature_alignment.h:85, src/Feature_alignment.cpp:318-417)
+ * for M independent features at once (the speculative form SearchLocalPoints needs,
+ * SURVEY.md §7 "Sequential semantics of SearchLocalPoints").
+ *
+ * cur          : pyramid of the current frame (host)
+ * patch_border : M x 100 u8  (10x10 bordered reference patch, mPatch_WithBoarder)
+ * patch        : M x 64  u8  (8x8 reference patch, mPatch)
+ * level        : M           search level of each feature (image = cur level[level[i]])
+ * px_xy        : M x 2 double, in level coordinates; in: start, out: result. Written back
+ *                even when not converged (NaN included), as the reference does (:414).
+ * converged    : M x u8      the bool the reference returns
+ */
+int dsdtm_align2d_batch(dsdtm_ctx* ctx, const dsdtm_pyramid* cur,
+                        const uint8_t* patch_border, const uint8_t* patch,
+                        const int32_t* level, double* px_xy, uint8_t* converged,
+                        int max_iters, int m);
+
+/* Device-resident form. cur_pyr is one packed pyramid (same packing rules as the batch
+ * descriptor above: level l at cur_pyr + level_offset[l]). */
+typedef struct dsdtm_image_desc {
+    int levels;
+    int width[DSDTM_MAX_LEVELS];
+    int height[DSDTM_MAX_LEVELS];
+    int stride[DSDTM_MAX_LEVELS];
+    size_t level_offset[DSDTM_MAX_LEVELS];
+    size_t bytes;           /* size of the packed pyramid allocation */
+    const uint8_t* data;    /* device */
+} dsdtm_image_desc;
+
+int dsdtm_align2d_batch_device(dsdtm_ctx* ctx, const dsdtm_image_desc* cur,
+                               const uint8_t* patch_border, const uint8_t* patch,
+                               const int32_t* level, double* px_xy, uint8_t* converged,
+                               int max_iters, int m, void* hip_stream);
+
+/* ---- Frame::ComputeImagePyramid ------------------------------ */
+/*
+ * Replaces the cv::pyrDown chain of Frame::ComputeImagePyramid (src/Frame.cpp:74-81)
+ * for n_images packed pyramids on the device: level 0 must already be present at
+ * pyr + i*pyr_pitch + level_offset[0]; levels 1..levels-1 are written. Bit-exact
+ * OpenCV 8-bit semantics: separable [1 4 6 4 1], BORDER_REFLECT_101, (sum+128)>>8,
+ * output size ((w+1)/2, (h+1)/2).
+ */
+int dsdtm_pyrdown_batch_device(dsdtm_ctx* ctx, uint8_t* pyr, size_t pyr_pitch, int n_images,
+                               int levels, const int* width, const int* height,
+                               const int* stride, const size_t* level_offset,
+                               void* hip_stream);
+
+/* Host convenience: builds levels 1.. of one pyramid whose level 0 is given. `out` levels
+ * 1..levels-1 must point at caller-owned buffers of stride[l]*height[l] bytes. */
+int dsdtm_pyrdown(dsdtm_ctx* ctx, const uint8_t* level0, int width, int height, int stride,
+                  int levels, uint8_t* const* out_levels, const int* out_stride);
+
+/* ---- Warp prelude of FindMatchDirect ------------------------- */
+/*
+ * Replaces, for M candidates at once, SolveAffineMatrix (src/Feature_alignment.cpp:160-190),
+ * GetBestSearchLevel (:192-204), WarpAffine (:206-259) and GetPatchNoBoarder (:261-275).
+ * One candidate = one (MapPoint, closest-observation reference feature) pair whose
+ * reference keyframe is one of `n_kf` keyframes.
+ *
+ * kf_pyr[k]        : pyramid of reference keyframe k (host)
+ * T_kf_w           : n_kf x 12, keyframe poses (world -> keyframe camera)
+ * T_cur_w          : 12, current frame pose
+ * cand_kf          : M, index of the candidate's reference keyframe
+ * ref_px           : M x 2 float, Feature::mpx of the reference feature (level-0 coords)
+ * ref_level        : M, Feature::mlevel of the reference feature
+ * ref_bearing      : M x 3 double, Feature::mNormal
+ * p_world          : M x 3 double, MapPoint position
+ * max_search_level : Camera.MaxPyraLevels - 3 (:144)
+ * outputs          : affine (M x 4 double, row-major 2x2 A_cur<-ref), search_level (M),
+ *                    patch_border (M x 100), patch (M x 64)
+ */
+int dsdtm_warp_patches(dsdtm_ctx* ctx, const dsdtm_pyramid* kf_pyr, int n_kf,
+                       const dsdtm_camera* cam, const double* T_kf_w, const double T_cur_w[12],
+                       const int32_t* cand_kf, const float* ref_px, const int32_t* ref_level,
+                       const double* ref_bearing, const double* p_world,
+                       int max_search_level, int m,
+                       double* affine, int32_t* search_level,
+                       uint8_t* patch_border, uint8_t* patch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSDTM_AMD_H */

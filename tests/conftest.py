@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests import oracle_lib
+    oracle_lib.load()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    from dsdtm_amd import capi
+    return capi.default_context(0)
+
+
+_SCENES = {}
+
+
+def cached_scene(**kw):
+    """Synthetic scenes are deterministic in their arguments; cache them per session."""
+    from dsdtm_amd import synth
+    key = tuple(sorted((k, (tuple(v) if hasattr(v, "__len__") else v)) for k, v in kw.items()))
+    if key not in _SCENES:
+        _SCENES[key] = synth.make_scene(**kw)
+    return _SCENES[key]

@@ -1,0 +1,157 @@
+"""ctypes loader for the CPU oracle (oracle/_build/liboracle.so) — checker only.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dsdtm_amd import capi
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_LIBS = {}
+
+
+class OracleSE3(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3)]
+
+
+def build(native: bool = False):
+    subprocess.run(["make", "-s", "-C", _ORACLE_DIR] + (["native"] if native else []), check=True)
+
+
+def load(native: bool = False):
+    key = "native" if native else "ref"
+    if key in _LIBS:
+        return _LIBS[key]
+    name = "liboracle_native.so" if native else "liboracle.so"
+    path = os.path.join(_ORACLE_DIR, "_build", name)
+    src = os.path.join(_ORACLE_DIR, "dsdtm_oracle.c")
+    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+        build(native)
+    lib = C.CDLL(path)
+    capi.declare_signatures(lib, "oracle_", with_ctx=False)
+    dp = C.POINTER(C.c_double)
+    lib.oracle_align2d.restype = C.c_int
+    lib.oracle_align2d.argtypes = [capi.u8p, C.c_int, C.c_int, C.c_int, capi.u8p, capi.u8p, C.c_int, dp]
+    lib.oracle_pyrdown.restype = None
+    lib.oracle_pyrdown.argtypes = [capi.u8p, C.c_int, C.c_int, C.c_int, capi.u8p, C.c_int]
+    lib.oracle_se3_from_rt.argtypes = [dp, C.POINTER(OracleSE3)]
+    lib.oracle_se3_to_rt.argtypes = [C.POINTER(OracleSE3), dp]
+    lib.oracle_se3_exp.argtypes = [dp, C.POINTER(OracleSE3)]
+    lib.oracle_se3_mul.argtypes = [C.POINTER(OracleSE3)] * 3
+    lib.oracle_se3_inverse.argtypes = [C.POINTER(OracleSE3)] * 2
+    lib.oracle_se3_act.argtypes = [C.POINTER(OracleSE3), dp, dp]
+    lib.oracle_ldlt6_solve.argtypes = [dp, dp, dp]
+    lib.oracle_jacobian_ba.argtypes = [dp, dp]
+    lib.oracle_sparse_align_batch_timed.restype = C.c_double
+    lib.oracle_sparse_align_batch_timed.argtypes = [C.POINTER(capi.BatchDesc), C.POINTER(capi.Camera),
+                                                    C.POINTER(capi.AlignParams), C.c_int]
+    _LIBS[key] = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def sparse_align(scene, max_level, min_level, max_iters, min_fts=15, T_seed=None, native=False):
+    """Runs oracle_sparse_align on an AlignScene-like object.
+    Returns (T_cur_w 3x4, n_tracked, stats dict)."""
+    lib = load(native)
+    ref, k1 = capi.pyramid_struct(scene.ref_pyr)
+    cur, k2 = capi.pyramid_struct(scene.cur_pyr)
+    cam = capi.camera_struct(scene.cam)
+    px = np.ascontiguousarray(scene.px, dtype=np.float32)
+    bearing = np.ascontiguousarray(scene.bearing, dtype=np.float64)
+    pw = np.ascontiguousarray(scene.p_world, dtype=np.float64)
+    ini = np.ascontiguousarray(scene.initial, dtype=np.uint8)
+    Tr = np.ascontiguousarray(scene.T_ref_w, dtype=np.float64).reshape(12).copy()
+    Tc = np.ascontiguousarray(scene.T_cur_w_seed if T_seed is None else T_seed, dtype=np.float64).reshape(12).copy()
+    prm = capi.AlignParams(max_level, min_level, max_iters, min_fts)
+    nt = C.c_int(0)
+    st = capi.AlignStats()
+    rc = lib.oracle_sparse_align(C.byref(ref), C.byref(cur), C.byref(cam),
+                                 px.ctypes.data_as(C.POINTER(C.c_float)), _dp(bearing), _dp(pw),
+                                 ini.ctypes.data_as(capi.u8p), len(px), _dp(Tr), _dp(Tc),
+                                 C.byref(prm), C.byref(nt), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"oracle_sparse_align -> {rc}")
+    return Tc.reshape(3, 4), nt.value, st.as_dict()
+
+
+def align2d(img, patch_border, patch, max_iters, px):
+    lib = load()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    pb = np.ascontiguousarray(patch_border, dtype=np.uint8).reshape(100)
+    p = np.ascontiguousarray(patch, dtype=np.uint8).reshape(64)
+    pxa = np.array(px, dtype=np.float64)
+    ok = lib.oracle_align2d(img.ctypes.data_as(capi.u8p), img.shape[1], img.shape[0], img.strides[0],
+                            pb.ctypes.data_as(capi.u8p), p.ctypes.data_as(capi.u8p), max_iters, _dp(pxa))
+    return bool(ok), pxa
+
+
+def align2d_batch(cur_pyr, patch_border, patch, level, px, max_iters):
+    lib = load()
+    cur, keep = capi.pyramid_struct(cur_pyr)
+    pb = np.ascontiguousarray(patch_border, dtype=np.uint8)
+    p = np.ascontiguousarray(patch, dtype=np.uint8)
+    lv = np.ascontiguousarray(level, dtype=np.int32)
+    pxa = np.array(px, dtype=np.float64).reshape(-1, 2).copy()
+    m = len(lv)
+    conv = np.zeros(m, dtype=np.uint8)
+    rc = lib.oracle_align2d_batch(C.byref(cur), pb.ctypes.data_as(capi.u8p), p.ctypes.data_as(capi.u8p),
+                                  lv.ctypes.data_as(C.POINTER(C.c_int32)), _dp(pxa),
+                                  conv.ctypes.data_as(capi.u8p), max_iters, m)
+    if rc != 0:
+        raise RuntimeError(f"oracle_align2d_batch -> {rc}")
+    return conv.astype(bool), pxa
+
+
+def pyrdown(img):
+    lib = load()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), dtype=np.uint8)
+    lib.oracle_pyrdown(img.ctypes.data_as(capi.u8p), w, h, img.strides[0],
+                       out.ctypes.data_as(capi.u8p), out.strides[0])
+    return out
+
+
+def warp_patches(kf_pyrs, cam, T_kf_w, T_cur_w, cand_kf, ref_px, ref_level, ref_bearing, p_world,
+                 max_search_level):
+    lib = load()
+    n_kf = len(kf_pyrs)
+    arr = (capi.Pyramid * n_kf)()
+    keep = []
+    for i, p in enumerate(kf_pyrs):
+        s, k = capi.pyramid_struct(p)
+        arr[i] = s
+        keep.append(k)
+    m = len(cand_kf)
+    Tk = np.ascontiguousarray(T_kf_w, dtype=np.float64).reshape(n_kf, 12)
+    Tc = np.ascontiguousarray(T_cur_w, dtype=np.float64).reshape(12)
+    ck = np.ascontiguousarray(cand_kf, dtype=np.int32)
+    rp = np.ascontiguousarray(ref_px, dtype=np.float32)
+    rl = np.ascontiguousarray(ref_level, dtype=np.int32)
+    rb = np.ascontiguousarray(ref_bearing, dtype=np.float64)
+    pw = np.ascontiguousarray(p_world, dtype=np.float64)
+    aff = np.zeros((m, 4))
+    sl = np.zeros(m, dtype=np.int32)
+    pb = np.zeros((m, 100), dtype=np.uint8)
+    pp = np.zeros((m, 64), dtype=np.uint8)
+    ip = C.POINTER(C.c_int32)
+    rc = lib.oracle_warp_patches(arr, n_kf, C.byref(capi.camera_struct(cam)), _dp(Tk), _dp(Tc),
+                                 ck.ctypes.data_as(ip), rp.ctypes.data_as(C.POINTER(C.c_float)),
+                                 rl.ctypes.data_as(ip), _dp(rb), _dp(pw), max_search_level, m,
+                                 _dp(aff), sl.ctypes.data_as(ip), pb.ctypes.data_as(capi.u8p),
+                                 pp.ctypes.data_as(capi.u8p))
+    if rc != 0:
+        raise RuntimeError(f"oracle_warp_patches -> {rc}")
+    return aff, sl, pb, pp
