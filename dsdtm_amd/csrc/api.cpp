@@ -158,6 +158,8 @@ static int validate_params(dsdtm_ctx* ctx, const dsdtm_align_params* p, int leve
     return DSDTM_OK;
 }
 
+static thread_local void* g_stamp_out = nullptr;   // device buffer, set only by the stamps debug entry
+
 extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam,
                                                const dsdtm_align_params* prm, void* hip_stream) {
     if (!ctx) return DSDTM_ERR_INVALID;
@@ -191,6 +193,12 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     a.pyr_pitch = b->pyr_pitch; a.n_pairs = b->n_pairs; a.max_features = b->max_features;
     a.max_level = prm->max_level; a.min_level = prm->min_level; a.max_iters = prm->max_iters; a.min_fts = prm->min_fts;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy; a.f = cam->f;
+    if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
+        if (sparse_align_pick_variant(b->max_features) != SA_REG320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
+        a.workspace = (double*)g_stamp_out;
+        HIP_TRY(ctx, sparse_align_launch_stamps(a, (hipStream_t)hip_stream));
+        return DSDTM_OK;
+    }
     const SAVariant v = sparse_align_pick_variant(b->max_features);
     const size_t ws = sparse_align_workspace_bytes(b->n_pairs, b->max_features);
     if (ws) {
@@ -514,4 +522,17 @@ extern "C" int dsdtm_debug_selftest(dsdtm_ctx* ctx, const double* in, double* ou
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, h + ib, ob);
     return DSDTM_OK;
+}
+
+// ---- debug: in-kernel stamps of the register kernel (diagnostic instantiation, never timed) ----
+// stamps_dev: device buffer of n_pairs*8 uint64: [0] cycles the solver waited for the first pass of
+// each level (precompute + pass), [1] waits of the later passes, [2] solve cycles, [3] iterations,
+// [4] whole-block cycles, [5] s_memrealtime at the end, [6] s_memtime at the start.
+extern "C" int dsdtm_debug_sparse_align_stamps(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam,
+                                               const dsdtm_align_params* prm, void* stamps_dev, void* hip_stream) {
+    if (!ctx || !stamps_dev) return DSDTM_ERR_INVALID;
+    g_stamp_out = stamps_dev;
+    const int rc = dsdtm_sparse_align_batch_device(ctx, b, cam, prm, hip_stream);
+    g_stamp_out = nullptr;
+    return rc;
 }

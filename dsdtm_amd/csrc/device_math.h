@@ -18,8 +18,10 @@ struct SE3d {
 };
 
 __device__ __forceinline__ void quat_normalize(SE3d& T) {
-    const double n = sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
-    T.qw /= n; T.qx /= n; T.qy /= n; T.qz /= n;
+    // one reciprocal instead of Eigen's four divisions (<= 1 ulp per coefficient; the solver wave is
+    // the serial part of every Gauss-Newton iteration, so its dependent chain is kept short)
+    const double rn = 1.0 / sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
+    T.qw *= rn; T.qx *= rn; T.qy *= rn; T.qz *= rn;
 }
 
 __device__ __forceinline__ void quat_rotate(const SE3d& T, double vx, double vy, double vz,
@@ -108,24 +110,27 @@ __device__ inline SE3d se3_inverse(const SE3d& a) {
     return r;
 }
 
-// SE3::exp([upsilon, omega]) — Sophus: quaternion from half angle, V matrix for the translation
+// SE3::exp([upsilon, omega]) — Sophus: quaternion from the half angle, V matrix for the translation.
+// One sincos(theta/2) serves both: sin(theta) = 2 s c, 1 - cos(theta) = 2 s^2 (no cancellation), and
+// one reciprocal of theta replaces Sophus' three divisions.
 __device__ inline SE3d se3_exp(const double* x) {
     const double ux = x[0], uy = x[1], uz = x[2];
     const double wx = x[3], wy = x[4], wz = x[5];
-    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
-    const double half_theta = 0.5 * theta;
-    double imag_factor;
-    const double real_factor = cos(half_theta);
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    const double theta = sqrt(theta_sq);
+    double sh, ch;
+    sincos(0.5 * theta, &sh, &ch);
     const bool small = theta < 1e-10;
+    const double inv_theta = 1.0 / theta;
+    double imag_factor;
     if (small) {
-        const double theta_sq = theta * theta;
         const double theta_po4 = theta_sq * theta_sq;
         imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
     } else {
-        imag_factor = sin(half_theta) / theta;
+        imag_factor = sh * inv_theta;
     }
     SE3d o;
-    o.qw = real_factor;
+    o.qw = ch;
     o.qx = imag_factor * wx;
     o.qy = imag_factor * wy;
     o.qz = imag_factor * wz;
@@ -134,10 +139,10 @@ __device__ inline SE3d se3_exp(const double* x) {
     if (small) {
         quat_to_matrix(o, V);
     } else {
-        const double theta_sq = theta * theta;
-        const double a = (1.0 - cos(theta)) / theta_sq;
-        const double b = (theta - sin(theta)) / (theta_sq * theta);
-        // Omega = hat(omega); Omega^2 = omega omega^T - |omega|^2 I, written out as the matrix product
+        const double si = sh * inv_theta;
+        const double a = 2.0 * si * si;                                  // (1 - cos theta) / theta^2
+        const double b = (theta - 2.0 * sh * ch) * (inv_theta * inv_theta * inv_theta);   // (theta - sin theta) / theta^3
+        // Omega = hat(omega); Omega^2 written out as the matrix product
         const double o00 = -wz * wz - wy * wy, o01 = wy * wx, o02 = wz * wx;
         const double o10 = wx * wy, o11 = -wz * wz - wx * wx, o12 = wz * wy;
         const double o20 = wx * wz, o21 = wy * wz, o22 = -wy * wy - wx * wx;
@@ -187,7 +192,7 @@ __device__ __forceinline__ void ldlt_pivot_case(double* m, double* d, int piv) {
 
 // One elimination step; returns the chosen pivot row (K itself once the rank cutoff hit).
 template <int K>
-__device__ __forceinline__ int ldlt_step(double* m, double* d, double& cutoff, bool& done) {
+__device__ __forceinline__ int ldlt_step(double* m, double* d, double* rD, double& cutoff, bool& done) {
     if (done) return K;
     int piv = K;
     double big = fabs(DSDTM_M(K, K));
@@ -220,10 +225,11 @@ __device__ __forceinline__ int ldlt_step(double* m, double* d, double& cutoff, b
             DSDTM_M(i, K) -= a;
         }
     }
+    // A21 /= D_k as one reciprocal + multiplies; the reciprocal is reused by the D^+ step of the solve
+    rD[K] = 1.0 / DSDTM_M(K, K);
     if (K < 5 && fabs(DSDTM_M(K, K)) > cutoff) {
-        const double dk = DSDTM_M(K, K);
 #pragma unroll
-        for (int i = K + 1; i < 6; ++i) DSDTM_M(i, K) /= dk;
+        for (int i = K + 1; i < 6; ++i) DSDTM_M(i, K) *= rD[K];
     }
     return piv;
 }
@@ -257,12 +263,13 @@ __device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x)
 
     double cutoff = 0.0;
     bool done = false;
-    const int tr0 = ldlt_step<0>(m, d, cutoff, done);
-    const int tr1 = ldlt_step<1>(m, d, cutoff, done);
-    const int tr2 = ldlt_step<2>(m, d, cutoff, done);
-    const int tr3 = ldlt_step<3>(m, d, cutoff, done);
-    const int tr4 = ldlt_step<4>(m, d, cutoff, done);
-    (void)ldlt_step<5>(m, d, cutoff, done);
+    double rD[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // 1/D_k where the factorisation reached step k
+    const int tr0 = ldlt_step<0>(m, d, rD, cutoff, done);
+    const int tr1 = ldlt_step<1>(m, d, rD, cutoff, done);
+    const int tr2 = ldlt_step<2>(m, d, rD, cutoff, done);
+    const int tr3 = ldlt_step<3>(m, d, rD, cutoff, done);
+    const int tr4 = ldlt_step<4>(m, d, rD, cutoff, done);
+    (void)ldlt_step<5>(m, d, rD, cutoff, done);
 
     // L^-1
 #pragma unroll
@@ -278,11 +285,13 @@ __device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x)
     for (int i = 0; i < 6; ++i) maxd = fmax(maxd, fabs(DSDTM_M(i, i)));
     double tol = maxd * 2.220446049250313e-16;
     tol = fmax(tol, 1.0 / 1.7976931348623157e308);
+    if (done) {   // rank cutoff hit (rare, wave-uniform): reciprocals of the steps that were skipped
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        if (fabs(DSDTM_M(i, i)) > tol) d[i] /= DSDTM_M(i, i);
-        else d[i] = 0.0;
+        for (int i = 0; i < 6; ++i)
+            if (rD[i] == 0.0) rD[i] = 1.0 / DSDTM_M(i, i);
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = (fabs(DSDTM_M(i, i)) > tol) ? d[i] * rD[i] : 0.0;
     // L^-T
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
@@ -322,6 +331,15 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
     v += dpp_f64<0x121, 0xf>(v);  // row_ror:1
     v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
     v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// Sum over the 16 lanes of each DPP row only; every lane of a row ends up holding its row's sum.
+__device__ __forceinline__ double row_sum16(double v) {
+    v += dpp_f64<0x128, 0xf>(v);  // row_ror:8
+    v += dpp_f64<0x124, 0xf>(v);  // row_ror:4
+    v += dpp_f64<0x122, 0xf>(v);  // row_ror:2
+    v += dpp_f64<0x121, 0xf>(v);  // row_ror:1
     return v;
 }
 

@@ -44,6 +44,8 @@ enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2 };
 SAVariant sparse_align_pick_variant(int max_features);
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features);
 hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, hipStream_t stream);
+// diagnostic (in-kernel stamps) instantiation of the 5+1-wave register kernel; workspace = n_pairs*8 u64
+hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, hipStream_t stream);
 
 // Align2D: one wavefront per feature.
 struct A2DKernelArgs {

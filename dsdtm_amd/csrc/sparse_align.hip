@@ -126,36 +126,65 @@ __device__ __forceinline__ void patch_AB(double fs, const double* X, double* A, 
     B[4] = -x * z_inv * fs;              // J(1,5)
 }
 
-// GetJocabianMat for one feature (reference :84-162), producing the register-resident state.
+// Level-independent part of GetJocabianMat (reference :84-119) for one feature: the feature
+// columns are read from HBM once per alignment, not once per level.
+struct FeatureRegs {
+    float px, py;     // Feature::mpx
+    double X[3];      // bearing * |P_w - C_ref|  (:117-119)
+    bool ok;          // mbInitial && P_w != 0 (:86, :95)
+};
+
+struct FeatureRaw {   // the raw loads, issued before the first barrier so their latency overlaps solver_init
+    float px, py;
+    double b0, b1, b2, w0, w1, w2;
+    bool initial;
+};
+
+__device__ __forceinline__ FeatureRaw load_feature_raw(const SAKernelArgs& a, size_t fidx, bool live) {
+    FeatureRaw r;
+    r.px = r.py = 0.0f; r.b0 = r.b1 = r.b2 = r.w0 = r.w1 = r.w2 = 0.0; r.initial = false;
+    if (live) {
+        r.initial = a.initial[fidx] != 0;
+        r.px = a.px_xy[2 * fidx]; r.py = a.px_xy[2 * fidx + 1];
+        r.b0 = a.bearing[3 * fidx]; r.b1 = a.bearing[3 * fidx + 1]; r.b2 = a.bearing[3 * fidx + 2];
+        r.w0 = a.p_world[3 * fidx]; r.w1 = a.p_world[3 * fidx + 1]; r.w2 = a.p_world[3 * fidx + 2];
+    }
+    return r;
+}
+
+__device__ __forceinline__ FeatureRegs make_feature(const FeatureRaw& r, const double* Cref) {
+    FeatureRegs f;
+    f.px = r.px; f.py = r.py;
+    const bool is_zero = (r.w0 == 0.0 && r.w1 == 0.0 && r.w2 == 0.0);    // :95 isZero(0)
+    f.ok = r.initial && !is_zero;
+    const double d0 = r.w0 - Cref[0], d1 = r.w1 - Cref[1], d2 = r.w2 - Cref[2];
+    const double depth = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    f.X[0] = r.b0 * depth; f.X[1] = r.b1 * depth; f.X[2] = r.b2 * depth;
+    return f;
+}
+
+// Per-level part of GetJocabianMat for one feature (reference :89-100, :123-162), producing the
+// register-resident state.
 template <typename GT>
 __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const LevelGeom& lg, int level,
                                                  const uint8_t* __restrict__ ref_base,  // pair's ref pyramid
-                                                 size_t fidx, bool live, const double* Cref, PatchRegs<GT>& P) {
+                                                 const FeatureRegs& F, PatchRegs<GT>& P) {
     P.valid = false;
-    P.X[0] = P.X[1] = P.X[2] = 0.0;
+    P.X[0] = F.X[0]; P.X[1] = F.X[1]; P.X[2] = F.X[2];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c) P.g[r][c] = (GT)0;
-    if (!live) return;
+    if (!F.ok) return;
     const float scale_f = 1.0f / (float)(1 << level);                  // :65 tScale (float)
     const double scale = (double)scale_f;
-    if (!a.initial[fidx]) return;                                      // :86
-    const double px = (double)a.px_xy[2 * fidx] * scale;               // :89-91
-    const double py = (double)a.px_xy[2 * fidx + 1] * scale;
-    const double Pw0 = a.p_world[3 * fidx], Pw1 = a.p_world[3 * fidx + 1], Pw2 = a.p_world[3 * fidx + 2];
-    const bool is_zero = (Pw0 == 0.0 && Pw1 == 0.0 && Pw2 == 0.0);    // :95 isZero(0)
+    const double px = (double)F.px * scale;                            // :89-91
+    const double py = (double)F.py * scale;
     const double boarder = 3.0;                                        // :67 int(0.5*4+1)
-    if (is_zero || px - boarder < 0 || py - boarder < 0 || px + boarder >= (double)lg.w ||
+    if (px - boarder < 0 || py - boarder < 0 || px + boarder >= (double)lg.w ||
         py + boarder >= (double)lg.h || !(px == px) || !(py == py))
         return;                                                        // :95-100
     P.valid = true;
-    // :117-119
-    const double d0 = Pw0 - Cref[0], d1 = Pw1 - Cref[1], d2 = Pw2 - Cref[2];
-    const double depth = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-    P.X[0] = a.bearing[3 * fidx] * depth;
-    P.X[1] = a.bearing[3 * fidx + 1] * depth;
-    P.X[2] = a.bearing[3 * fidx + 2] * depth;
     // :123-132
     const double fu_d = floor(px), fv_d = floor(py);
     const int fu = (int)fu_d, fv = (int)fv_d;
@@ -249,8 +278,10 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
     const double pyc = sR[3] * P.X[0] + sR[4] * P.X[1] + sR[5] * P.X[2] + st[1];
     const double pzc = sR[6] * P.X[0] + sR[7] * P.X[1] + sR[8] * P.X[2] + st[2];
     // Camera2Pixel (src/Camera.cpp:167-171), * tScale (:255)
-    const double u = ((double)a.fx * pxc / pzc + (double)a.cx) * scale;
-    const double v = ((double)a.fy * pyc / pzc + (double)a.cy) * scale;
+    // one reciprocal for both coordinates (the reference divides twice; <= 1 ulp on u,v)
+    const double izc = 1.0 / pzc;
+    const double u = ((double)a.fx * pxc * izc + (double)a.cx) * scale;
+    const double v = ((double)a.fy * pyc * izc + (double)a.cy) * scale;
     // :262 with mnboarder = 3 on floored ints: floor(u) >= 3 && floor(u)+3 < cols (NaN fails)
     if (!(u >= 3.0 && u < (double)(lg.w - 3) && v >= 3.0 && v < (double)(lg.h - 3))) return false;
     const double fu_d = floor(u), fv_d = floor(v);
@@ -340,7 +371,7 @@ __device__ __forceinline__ void solver_init(const SAKernelArgs& a, int pair, Blo
 
 // Solver wave, one Gauss-Newton iteration (reference :310-343). Executed uniformly by all 64
 // lanes of the solver wave (same cost as one lane); lane 0 publishes. Returns ctrl.
-template <int NPW>
+template <int NP>   // NP = number of partial slots (rows or waves)
 __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int level, int it,
                                            const WavePartial* s_part, BlockState& s, int lane) {
     // Cross-wave totals, lane-parallel: lane q<21 sums H[q], lanes 21..26 sum b, lane 27 chi2
@@ -348,7 +379,7 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     // solve needs are ever live in registers.
     int cnt = 0, changed = 0, n_ref = 0;
 #pragma unroll
-    for (int w = 0; w < NPW; ++w) {
+    for (int w = 0; w < NP; ++w) {
         cnt += s_part[w].cnt;
         changed |= s_part[w].h_changed;
         n_ref += s_part[w].n_ref;
@@ -363,7 +394,7 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
         if (lane < 28 && (changed || lane >= 21)) {
             double acc = 0.0;
 #pragma unroll
-            for (int w = 0; w < NPW; ++w) acc += base[w * WP + off];
+            for (int w = 0; w < NP; ++w) acc += base[w * WP + off];
             if (lane < 21) s.Hsum[lane] = acc;
             else s.bsum[lane - 21] = acc;
         }
@@ -457,9 +488,13 @@ __device__ __forceinline__ void solver_finish(const SAKernelArgs& a, int pair, B
 // Register-resident kernel: NPW patch waves (one patch per lane, NPW*64 >= n_features) + 1 solver
 // wave.
 // ---------------------------------------------------------------------------------------------
-template <int NPW, typename GT>
+// STAMPS = diagnostic instantiation only (dsdtm_debug_sparse_align_stamps): the solver wave
+// accumulates shader-clock cycles spent waiting for the patch waves (B1) and solving, and writes
+// them to a.workspace[pair*4 ..]; the timed/product instantiation contains no stamp.
+template <int NPW, typename GT, bool STAMPS = false>
 __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const SAKernelArgs a) {
-    __shared__ WavePartial s_part[NPW];
+    constexpr int NP = NPW * 4;            // one partial slot per 16-lane DPP row
+    __shared__ WavePartial s_part[NP];
     __shared__ BlockState s;
 
     const int pair = blockIdx.x;
@@ -476,6 +511,8 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const 
 
     if (wave == NPW) {
         // ------------------------------ solver wave ------------------------------
+        unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0;
+        if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
         solver_init(a, pair, s, lane);
         __syncthreads();                                               // B0
         for (int level = a.max_level - 1; level >= a.min_level; --level) {
@@ -487,68 +524,107 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const 
                 for (int i = 0; i < 3; ++i) s.to[i] = s.t[i];
             }
             for (int it = 0; it < a.max_iters; ++it) {
+                unsigned long long t0 = 0, t1 = 0, t2 = 0;
+                if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
                 __syncthreads();                                       // B1
-                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane);
+                if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
+                const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane);
+                if (STAMPS) {
+                    t2 = __builtin_amdgcn_s_memtime();
+                    if (it == 0) t_first += t1 - t0; else t_wait += t1 - t0;
+                    t_solve += t2 - t1;
+                    n_it += 1;
+                }
                 __syncthreads();                                       // B2
                 if (ctrl) break;
             }
         }
         solver_finish(a, pair, s, lane);
+        if (STAMPS && lane == 0 && a.workspace) {
+            unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 8;
+            o[0] = t_first; o[1] = t_wait; o[2] = t_solve; o[3] = n_it;
+            o[4] = __builtin_amdgcn_s_memtime() - t_begin;
+            o[5] = __builtin_amdgcn_s_memrealtime();
+            o[6] = t_begin;
+        }
         return;
     }
 
     // ---------------------------------- patch waves ----------------------------------
     const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
     const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
-    const size_t fidx = (size_t)pair * a.max_features + tid;
-    const bool live = tid < nf;
+    const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + tid, tid < nf);
+    unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
     __syncthreads();                                                   // B0
+    FeatureRegs F;
+    {
+        const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
+        F = make_feature(fraw, Cref);
+    }
+    const int row = lane >> 4;
+    const bool row_writer = (lane & 15) == 15;
+    WavePartial& my_part = s_part[wave * 4 + row];
 
     for (int level = a.max_level - 1; level >= a.min_level; --level) {
         const LevelGeom lg = a.lv[level];
         const double scale = (double)(1.0f / (float)(1 << level));
         const double fs = (double)a.f * scale;
         PatchRegs<GT> P;
-        {
-            const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
-            precompute_patch<GT>(a, lg, level, ref_base, fidx, live, Cref, P);
+        unsigned long long tp0 = 0;
+        if (STAMPS) tp0 = __builtin_amdgcn_s_memtime();
+        precompute_patch<GT>(a, lg, level, ref_base, F, P);
+        if (STAMPS) {
+            pin_patch(P);   // make the stamp wait for the precompute results
+            st_pre += __builtin_amdgcn_s_memtime() - tp0;
         }
-        const int n_ref_wave = __popcll(__ballot(P.valid));
+        const int n_ref_row = __popc((unsigned)(__ballot(P.valid) >> (16 * row)) & 0xffffu);
         unsigned long long cached_mask = 0ull;
         bool first = true;   // forces the first H reduction of the level
 
         for (int it = 0; it < a.max_iters; ++it) {
             double chi2, b[6];
+            unsigned long long tq0 = 0, tq1 = 0;
+            if (STAMPS) tq0 = __builtin_amdgcn_s_memtime();
             pin_patch(P);
             const bool vis = residual_patch<GT>(a, lg, scale, fs, cur_base, P, s.R, s.tt, chi2, b);
             const unsigned long long vmask = __ballot(vis);
+            // reduce to the 16-lane DPP rows only (4 steps instead of 6); the solver's lane-parallel
+            // summation folds the 4*NPW row partials
 #pragma unroll
-            for (int i = 0; i < 6; ++i) b[i] = wave_sum_to_lane63(b[i]);
-            chi2 = wave_sum_to_lane63(chi2);
-            if (lane == 63) {
+            for (int i = 0; i < 6; ++i) b[i] = row_sum16(b[i]);
+            chi2 = row_sum16(chi2);
+            if (row_writer) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) s_part[wave].b[i] = b[i];
-                s_part[wave].chi2 = chi2;
-                s_part[wave].cnt = __popcll(vmask);
-                s_part[wave].n_ref = n_ref_wave;
+                for (int i = 0; i < 6; ++i) my_part.b[i] = b[i];
+                my_part.chi2 = chi2;
+                my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
+                my_part.n_ref = n_ref_row;
             }
+            if (STAMPS) { tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0; }
             const bool h_changed = first || (vmask != cached_mask);   // wave-uniform
             if (h_changed) {
                 const PatchHess ph = patch_hess_factors<GT>(P, fs);
-                double* Hout = s_part[wave].H;
+                double* Hout = my_part.H;
                 patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
-                    const double hs = wave_sum_to_lane63(vis ? v : 0.0);
-                    if (lane == 63) Hout[q] = hs;
+                    const double hs = row_sum16(vis ? v : 0.0);
+                    if (row_writer) Hout[q] = hs;
                     __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
                 });
                 cached_mask = vmask;
                 first = false;
             }
-            if (lane == 63) s_part[wave].h_changed = h_changed ? 1 : 0;
+            if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
+            unsigned long long tq2 = 0;
+            if (STAMPS) { tq2 = __builtin_amdgcn_s_memtime(); st_h += tq2 - tq1; }
             __syncthreads();                                           // B1
             __syncthreads();                                           // B2
+            if (STAMPS) st_bar += __builtin_amdgcn_s_memtime() - tq2;
             if (s.ctrl) break;
         }
+    }
+    if (STAMPS && tid == 0 && a.workspace) {
+        unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 4;
+        o[0] = st_pre; o[1] = st_pass; o[2] = st_h; o[3] = st_bar;
     }
 }
 
@@ -648,7 +724,8 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
             const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
             for (int p = tid; p < (int)npad; p += PT) {
                 PatchRegs<double> P;
-                precompute_patch<double>(a, lg, level, ref_base, (size_t)pair * a.max_features + p, p < nf, Cref, P);
+                const FeatureRegs F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + p, p < nf), Cref);
+                precompute_patch<double>(a, lg, level, ref_base, F, P);
                 ws_store(ws, npad, p, P);          // read back only by this same thread
                 n_valid_lane += P.valid ? 1 : 0;
             }
@@ -711,6 +788,12 @@ SAVariant sparse_align_pick_variant(int max_features) {
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
     if (sparse_align_pick_variant(max_features) != SA_WS) return 0;
     return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
+}
+
+hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, hipStream_t stream) {
+    if (args.n_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, true>), dim3((unsigned)args.n_pairs), dim3(6 * 64), 0, stream, args);
+    return hipGetLastError();
 }
 
 hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, hipStream_t stream) {
