@@ -202,8 +202,9 @@ def main():
     prm = capi.AlignParams(args.levels, 0, args.iters, 15)
     stream = torch.cuda.Stream(device=dev)
 
+    from dsdtm_amd import shard
     d = build_batch(torch, dev, ctx, cam, args.pairs, args.width, args.height, args.levels, args.patches,
-                    seed=0xD5D7 + 1000 * rank, stream=stream)
+                    seed=shard.batch_seed(0xD5D7, rank), stream=stream)
     desc = d["desc"]
     ws_bytes = ctx.lib.dsdtm_sparse_align_workspace_bytes(C.byref(desc))
     if ws_bytes:
@@ -241,9 +242,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = shard.max_over_ranks(elapsed, dist, dev)
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
     if rank == 0:

@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch (device memory / streams for the *_device entry points) bundles its own HIP runtime.
+    # On a GPU box let it initialise before anything loads libdsdtm_amd.so (even at collection
+    # time), so that both bind to the same libamdhip64 inside this process.
+    if os.path.exists("/dev/kfd"):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope="session")

@@ -61,3 +61,24 @@ def make_border_patches(img, centers, rng=None):
         pbs.append(pb.reshape(100))
         ps.append(pb[1:9, 1:9].reshape(64))
     return np.array(pbs), np.array(ps)
+
+
+class GoldenScene:
+    """AlignScene-shaped view of a tests/golden/sparse_align_*.npz fixture."""
+
+    def __init__(self, path):
+        d = np.load(path)
+        self.d = d
+        L = int(d["levels"])
+        c = d["cam"]
+        self.cam = synth.Camera(c[0], c[1], c[2], c[3], c[4], int(c[5]), int(c[6]))
+        self.ref_pyr = [d[f"ref{l}"] for l in range(L)]
+        self.cur_pyr = [d[f"cur{l}"] for l in range(L)]
+        self.px, self.bearing, self.p_world, self.initial = d["px"], d["bearing"], d["p_world"], d["initial"]
+        self.T_ref_w, self.T_cur_w_seed, self.T_cur_w_true = d["T_ref_w"], d["T_seed"], d["T_true"]
+        self.params = tuple(int(x) for x in d["params"])
+
+
+def golden_path(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)

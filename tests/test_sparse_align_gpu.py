@@ -155,3 +155,77 @@ def test_identity_motion_converges_immediately(gpu_ctx, oracle):
     H.assert_pose_close(Tg, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10)
     ea, et = synth.pose_error(Tg, sc.T_cur_w_true)
     assert ea < 1e-4 and et < 2e-4 and sg["iters"] == so["iters"]
+
+
+@pytest.mark.parametrize("name", ["sparse_align_a.npz", "sparse_align_b.npz"])
+def test_golden_fixtures(gpu_ctx, name):
+    """HIP path against the committed golden vectors (tests/golden, generated by make_golden.py)."""
+    g = H.GoldenScene(H.golden_path(name))
+    mx, mn, it, mf = g.params
+    Tg, ng, sg = H.gpu_sparse_align(g, mx, mn, it, min_fts=mf, ctx=gpu_ctx)
+    H.assert_pose_close(Tg, g.d["out_T"], H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=name)
+    assert ng == int(g.d["out_n"])
+    assert sg["iters"] == list(g.d["out_iters"]) and sg["exit_code"] == list(g.d["out_exit"])
+    assert sg["n_ref"] == list(g.d["out_nref"]) and sg["n_vis"] == list(g.d["out_nvis"])
+
+
+def test_batch_device_api_with_ragged_feature_counts(gpu_ctx, oracle):
+    """dsdtm_sparse_align_batch_device: several pairs in one launch, per-pair feature counts
+    (including one below Camera.Min_fts and one empty), stats array, in/out pose buffer."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, NMAX = 320, 240, 3, 300
+    counts = [300, 257, 64, 15, 14, 0, 129, 300]
+    scenes = []
+    for i, n in enumerate(counts):
+        rng = np.random.default_rng(500 + i)
+        scenes.append(cached_scene(width=W, height=Hh, levels=L, n_patches=max(n, 1), seed=600 + i, margin=12,
+                                   xi=tuple(synth.random_xi(rng)), depth=float(rng.uniform(1, 4)),
+                                   T_ref_w=tuple(map(tuple, synth.random_pose(rng)))))
+    ws, hs, st, offs, nbytes = capi.pyramid_layout(W, Hh, L)
+    pitch = (nbytes + 255) // 256 * 256
+    P = len(counts)
+    ref = np.zeros((P, pitch), np.uint8); cur = np.zeros((P, pitch), np.uint8)
+    px = np.zeros((P, NMAX, 2), np.float32); bear = np.zeros((P, NMAX, 3)); pw = np.zeros((P, NMAX, 3))
+    ini = np.zeros((P, NMAX), np.uint8); Tr = np.zeros((P, 12)); Tc = np.zeros((P, 12))
+    for i, (sc, n) in enumerate(zip(scenes, counts)):
+        for l in range(L):
+            ref[i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.ref_pyr[l].reshape(-1)
+            cur[i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.cur_pyr[l].reshape(-1)
+        px[i, :n] = sc.px[:n]; bear[i, :n] = sc.bearing[:n]; pw[i, :n] = sc.p_world[:n]; ini[i, :n] = sc.initial[:n]
+        # poison the padding: it must never be read
+        px[i, n:] = np.nan; bear[i, n:] = np.nan; pw[i, n:] = np.nan; ini[i, n:] = 1
+        Tr[i] = sc.T_ref_w.reshape(12); Tc[i] = sc.T_cur_w_seed.reshape(12)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(ref=ref, cur=cur, px=px, bear=bear, pw=pw, ini=ini, Tr=Tr, Tc=Tc).items()}
+    t["nf"] = torch.tensor(counts, dtype=torch.int32, device=dev)
+    t["nt"] = torch.full((P,), -7, dtype=torch.int32, device=dev)
+    t["st"] = torch.zeros((P, capi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    b = capi.BatchDesc()
+    b.n_pairs, b.max_features, b.levels = P, NMAX, L
+    for l in range(L):
+        b.width[l], b.height[l], b.stride[l], b.level_offset[l] = ws[l], hs[l], st[l], offs[l]
+    b.pyr_pitch = pitch
+    b.ref_pyr, b.cur_pyr, b.px_xy, b.bearing, b.p_world = (t[k].data_ptr() for k in ("ref", "cur", "px", "bear", "pw"))
+    b.initial, b.n_features, b.T_ref_w, b.T_cur_w = t["ini"].data_ptr(), t["nf"].data_ptr(), t["Tr"].data_ptr(), t["Tc"].data_ptr()
+    b.n_tracked, b.stats = t["nt"].data_ptr(), t["st"].data_ptr()
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    stream = torch.cuda.Stream(device=dev)
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm),
+                                                              stream.cuda_stream))
+    stream.synchronize()
+    Tg = t["Tc"].cpu().numpy(); ntg = t["nt"].cpu().numpy()
+    stg = np.frombuffer(t["st"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
+    import copy
+    for i, (sc, n) in enumerate(zip(scenes, counts)):
+        s2 = copy.copy(sc)
+        s2.px, s2.bearing, s2.p_world, s2.initial = sc.px[:n], sc.bearing[:n], sc.p_world[:n], sc.initial[:n]
+        To, no, so = oracle.sparse_align(s2, L, 0, 10)
+        assert ntg[i] == no, (i, ntg[i], no)
+        if n < 15:
+            assert no == 0 and np.array_equal(Tg[i], sc.T_cur_w_seed.reshape(12))      # pose untouched
+        else:
+            H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"pair {i}")
+            assert list(stg["iters"][i]) == so["iters"] and list(stg["n_ref"][i]) == so["n_ref"]

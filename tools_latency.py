@@ -1,0 +1,40 @@
+"""Single-pair latency of the HOST entry points (PCIe-inclusive): what Tracking would see per
+frame through the reference-shaped classes. Configs 2, 3 and 5 of BASELINE.md.
+Usage: python tools_latency.py"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dsdtm_amd import capi, synth, feature_alignment as FA
+from dsdtm_amd.frame import Config, frames_from_scene
+from dsdtm_amd.sparse_align import Sprase_ImgAlign
+from tests import helpers, oracle_lib
+
+ctx = capi.default_context(0)
+Config.Set("Camera.Min_fts", 15)
+for name, kw, prm in [("config2 640x480 N=300", dict(), (4, 0, 10)),
+                      ("config3 640x480 N=1000", dict(n_patches=1000, cam=synth.Camera.tum(640, 480, synth.TUM_FR3)), (4, 0, 10)),
+                      ("config5 1280x960 N=2000", dict(width=1280, height=960, n_patches=2000, margin=60), (4, 0, 10))]:
+    sc = synth.make_scene(**kw)
+    al = Sprase_ImgAlign(*prm, ctx=ctx)
+    ts = []
+    for i in range(30):
+        cur, ref = frames_from_scene(sc)
+        t0 = time.perf_counter(); n = al.Run(cur, ref); ts.append(time.perf_counter() - t0)
+    t0 = time.perf_counter(); To, no, so = oracle_lib.sparse_align(sc, *prm); tc = time.perf_counter() - t0
+    ang, dt = synth.pose_error(cur.Get_Pose(), To)
+    print(f"{name}: GPU host call median {np.median(ts[5:])*1e3:.3f} ms (min {min(ts)*1e3:.3f}) | CPU oracle {tc*1e3:.2f} ms | "
+          f"n={n}/{no} iters={al.last_stats['iters'][:4]} delta={ang:.1e} rad {dt:.1e} m")
+# config 5 second half: 2000 Align2D problems on the 1280x960 current frame
+sc = synth.make_scene(width=1280, height=960, n_patches=2000, margin=60)
+rng = np.random.default_rng(0)
+img = sc.cur_pyr[0]
+cs = np.stack([rng.uniform(20, 1260, 2000), rng.uniform(20, 940, 2000)], 1)
+pb, p = helpers.make_border_patches(img, cs)
+px0 = cs + rng.uniform(-1.5, 1.5, cs.shape)
+ts = []
+for i in range(20):
+    t0 = time.perf_counter(); cg, pxg = FA.align2d_batch(sc.cur_pyr, pb, p, np.zeros(2000, np.int32), px0, 10, ctx=ctx); ts.append(time.perf_counter() - t0)
+t0 = time.perf_counter(); co, pxo = oracle_lib.align2d_batch(sc.cur_pyr, pb, p, np.zeros(2000, np.int32), px0, 10); tc = time.perf_counter() - t0
+same = cg == co
+print(f"config5 Align2D x2000: GPU host call median {np.median(ts[3:])*1e3:.3f} ms | CPU oracle {tc*1e3:.2f} ms | flags equal {same.mean():.4f} "
+      f"max|dpx| {np.abs(pxg-pxo)[same & co].max():.2e} converged {co.mean():.3f}")
