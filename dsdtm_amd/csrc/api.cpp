@@ -54,7 +54,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" {
 
-const char* dsdtm_version(void) { return "dsdtm_amd 0.1 (gfx950, HIP; grid=" DSDTM_STR(SA_GRID_T) ")"; }
+const char* dsdtm_version(void) { return "dsdtm_amd 0.2 (gfx950, HIP; grid=" DSDTM_STR(SA_GRID_T) ", pairs/workgroup=" DSDTM_STR(SA_PPW) ")"; }
 
 int dsdtm_device_count(void) {
     int n = 0;
@@ -535,4 +535,10 @@ extern "C" int dsdtm_debug_sparse_align_stamps(dsdtm_ctx* ctx, const dsdtm_batch
     const int rc = dsdtm_sparse_align_batch_device(ctx, b, cam, prm, hip_stream);
     g_stamp_out = nullptr;
     return rc;
+}
+
+extern "C" int dsdtm_debug_occupancy(dsdtm_ctx* ctx, int variant) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    return sparse_align_occupancy(variant);
 }

@@ -21,12 +21,12 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(grid="double", force=False, verbose=True):
+def build(grid="double", force=False, verbose=True, extra=()):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-DSA_GRID_T=" + grid, "-x", "hip"]
+           "-fno-gpu-rdc", "-DSA_GRID_T=" + grid, *extra, "-x", "hip"]
     cmd += [os.path.join(HERE, s) for s in SOURCES]
     cmd += ["-o", OUT]
     if verbose:
@@ -39,6 +39,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", default=os.environ.get("DSDTM_GRID_T", "double"), choices=["double", "float"])
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--define", action="append", default=[], help="extra -D for experiments, e.g. SA_WAVES_PER_EU=5")
     a = ap.parse_args()
-    build(a.grid, a.force)
+    build(a.grid, a.force, extra=["-D" + d for d in a.define])
     print(OUT)

@@ -38,6 +38,10 @@ struct SAKernelArgs {
 #ifndef SA_GRID_T
 #define SA_GRID_T double
 #endif
+// pairs per workgroup of the <=320-feature register kernel (see sparse_align.hip)
+#ifndef SA_PPW
+#define SA_PPW 2
+#endif
 #define DSDTM_STR2(x) #x
 #define DSDTM_STR(x) DSDTM_STR2(x)
 enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2 };
@@ -45,6 +49,7 @@ SAVariant sparse_align_pick_variant(int max_features);
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features);
 hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, hipStream_t stream);
 // diagnostic (in-kernel stamps) instantiation of the 5+1-wave register kernel; workspace = n_pairs*8 u64
+int sparse_align_occupancy(int variant);   // occupancy API answer (workgroups per CU)
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, hipStream_t stream);
 
 // Align2D: one wavefront per feature.

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dsdtm_amd.h"
 #include "device_math.h"
@@ -62,7 +63,39 @@ struct BlockState {
     double Cref[3];             // reference camera centre in world (Frame::mOw)
     int ctrl;                   // 0 continue, 1 level finished
     int n_vis;
+    // pair-local synchronisation (used when several pairs share a workgroup): monotonic counters
+    unsigned arrive;            // +1 per patch wave whose partials are in LDS
+    unsigned seq;               // number of states published by the solver (1 after solver_init)
+    unsigned pad_[2];
 };
+
+// ---- pair-local synchronisation ------------------------------------------------------------
+// With PPW > 1 pairs per workgroup each pair runs its own pass/solve pipeline; s_barrier would
+// couple them, so patch waves and the pair's solver wave hand over through two monotonic LDS
+// counters instead. All waves of a workgroup are co-resident, every wait has its producer in
+// flight, and every spin is bounded (a broken protocol ends the kernel instead of hanging the GPU).
+constexpr unsigned SPIN_LIMIT = 1u << 24;
+
+__device__ __forceinline__ void pair_signal_arrive(BlockState& s, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS stores first
+    if (lane == 0) __hip_atomic_fetch_add(&s.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pair_wait_arrive(BlockState& s, unsigned target) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(&s.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < SPIN_LIMIT)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void pair_publish(BlockState& s, unsigned seq, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&s.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pair_wait_seq(BlockState& s, unsigned seq) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(&s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq && ++spins < SPIN_LIMIT)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 __device__ __forceinline__ void store_se3(double* q, double* t, const SE3d& T) {
     q[0] = T.qw; q[1] = T.qx; q[2] = T.qy; q[3] = T.qz;
@@ -219,6 +252,7 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
         }
 #pragma unroll
         for (int c = 0; c < 7; ++c) top[c] = bot[c];
+        __builtin_amdgcn_sched_barrier(0);   // same: one footprint row in flight
     }
 }
 
@@ -321,6 +355,9 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
         }
 #pragma unroll
         for (int k = 0; k < 5; ++k) top[k] = bot[k];
+        // keep the rows in program order: without this the scheduler converts the whole 5x5
+        // footprint to doubles up front (50 live VGPRs instead of the two rows in flight)
+        __builtin_amdgcn_sched_barrier(0);
     }
     chi2 = c2a + c2b;
     // the 0.5 of the central difference commutes exactly with every rounding in the sums
@@ -489,23 +526,47 @@ __device__ __forceinline__ void solver_finish(const SAKernelArgs& a, int pair, B
 // wave.
 // ---------------------------------------------------------------------------------------------
 // STAMPS = diagnostic instantiation only (dsdtm_debug_sparse_align_stamps): the solver wave
-// accumulates shader-clock cycles spent waiting for the patch waves (B1) and solving, and writes
-// them to a.workspace[pair*4 ..]; the timed/product instantiation contains no stamp.
-template <int NPW, typename GT, bool STAMPS = false>
-__global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const SAKernelArgs a) {
+// accumulates shader-clock cycles spent waiting for the patch waves and solving, and writes them to
+// a.workspace[pair*8 ..]; the timed/product instantiation contains no stamp.
+//
+// PPW = pairs per workgroup. A 6-wave group at ~166 VGPRs leaves the CU at one resident group
+// (the dispatcher does not co-schedule two such groups), but ONE 12-wave workgroup at 3 waves/SIMD
+// fits: PPW = 2 runs two independent pair pipelines in one workgroup, synchronised by the
+// pair-local counters above instead of s_barrier, so one pair's solve overlaps the other's pass and
+// the 10 patch waves balance over the 4 SIMDs.
+#ifndef SA_WAVES_PER_EU
+#define SA_WAVES_ATTR
+#else
+#define SA_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SA_WAVES_PER_EU, SA_WAVES_PER_EU)))
+#endif
+template <int NPW, typename GT, int PPW, bool STAMPS = false>
+__global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_align_reg_kernel(const SAKernelArgs a) {
     constexpr int NP = NPW * 4;            // one partial slot per 16-lane DPP row
-    __shared__ WavePartial s_part[NP];
-    __shared__ BlockState s;
+    constexpr int WPP = NPW + 1;           // waves per pair
+    __shared__ WavePartial s_part_all[PPW][NP];
+    __shared__ BlockState s_all[PPW];
 
-    const int pair = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = gwave / WPP;                              // which pair of this workgroup
+    const int wave = gwave - slot * WPP;                       // wave inside the pair
+    const int ltid = tid - slot * WPP * 64;                    // thread inside the pair
+    const int pair = blockIdx.x * PPW + slot;
+    if (PPW > 1) {
+        // LDS is uninitialised at kernel start: zero the pair-local counters and run the one real
+        // workgroup barrier of this kernel while every wave is still present
+        if (tid < PPW) { s_all[tid].arrive = 0u; s_all[tid].seq = 0u; }
+        __syncthreads();
+    }
+    if (pair >= a.n_pairs) return;                             // whole pair slot leaves together
+    WavePartial* s_part = s_part_all[slot];
+    BlockState& s = s_all[slot];
     const int nf = a.n_features ? a.n_features[pair] : a.max_features;
 
     // Run(): "Too few features to track" (:34-38) -> return 0, pose untouched
     if (nf < a.min_fts || a.max_level - 1 < a.min_level) {
-        if (tid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
+        if (ltid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
         return;
     }
 
@@ -513,8 +574,9 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const 
         // ------------------------------ solver wave ------------------------------
         unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0;
         if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
+        unsigned round = 0;                                            // completed solver rounds
         solver_init(a, pair, s, lane);
-        __syncthreads();                                               // B0
+        if (PPW == 1) __syncthreads(); else pair_publish(s, 1u, lane); // B0
         for (int level = a.max_level - 1; level >= a.min_level; --level) {
             if (lane == 0) {                                           // GaussNewtonSolver entry (:304-308)
                 s.chi2 = 0.0;
@@ -526,7 +588,8 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const 
             for (int it = 0; it < a.max_iters; ++it) {
                 unsigned long long t0 = 0, t1 = 0, t2 = 0;
                 if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
-                __syncthreads();                                       // B1
+                ++round;
+                if (PPW == 1) __syncthreads(); else pair_wait_arrive(s, (unsigned)NPW * round);   // B1
                 if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
                 const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane);
                 if (STAMPS) {
@@ -535,7 +598,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const 
                     t_solve += t2 - t1;
                     n_it += 1;
                 }
-                __syncthreads();                                       // B2
+                if (PPW == 1) __syncthreads(); else pair_publish(s, 1u + round, lane);          // B2
                 if (ctrl) break;
             }
         }
@@ -553,9 +616,10 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const 
     // ---------------------------------- patch waves ----------------------------------
     const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
     const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
-    const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + tid, tid < nf);
+    const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + ltid, ltid < nf);
     unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
-    __syncthreads();                                                   // B0
+    unsigned seen = 1;                                                 // states consumed so far
+    if (PPW == 1) __syncthreads(); else pair_wait_seq(s, 1u);          // B0
     FeatureRegs F;
     {
         const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
@@ -616,13 +680,19 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_reg_kernel(const 
             if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
             unsigned long long tq2 = 0;
             if (STAMPS) { tq2 = __builtin_amdgcn_s_memtime(); st_h += tq2 - tq1; }
-            __syncthreads();                                           // B1
-            __syncthreads();                                           // B2
+            ++seen;
+            if (PPW == 1) {
+                __syncthreads();                                       // B1
+                __syncthreads();                                       // B2
+            } else {
+                pair_signal_arrive(s, lane);                           // B1
+                pair_wait_seq(s, seen);                                // B2
+            }
             if (STAMPS) st_bar += __builtin_amdgcn_s_memtime() - tq2;
             if (s.ctrl) break;
         }
     }
-    if (STAMPS && tid == 0 && a.workspace) {
+    if (STAMPS && ltid == 0 && a.workspace) {
         unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 4;
         o[0] = st_pre; o[1] = st_pass; o[2] = st_h; o[3] = st_bar;
     }
@@ -790,21 +860,33 @@ size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
     return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
 }
 
+int sparse_align_occupancy(int variant) {
+    int nb = -1;
+    if (variant == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, false>, SA_PPW * 6 * 64, 0);
+    else if (variant == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<7, SA_GRID_T, 1, false>, 8 * 64, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<7>, 8 * 64, 0);
+    return nb;
+}
+
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, true>), dim3((unsigned)args.n_pairs), dim3(6 * 64), 0, stream, args);
+    hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, true>), dim3((unsigned)((args.n_pairs + SA_PPW - 1) / SA_PPW)),
+                       dim3(SA_PPW * 6 * 64), 0, stream, args);
     return hipGetLastError();
 }
 
 hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
     const dim3 grid((unsigned)args.n_pairs);
+    // experiment knob: unused dynamic LDS to cap the number of resident workgroups per CU
+    static const unsigned lds_pad = getenv("DSDTM_DEBUG_LDS_PAD") ? (unsigned)atoi(getenv("DSDTM_DEBUG_LDS_PAD")) : 0u;
     switch (variant) {
         case SA_REG320:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T>), grid, dim3(6 * 64), 0, stream, args);
+            hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW>), dim3((unsigned)((args.n_pairs + SA_PPW - 1) / SA_PPW)),
+                               dim3(SA_PPW * 6 * 64), lds_pad, stream, args);
             break;
         case SA_REG448:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<7, SA_GRID_T>), grid, dim3(8 * 64), 0, stream, args);
+            hipLaunchKernelGGL((sparse_align_reg_kernel<7, SA_GRID_T, 1>), grid, dim3(8 * 64), 0, stream, args);
             break;
         case SA_WS:
             hipLaunchKernelGGL((sparse_align_ws_kernel<7>), grid, dim3(8 * 64), 0, stream, args);
