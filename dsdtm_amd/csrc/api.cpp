@@ -165,7 +165,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     if (!ctx) return DSDTM_ERR_INVALID;
     if (!b || !cam) { set_err(ctx, "batch/cam is NULL"); return DSDTM_ERR_INVALID; }
     if (int rc = validate_params(ctx, prm, b->levels)) return rc;
-    if (b->n_pairs < 0 || b->max_features < 0 || b->levels <= 0 || b->levels > DSDTM_MAX_LEVELS) {
+    if (b->n_pairs < 0 || b->max_features < 0 || b->max_features > 32767 || b->levels <= 0 || b->levels > DSDTM_MAX_LEVELS) {
         set_err(ctx, "bad batch geometry"); return DSDTM_ERR_INVALID;
     }
     if (b->n_pairs == 0) return DSDTM_OK;

@@ -18,9 +18,16 @@ struct SE3d {
 };
 
 __device__ __forceinline__ void quat_normalize(SE3d& T) {
-    // one reciprocal instead of Eigen's four divisions (<= 1 ulp per coefficient; the solver wave is
-    // the serial part of every Gauss-Newton iteration, so its dependent chain is kept short)
-    const double rn = 1.0 / sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
+    // Eigen divides the four coefficients by sqrt(|q|^2). The solver wave is the serial part of
+    // every Gauss-Newton iteration, so its dependent chain is kept short: every quaternion
+    // normalised on this path is a product of unit quaternions, |q|^2 = 1 + e with |e| ~ 1e-16, and
+    // 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 to better than double precision for |e| < 1e-5 (<= 1 ulp per
+    // coefficient vs the division); anything else takes the exact path.
+    const double n2 = T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz;
+    const double e = n2 - 1.0;
+    double rn;
+    if (fabs(e) < 1e-5) rn = 1.0 + e * (-0.5 + 0.375 * e);
+    else rn = 1.0 / sqrt(n2);
     T.qw *= rn; T.qx *= rn; T.qy *= rn; T.qz *= rn;
 }
 
@@ -110,24 +117,45 @@ __device__ inline SE3d se3_inverse(const SE3d& a) {
     return r;
 }
 
-// SE3::exp([upsilon, omega]) — Sophus: quaternion from the half angle, V matrix for the translation.
-// One sincos(theta/2) serves both: sin(theta) = 2 s c, 1 - cos(theta) = 2 s^2 (no cancellation), and
-// one reciprocal of theta replaces Sophus' three divisions.
+// SE3::exp([upsilon, omega]) — Sophus: q = (cos(th/2), sin(th/2)/th * omega), t = V * upsilon with
+// V = I + (1-cos th)/th^2 * Om + (th - sin th)/th^3 * Om^2.
+// Gauss-Newton steps are small rotations, and for small th every factor above is a short power
+// series in th^2 (used for th^2 < 0.01) — no sqrt, no division, no trig call on the solver's
+// dependent chain:
+//   cos(h)            = sum (-1)^k h^2k / (2k)!          h = th/2
+//   sin(h)/th         = 1/2 * sum (-1)^k h^2k / (2k+1)!
+//   (1-cos th)/th^2   = 2 (sin(h)/th)^2
+//   (th-sin th)/th^3  = sum (-1)^k th^2k / (2k+3)!
+// (truncation < 1e-19 relative; <= 2 ulp vs libm). Larger angles use the closed forms with one
+// sincos(th/2). Sophus' own th < 1e-10 branch (V = R) is kept.
 __device__ inline SE3d se3_exp(const double* x) {
     const double ux = x[0], uy = x[1], uz = x[2];
     const double wx = x[3], wy = x[4], wz = x[5];
     const double theta_sq = wx * wx + wy * wy + wz * wz;
-    const double theta = sqrt(theta_sq);
-    double sh, ch;
-    sincos(0.5 * theta, &sh, &ch);
-    const bool small = theta < 1e-10;
-    const double inv_theta = 1.0 / theta;
-    double imag_factor;
-    if (small) {
-        const double theta_po4 = theta_sq * theta_sq;
-        imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+    double ch, imag_factor, a, b;
+    if (theta_sq < 0.01) {               // |omega| < 0.1 rad: every Gauss-Newton step in practice
+        const double h2 = 0.25 * theta_sq;
+        // Horner in h2 / theta_sq, six terms each: truncation < 1e-19 for theta_sq < 0.01
+        ch = 1.0 + h2 * (-1.0 / 2 + h2 * (1.0 / 24 + h2 * (-1.0 / 720 + h2 * (1.0 / 40320 + h2 * (-1.0 / 3628800)))));
+        const double sinc = 1.0 + h2 * (-1.0 / 6 + h2 * (1.0 / 120 + h2 * (-1.0 / 5040 + h2 * (1.0 / 362880 +
+                            h2 * (-1.0 / 39916800)))));
+        imag_factor = 0.5 * sinc;
+        a = 2.0 * imag_factor * imag_factor;
+        const double t2 = theta_sq;
+        b = 1.0 / 6 + t2 * (-1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800 +
+            t2 * (-1.0 / 6227020800.0)))));
+        if (theta_sq < 1e-20) {          // Sophus: theta < SMALL_EPS
+            const double theta_po4 = theta_sq * theta_sq;
+            imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+        }
     } else {
+        const double theta = sqrt(theta_sq);
+        double sh;
+        sincos(0.5 * theta, &sh, &ch);
+        const double inv_theta = 1.0 / theta;
         imag_factor = sh * inv_theta;
+        a = 2.0 * imag_factor * imag_factor;
+        b = (theta - 2.0 * sh * ch) * (inv_theta * inv_theta * inv_theta);
     }
     SE3d o;
     o.qw = ch;
@@ -136,12 +164,9 @@ __device__ inline SE3d se3_exp(const double* x) {
     o.qz = imag_factor * wz;
     quat_normalize(o);
     double V[9];
-    if (small) {
-        quat_to_matrix(o, V);
+    if (theta_sq < 1e-20) {
+        quat_to_matrix(o, V);            // Sophus: V = so3.matrix()
     } else {
-        const double si = sh * inv_theta;
-        const double a = 2.0 * si * si;                                  // (1 - cos theta) / theta^2
-        const double b = (theta - 2.0 * sh * ch) * (inv_theta * inv_theta * inv_theta);   // (theta - sin theta) / theta^3
         // Omega = hat(omega); Omega^2 written out as the matrix product
         const double o00 = -wz * wz - wy * wy, o01 = wy * wx, o02 = wz * wx;
         const double o10 = wx * wy, o11 = -wz * wz - wx * wx, o12 = wz * wy;
@@ -245,11 +270,16 @@ __device__ __forceinline__ void ldlt_unswap(double* d, int trk) {
     }
 }
 
-// x = H^+ b. Swapping d[K] <-> d[piv] at step K is exactly Eigen's `dst = m_transpositions * rhs`
-// (the later steps never touch d), so P*b is built while factorising; P^T replays the recorded
-// pivots in reverse at the end.
-__device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x) {
-    double m[21];
+// Factorisation of H, kept so that later right-hand sides reuse it: within a pyramid level H only
+// changes when the set of visible patches does, so most Gauss-Newton iterations skip ldlt6_factor
+// and only run ldlt6_apply on the cached factors (identical factors => identical x).
+//   m[21]   packed lower triangle: L below the diagonal, D on it
+//   dinv[6] 1/D_i
+//   tr0..4  transpositions (pivot rows) of steps 0..4
+//   dmask   bit i set when |D_i| > tolerance (the pseudo-inverse keeps that component)
+// Plain arrays and scalars (not a struct) so that every element stays in a statically indexed VGPR.
+__device__ __forceinline__ void ldlt6_factor(const double* Hu, double* m, double* dinv, int& tr0, int& tr1, int& tr2,
+                                             int& tr3, int& tr4, unsigned& dmask) {
     {   // lower triangle from the 21 upper-triangular entries (H is symmetric)
         int q = 0;
 #pragma unroll
@@ -257,20 +287,47 @@ __device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x)
 #pragma unroll
             for (int j = i; j < 6; ++j) { DSDTM_M(j, i) = Hu[q]; ++q; }
     }
+    double dummy[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // the right-hand side is permuted in ldlt6_apply
+    double cutoff = 0.0;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dinv[i] = 0.0;          // 1/D_k where the factorisation reached step k
+    tr0 = ldlt_step<0>(m, dummy, dinv, cutoff, done);
+    tr1 = ldlt_step<1>(m, dummy, dinv, cutoff, done);
+    tr2 = ldlt_step<2>(m, dummy, dinv, cutoff, done);
+    tr3 = ldlt_step<3>(m, dummy, dinv, cutoff, done);
+    tr4 = ldlt_step<4>(m, dummy, dinv, cutoff, done);
+    (void)ldlt_step<5>(m, dummy, dinv, cutoff, done);
+    if (done) {   // rank cutoff hit (rare, wave-uniform): reciprocals of the steps that were skipped
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (dinv[i] == 0.0) dinv[i] = 1.0 / DSDTM_M(i, i);
+    }
+    // pseudo-inverse of D (Eigen 3.2 LDLT::solve): components with |D_i| <= tolerance are zeroed
+    double maxd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) maxd = fmax(maxd, fabs(DSDTM_M(i, i)));
+    double tol = maxd * 2.220446049250313e-16;
+    tol = fmax(tol, 1.0 / 1.7976931348623157e308);
+    unsigned mask = 0u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (fabs(DSDTM_M(i, i)) > tol) mask |= 1u << i;
+    dmask = mask;
+}
+
+// x = H^+ b from the cached factors: dst = P b; L^-1; D^+; L^-T; P^T.
+__device__ __forceinline__ void ldlt6_apply(const double* m, const double* dinv, int tr0, int tr1, int tr2, int tr3,
+                                            int tr4, unsigned dmask, const double* b, double* x) {
     double d[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) d[i] = b[i];
-
-    double cutoff = 0.0;
-    bool done = false;
-    double rD[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // 1/D_k where the factorisation reached step k
-    const int tr0 = ldlt_step<0>(m, d, rD, cutoff, done);
-    const int tr1 = ldlt_step<1>(m, d, rD, cutoff, done);
-    const int tr2 = ldlt_step<2>(m, d, rD, cutoff, done);
-    const int tr3 = ldlt_step<3>(m, d, rD, cutoff, done);
-    const int tr4 = ldlt_step<4>(m, d, rD, cutoff, done);
-    (void)ldlt_step<5>(m, d, rD, cutoff, done);
-
+    // P b: swap d[K] <-> d[tr_K] for K = 0..4 (selects keep d[] statically indexed)
+    ldlt_unswap<0>(d, tr0);
+    ldlt_unswap<1>(d, tr1);
+    ldlt_unswap<2>(d, tr2);
+    ldlt_unswap<3>(d, tr3);
+    ldlt_unswap<4>(d, tr4);
     // L^-1
 #pragma unroll
     for (int i = 1; i < 6; ++i) {
@@ -279,19 +336,9 @@ __device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x)
         for (int j = 0; j < i; ++j) s += DSDTM_M(i, j) * d[j];
         d[i] -= s;
     }
-    // D^+ (pseudo-inverse of the diagonal)
-    double maxd = 0.0;
+    // D^+
 #pragma unroll
-    for (int i = 0; i < 6; ++i) maxd = fmax(maxd, fabs(DSDTM_M(i, i)));
-    double tol = maxd * 2.220446049250313e-16;
-    tol = fmax(tol, 1.0 / 1.7976931348623157e308);
-    if (done) {   // rank cutoff hit (rare, wave-uniform): reciprocals of the steps that were skipped
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (rD[i] == 0.0) rD[i] = 1.0 / DSDTM_M(i, i);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) d[i] = (fabs(DSDTM_M(i, i)) > tol) ? d[i] * rD[i] : 0.0;
+    for (int i = 0; i < 6; ++i) d[i] = ((dmask >> i) & 1u) ? d[i] * dinv[i] : 0.0;
     // L^-T
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
@@ -300,7 +347,7 @@ __device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x)
         for (int j = i + 1; j < 6; ++j) s += DSDTM_M(j, i) * d[j];
         d[i] -= s;
     }
-    // P^T
+    // P^T: the same transpositions in reverse order
     ldlt_unswap<4>(d, tr4);
     ldlt_unswap<3>(d, tr3);
     ldlt_unswap<2>(d, tr2);
@@ -308,6 +355,14 @@ __device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x)
     ldlt_unswap<0>(d, tr0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = d[i];
+}
+
+__device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x) {
+    double m[21], dinv[6];
+    int tr0, tr1, tr2, tr3, tr4;
+    unsigned dmask;
+    ldlt6_factor(Hu, m, dinv, tr0, tr1, tr2, tr3, tr4, dmask);
+    ldlt6_apply(m, dinv, tr0, tr1, tr2, tr3, tr4, dmask, b, x);
 }
 #undef DSDTM_M
 
@@ -332,6 +387,17 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
     v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
     v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
     return v;
+}
+
+// Wavefront sum of an int, result broadcast to every lane (wave-uniform, returned through an SGPR).
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);  // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);  // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);  // row_ror:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Sum over the 16 lanes of each DPP row only; every lane of a row ends up holding its row's sum.

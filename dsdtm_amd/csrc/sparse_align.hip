@@ -56,7 +56,10 @@ struct BlockState {
     double qo[4], to[3];        // T_c2r before the last accepted step (tT_c2rOld)
     double chi2;
     double qr[4], tr[3];        // T_ref_w
-    double Hsum[21];            // sum of the per-wave H partials (valid while no wave's ballot changed)
+    double Hsum[21];            // sum of the per-row H partials of the last change of the visible set
+    double Fm[21], Fdinv[6];    // cached LDLT factors of Hsum (ldlt6_factor), reused until the set changes
+    int Ftr[5];
+    unsigned Fmask;
     double bsum[7];             // b totals + chi2 total of the current iteration
     // published to the patch waves
     double R[9], tt[3];         // rotation matrix + translation of T_c2r for the residual pass
@@ -406,23 +409,55 @@ __device__ __forceinline__ void solver_init(const SAKernelArgs& a, int pair, Blo
     }
 }
 
+// Factorise BlockState::Hsum and park the factors in BlockState (LDS). Deliberately NOT inlined:
+// it runs only when the visible set changed (about once per pyramid level), and keeping its ~60
+// live registers out of solver_step's allocation keeps the whole kernel inside the 168-VGPR budget
+// of a 12-wave workgroup without spills on the per-iteration path.
+__device__ __attribute__((noinline)) void factor_to_lds(BlockState* sp, int lane) {
+    BlockState& s = *sp;
+    double H[21], Fm[21], Fdinv[6];
+    int tr0, tr1, tr2, tr3, tr4;
+    unsigned dmask;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) H[i] = s.Hsum[i];
+    ldlt6_factor(H, Fm, Fdinv, tr0, tr1, tr2, tr3, tr4, dmask);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 21; ++i) s.Fm[i] = Fm[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s.Fdinv[i] = Fdinv[i];
+        s.Ftr[0] = tr0; s.Ftr[1] = tr1; s.Ftr[2] = tr2; s.Ftr[3] = tr3; s.Ftr[4] = tr4;
+        s.Fmask = dmask;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Solver wave, one Gauss-Newton iteration (reference :310-343). Executed uniformly by all 64
 // lanes of the solver wave (same cost as one lane); lane 0 publishes. Returns ctrl.
 template <int NP>   // NP = number of partial slots (rows or waves)
 __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int level, int it,
-                                           const WavePartial* s_part, BlockState& s, int lane) {
+                                           const WavePartial* s_part, BlockState& s, int lane,
+                                           unsigned long long* tacc = nullptr /* diagnostic build only */) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    if (tacc) ts0 = __builtin_amdgcn_s_memtime();
     // Cross-wave totals, lane-parallel: lane q<21 sums H[q], lanes 21..26 sum b, lane 27 chi2
     // (fixed wave order -> deterministic). Totals go through LDS so that only the values the
     // solve needs are ever live in registers.
-    int cnt = 0, changed = 0, n_ref = 0;
-#pragma unroll
-    for (int w = 0; w < NP; ++w) {
-        cnt += s_part[w].cnt;
-        changed |= s_part[w].h_changed;
-        n_ref += s_part[w].n_ref;
+    static_assert(NP <= 64, "one lane per partial slot");
+    // counters: lane w < NP reads slot w; cnt and n_ref (< 2^15 patches per pair, checked by the
+    // launcher) share one int and are summed over the wave with one DPP reduction
+    int packed = 0;
+    bool chg = false;
+    if (lane < NP) {
+        packed = s_part[lane].cnt | (s_part[lane].n_ref << 16);
+        chg = s_part[lane].h_changed != 0;
     }
-    cnt = __builtin_amdgcn_readfirstlane(cnt);
-    changed = __builtin_amdgcn_readfirstlane(changed);
+    packed = wave_sum_i32(packed);
+    const int cnt = packed & 0xffff;
+    const int n_ref = (packed >> 16) & 0xffff;
+    const int changed = __ballot(chg) != 0ull;
     {
         constexpr int WP = sizeof(WavePartial) / sizeof(double);
         const double* base = (const double*)s_part;
@@ -430,8 +465,8 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
         const int off = lane < 21 ? (9 + lane) : (lane - 21);
         if (lane < 28 && (changed || lane >= 21)) {
             double acc = 0.0;
-#pragma unroll
-            for (int w = 0; w < NP; ++w) acc += base[w * WP + off];
+#pragma unroll 4
+            for (int w = 0; w < NP; ++w) acc += base[w * WP + off];   // fixed slot order: deterministic
             if (lane < 21) s.Hsum[lane] = acc;
             else s.bsum[lane - 21] = acc;
         }
@@ -439,15 +474,27 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    double H[21], bs[6];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) H[i] = s.Hsum[i];
+    double bs[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) bs[i] = s.bsum[i];
     const double chi2s = s.bsum[6];
+    if (tacc) { asm volatile("" : "+v"(bs[0])); ts1 = __builtin_amdgcn_s_memtime(); }
     const double chi2New = chi2s / (double)(16 * cnt);     // :298 (0/0 -> NaN)
+    // H.ldlt().solve(JRes) (:318). H is unchanged while the visible set is: factorise only when a
+    // row reported a new ballot, otherwise reuse the cached factors (same factors => same x).
+    if (changed) factor_to_lds(&s, lane);    // out-of-line: ~4 calls per alignment
+    __builtin_amdgcn_sched_barrier(0);   // keep the solver's sub-steps in order: short live ranges, no spills
     double x[6];
-    ldlt6_solve(H, bs, x);                                 // :318
+    {
+        double Fm[21], Fdinv[6];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) Fm[i] = s.Fm[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Fdinv[i] = s.Fdinv[i];
+        ldlt6_apply(Fm, Fdinv, s.Ftr[0], s.Ftr[1], s.Ftr[2], s.Ftr[3], s.Ftr[4], s.Fmask, bs, x);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tacc) { asm volatile("" : "+v"(x[0])); ts2 = __builtin_amdgcn_s_memtime(); }
     const bool stop = (x[0] != x[0]);                      // :321 isnan(x(0))
     const double chi2_prev = s.chi2;
     int ctrl = 0, exit_code = 0;
@@ -464,9 +511,11 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
         ctrl = 1;
         exit_code = stop ? 3 : 1;
     } else {
-        const SE3d Tcur = load_se3(s.q, s.t);
         const SE3d dT = se3_exp(x);
+        __builtin_amdgcn_sched_barrier(0);
+        const SE3d Tcur = load_se3(s.q, s.t);
         const SE3d Tn = se3_mul(Tcur, dT);                 // :335 right-multiply
+        __builtin_amdgcn_sched_barrier(0);
         double Rn[9];
         quat_to_matrix(Tn, Rn);
         double mx = 0.0;
@@ -483,6 +532,7 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
         if (mx <= 1e-8) { ctrl = 1; exit_code = 2; }        // :341
     }
     ctrl = __builtin_amdgcn_readfirstlane(ctrl);
+    if (tacc) { ts3 = __builtin_amdgcn_s_memtime(); tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; tacc[2] += ts3 - ts2; }
     if (lane == 0) {
         s.ctrl = ctrl;
         s.n_vis = cnt;
@@ -573,8 +623,12 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     if (wave == NPW) {
         // ------------------------------ solver wave ------------------------------
         unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0;
+        unsigned long long t_sub[3] = {0, 0, 0};
         if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
         unsigned round = 0;                                            // completed solver rounds
+        // The solve is the serial section of this pair's iteration, and this wave shares its SIMD
+        // with patch waves of the workgroup's other pair: give it issue priority.
+        if (PPW > 1) __builtin_amdgcn_s_setprio(2);
         solver_init(a, pair, s, lane);
         if (PPW == 1) __syncthreads(); else pair_publish(s, 1u, lane); // B0
         for (int level = a.max_level - 1; level >= a.min_level; --level) {
@@ -591,7 +645,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 ++round;
                 if (PPW == 1) __syncthreads(); else pair_wait_arrive(s, (unsigned)NPW * round);   // B1
                 if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
-                const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane);
+                const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, STAMPS ? t_sub : nullptr);
                 if (STAMPS) {
                     t2 = __builtin_amdgcn_s_memtime();
                     if (it == 0) t_first += t1 - t0; else t_wait += t1 - t0;
@@ -607,8 +661,9 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 8;
             o[0] = t_first; o[1] = t_wait; o[2] = t_solve; o[3] = n_it;
             o[4] = __builtin_amdgcn_s_memtime() - t_begin;
-            o[5] = __builtin_amdgcn_s_memrealtime();
-            o[6] = t_begin;
+            o[5] = t_sub[0];
+            o[6] = t_sub[1];
+            o[7] = t_sub[2];
         }
         return;
     }

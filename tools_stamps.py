@@ -25,6 +25,5 @@ n_it = s[:, 3]
 print("pairs", a.pairs, "iterations/pair mean", n_it.mean())
 print("cycles per block: total %.0f | first-pass waits (4 levels) %.0f | later-pass waits %.0f | solve %.0f" % (s[:,4].mean(), s[:,0].mean(), s[:,1].mean(), s[:,2].mean()))
 print("per first pass %.0f | per later pass %.0f | per solve %.0f cycles" % ((s[:,0]/4).mean(), (s[:,1]/np.maximum(n_it-4,1)).mean(), (s[:,2]/n_it).mean()))
-span = s[:,6].max() - s[:,6].min()
-print("block start spread (cycles)", span, " start->end max", (s[:,6]+s[:,4]).max() - s[:,6].min())
+print("solve sub-phases per solve: sums+LDS %.0f | factor/apply %.0f | exp+compose+publish %.0f" % ((s[:,5]/n_it).mean(), (s[:,6]/n_it).mean(), (s[:,7]/n_it).mean()))
 print("wave0: precompute %.0f (per level %.0f) | passes %.0f (per pass %.0f) | H-block+store %.0f | barriers(wait for solver) %.0f" % (w[:,0].mean(), (w[:,0]/4).mean(), w[:,1].mean(), (w[:,1]/n_it).mean(), w[:,2].mean(), w[:,3].mean()))
