@@ -1,0 +1,207 @@
+"""Feature_Alignment's reprojection grid and SearchLocalPoints (reference
+src/Feature_alignment.cpp:22-126, FindMatchDirect :128-158) as a speculative GPU batch plus a
+host replay of the reference's order-dependent side effects.
+
+The reference walks the cells in index order and, per cell, tries candidates one by one
+(warp + Align2D on the CPU) until one converges; a success paints a mask disc that can suppress
+candidates of later cells, and the search stops after 200 matched cells. FindMatchDirect itself
+has no side effect besides refining the candidate's pixel, so all candidates can be matched
+speculatively in two launches (dsdtm_warp_patches, dsdtm_align2d_batch); the sequential rules are
+then replayed on the (converged, px, level) triples. No image data is touched on the host.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from . import capi
+from . import feature_alignment as FA
+from .frame import Config, Frame
+
+mHalf_PatchSize = 4
+
+
+def cvRound(x: float) -> int:
+    """OpenCV 2.4 cvRound (SSE2 cvtsd2si): round half to even."""
+    return int(np.rint(x))
+
+
+def is_in_image(cam, x: float, y: float, boundary: int, level: int = 0) -> bool:
+    """Camera::IsInImage (src/Camera.cpp:187-193)."""
+    return (cvRound(x) >= boundary and cvRound(x) < cam.width // (1 << level) - boundary and
+            cvRound(y) >= boundary and cvRound(y) < cam.height // (1 << level) - boundary)
+
+
+def fill_circle(mask: np.ndarray, cx: int, cy: int, radius: int, value: int = 0):
+    """cv::circle(img, center, radius, value, -1) for 8-bit masks: OpenCV 2.4 drawing.cpp Circle()
+    (midpoint algorithm, filled by horizontal spans, clipped to the image)."""
+    h, w = mask.shape
+    err, dx, dy, plus, minus = 0, radius, 0, 1, (radius << 1) - 1
+
+    def hline(y, x1, x2):
+        if 0 <= y < h:
+            x1, x2 = max(x1, 0), min(x2, w - 1)
+            if x1 <= x2:
+                mask[y, x1:x2 + 1] = value
+
+    while dx >= dy:
+        hline(cy - dy, cx - dx, cx + dx)
+        hline(cy + dy, cx - dx, cx + dx)
+        hline(cy - dx, cx - dy, cx + dy)
+        hline(cy + dx, cx - dy, cx + dy)
+        dy += 1
+        err += plus
+        plus += 2
+        m = -1 if err > 0 else 0          # mask = (err <= 0) - 1
+        err -= minus & m
+        dx += m
+        minus -= m & 2
+
+
+@dataclasses.dataclass
+class MapPoint:
+    """What the search reads from DSDTM::MapPoint (include/MapPoint.h): position, observations
+    (keyframe index -> feature index, iterated in keyframe-index order), found counter, bad flag."""
+    mPose: np.ndarray
+    mObservations: dict
+    mnFound: int = 1
+    mbBad: bool = False
+
+    def Get_Pose(self):
+        return self.mPose
+
+    def IsBad(self):
+        return self.mbBad
+
+    def Get_FoundNums(self):
+        return self.mnFound
+
+    def IncreaseFound(self, n=1):
+        self.mnFound += n
+
+
+class KeyFrame(Frame):
+    """Frame + the identity the observations refer to (include/Keyframe.h:78 shares mvImg_Pyr)."""
+
+    def __init__(self, camera, img_pyr, T_c2w, kf_id):
+        super().__init__(camera, img_pyr, T_c2w)
+        self.mnId = kf_id
+
+
+def get_closest_obs(mp: MapPoint, frame: Frame, keyframes):
+    """MapPoint::Get_ClosetObs (src/MapPoint.cpp:133-174): observation whose viewing direction is
+    closest to the frame's; rejected when cos < 0.5. Returns (kf_index, feature_index) or None."""
+    if not mp.mObservations:
+        return None
+    v = frame.Get_CameraCnt() - mp.mPose
+    v = v / np.linalg.norm(v)
+    best, best_cos = None, 0.0
+    first = None
+    for kf_idx in sorted(mp.mObservations):
+        if first is None:
+            first = kf_idx
+        r = keyframes[kf_idx].Get_CameraCnt() - mp.mPose
+        r = r / np.linalg.norm(r)
+        c = float(r @ v)
+        if c > best_cos:
+            best_cos, best = c, kf_idx
+    if best is None:
+        best = first
+    if best_cos < 0.5:
+        return None
+    return best, mp.mObservations[best]
+
+
+class LocalPointSearch(FA.Feature_Alignment):
+    """Feature_Alignment(CameraPtr) with ResetGrid / ReprojectPoint / SearchLocalPoints."""
+
+    def __init__(self, camera, ctx=None):
+        super().__init__(camera, ctx)
+        self.mMax_pts = Config.Get("Camera.Max_tkfts")
+        self.mPyr_levels = Config.Get("Camera.MaxPyraLevels")
+        self.mCell_size = Config.Get("Camera.CellSize")
+        self.mGrid_Rows = int(np.ceil(camera.height / self.mCell_size))      # :29-30
+        self.mGrid_Cols = int(np.ceil(camera.width / self.mCell_size))
+        self.mCells = [[] for _ in range(self.mGrid_Rows * self.mGrid_Cols)]
+        self.last_stats = {}
+
+    def ResetGrid(self):                                                      # :46-52
+        for c in self.mCells:
+            c.clear()
+
+    def ReprojectPoint(self, tFrame: Frame, tMPoint: MapPoint) -> bool:      # :54-69
+        px = tFrame.World2Pixel(tMPoint.Get_Pose())
+        if not (np.isfinite(px).all() and is_in_image(self.mCam, px[0], px[1], 8)):
+            return False
+        index = int(px[1] / self.mCell_size) * self.mGrid_Cols + int(px[0] / self.mCell_size)
+        self.mCells[index].append([tMPoint, np.array(px, np.float64)])
+        return True
+
+    def SearchLocalPoints(self, tFrame: Frame, keyframes, img_mask: np.ndarray | None = None):
+        """:71-121. tFrame gains features (px, level, map point); returns the list of
+        (cell index, MapPoint, px, level) matches in the order the reference creates them."""
+        cam = self.mCam
+        if img_mask is None:
+            img_mask = np.full((cam.height, cam.width), 255, np.uint8)       # Frame::mImgMask
+        # ---- speculative part: every live candidate of every cell --------------------------------
+        cand = []                                      # (cell, position in sorted cell, mp, px0)
+        order = []
+        for ci, cell in enumerate(self.mCells):
+            cell.sort(key=lambda c: -c[0].Get_FoundNums())                   # :88, stable like std::list::sort
+            for pos, (mp, px) in enumerate(cell):
+                order.append((ci, pos))
+                if mp.IsBad():
+                    continue
+                obs = get_closest_obs(mp, tFrame, keyframes)                 # :135
+                if obs is None:
+                    continue
+                kf_idx, f_idx = obs
+                kf = keyframes[kf_idx]
+                rpx, rlv = kf.px[f_idx], int(kf.level[f_idx])
+                if not is_in_image(cam, rpx[0] / (1 << rlv), rpx[1] / (1 << rlv), mHalf_PatchSize + 1, rlv):
+                    continue                                                 # :138-140
+                cand.append((ci, pos, kf_idx, f_idx))
+        results = {}
+        if cand:
+            ck = np.array([c[2] for c in cand], np.int32)
+            fi = [c[3] for c in cand]
+            ref_px = np.array([keyframes[k].px[f] for k, f in zip(ck, fi)], np.float32)
+            ref_lv = np.array([keyframes[k].level[f] for k, f in zip(ck, fi)], np.int32)
+            ref_b = np.array([keyframes[k].bearing[f] for k, f in zip(ck, fi)], np.float64)
+            # SolveAffineMatrix uses tReferFeature->Mpt->Get_Pose() (:167), i.e. the same map point
+            pw = np.array([self.mCells[c[0]][c[1]][0].Get_Pose() for c in cand], np.float64)
+            aff, sl, pb, pp = FA.warp_patches([k.mvImg_Pyr for k in keyframes], cam,
+                                              np.array([k.Get_Pose() for k in keyframes]), tFrame.Get_Pose(),
+                                              ck, ref_px, ref_lv, ref_b, pw, self.mPyr_levels - 3, ctx=self._ctx)
+            px0 = np.array([self.mCells[c[0]][c[1]][1] / (1 << int(s)) for c, s in zip(cand, sl)])   # :150
+            conv, pxr = FA.align2d_batch(tFrame.mvImg_Pyr, pb, pp, sl, px0, 10, ctx=self._ctx)       # :152
+            for c, ok, p, s in zip(cand, conv, pxr, sl):
+                results[(c[0], c[1])] = (bool(ok), p * (1 << int(s)), int(s))                        # :154-156
+        # ---- replay of the sequential rules --------------------------------------------------------
+        matches = []
+        n_matches = 0
+        for ci, cell in enumerate(self.mCells):                              # :75 index order
+            for pos, (mp, px) in enumerate(cell):
+                if mp.IsBad():                                               # :93
+                    continue
+                if img_mask[cvRound(px[1]), cvRound(px[0])] != 255:          # :96 (Point2f -> Point rounds)
+                    continue
+                r = results.get((ci, pos))
+                if r is None or not r[0]:                                    # :101-104
+                    continue
+                ok, pxn, lvl = r
+                mp.IncreaseFound()                                           # :106
+                fill_circle(img_mask, cvRound(pxn[0]), cvRound(pxn[1]), self.mCell_size, 0)   # :111
+                matches.append((ci, mp, pxn.astype(np.float32), lvl))        # Feature(px as Point2f, level)
+                n_matches += 1
+                break                                                        # :117 first success wins
+            if n_matches >= 200:                                             # :80
+                break
+        # Frame::Add_Feature / Add_MapPoint (:113-114)
+        if matches:
+            new_px = np.array([m[2] for m in matches], np.float32)
+            tFrame.px = np.concatenate([tFrame.px, new_px]) if tFrame.n_features else new_px
+            tFrame.level = np.concatenate([tFrame.level, np.array([m[3] for m in matches], np.int32)])
+        self.last_stats = dict(candidates=len(cand), matched=n_matches)
+        return matches

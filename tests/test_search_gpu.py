@@ -1,0 +1,103 @@
+"""SearchLocalPoints: speculative GPU matching + host replay vs the sequential CPU restatement."""
+import copy
+
+import numpy as np
+import pytest
+
+from dsdtm_amd import search, synth
+from dsdtm_amd.frame import Config, Frame
+from tests import search_restatement as SR
+
+
+def make_world(seed, n_points=900, n_kf=3, width=640, height=480, cell=25):
+    """A textured plane seen by n_kf keyframes and one current frame; map points on the plane with
+    observations in the keyframes."""
+    rng = np.random.default_rng(seed)
+    cam = synth.Camera.tum(width, height)
+    tex = synth.make_texture(height, width, seed)
+    depth = 2.0
+    frames = []
+    poses = [np.eye(4)] + [synth.se3_exp(np.concatenate([rng.uniform(-0.06, 0.06, 3), rng.uniform(-0.03, 0.03, 3)])) for _ in range(n_kf)]
+    imgs = [np.clip(np.rint(tex), 0, 255).astype(np.uint8)] + [synth.warp_plane(tex, cam, T, depth) for T in poses[1:]]
+    kfs = [search.KeyFrame(cam, synth.build_pyramid(imgs[i], 5), poses[i][:3], i) for i in range(n_kf)]
+    cur = Frame(cam, synth.build_pyramid(imgs[n_kf], 5), poses[n_kf][:3])
+    # map points: plane points (world == first keyframe's camera frame)
+    uv = np.stack([rng.uniform(20, width - 20, n_points), rng.uniform(20, height - 20, n_points)], 1)
+    ray = np.stack([(uv[:, 0] - cam.cx) / cam.fx, (uv[:, 1] - cam.cy) / cam.fy, np.ones(n_points)], 1)
+    P = ray * depth
+    feats = [[] for _ in range(n_kf)]
+    mps = []
+    for i in range(n_points):
+        obs = {}
+        for k in range(n_kf):
+            if rng.random() < 0.7:
+                px = kfs[k].World2Pixel(P[i])
+                lvl = int(rng.integers(0, 2))
+                if 12 * (1 << lvl) < px[0] < width - 12 * (1 << lvl) and 12 * (1 << lvl) < px[1] < height - 12 * (1 << lvl):
+                    obs[k] = len(feats[k])
+                    feats[k].append((px.astype(np.float32), lvl))
+        mps.append(search.MapPoint(P[i].copy(), obs, mnFound=int(rng.integers(1, 6)), mbBad=bool(rng.random() < 0.03)))
+    for k in range(n_kf):
+        px = np.array([f[0] for f in feats[k]], np.float32).reshape(-1, 2)
+        kfs[k].set_features(px, synth.bearing_from_px(cam, px), np.zeros((len(px), 3)), np.ones(len(px), np.uint8),
+                            level=np.array([f[1] for f in feats[k]], np.int32))
+    return cam, kfs, cur, mps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4])
+def test_search_local_points_matches_sequential_reference_flow(gpu_ctx, seed):
+    Config.Set("Camera.CellSize", 25)
+    Config.Set("Camera.MaxPyraLevels", 5)
+    cam, kfs, cur, mps = make_world(seed)
+    s = search.LocalPointSearch(cam, ctx=gpu_ctx)
+    s.ResetGrid()
+    n_in = sum(s.ReprojectPoint(cur, mp) for mp in mps)
+    assert n_in > 500
+    cells_copy = [[[c[0], c[1].copy()] for c in cell] for cell in s.mCells]
+    mps_before = {id(mp): mp.mnFound for mp in mps}
+    mask_g = np.full((cam.height, cam.width), 255, np.uint8)
+    got = s.SearchLocalPoints(cur, kfs, mask_g)
+    # sequential restatement on an identical copy of the state
+    for mp in mps:
+        mp.mnFound = mps_before[id(mp)]
+    mask_o = np.full((cam.height, cam.width), 255, np.uint8)
+    want = SR.search_local_points(cells_copy, cur, kfs, cam, 25, 5, mask_o)
+    assert len(got) == len(want) and len(got) >= 150, (len(got), len(want))
+    assert [g[0] for g in got] == [w[0] for w in want]                    # same cells, same order
+    assert all(g[1] is w[1] for g, w in zip(got, want))                   # same map point per cell
+    assert [g[3] for g in got] == [w[3] for w in want]                    # same search level
+    dpx = np.abs(np.array([g[2] for g in got]) - np.array([w[2] for w in want])).max()
+    assert dpx < 2e-3, dpx
+    assert np.array_equal(mask_g, mask_o)
+    assert len(got) <= 200
+
+
+def test_fill_circle_matches_independent_version():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = np.full((60, 80), 255, np.uint8); b = a.copy()
+        cx, cy, r = int(rng.integers(-5, 85)), int(rng.integers(-5, 65)), int(rng.integers(0, 30))
+        search.fill_circle(a, cx, cy, r, 0)
+        SR.circle_filled(b, cx, cy, r)
+        assert np.array_equal(a, b)
+        yy, xx = np.mgrid[0:60, 0:80]
+        disc = (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r
+        assert (a[disc & ((xx - cx) ** 2 + (yy - cy) ** 2 <= (r - 1) ** 2 if r > 0 else disc)] == 0).all()   # interior is painted
+
+
+def test_grid_and_reproject_point():
+    Config.Set("Camera.CellSize", 25)
+    cam = synth.Camera.tum(640, 480)
+    s = search.LocalPointSearch.__new__(search.LocalPointSearch)
+    search.FA.Feature_Alignment.__init__(s, cam, None)
+    s.mCell_size = 25
+    s.mGrid_Rows, s.mGrid_Cols = int(np.ceil(480 / 25)), int(np.ceil(640 / 25))
+    s.mCells = [[] for _ in range(s.mGrid_Rows * s.mGrid_Cols)]
+    assert (s.mGrid_Rows, s.mGrid_Cols) == (20, 26)
+    f = Frame(cam, [np.zeros((480, 640), np.uint8)], np.eye(4)[:3])
+    mp_in = search.MapPoint(np.array([0.0, 0.0, 2.0]), {})
+    mp_out = search.MapPoint(np.array([5.0, 0.0, 2.0]), {})
+    assert s.ReprojectPoint(f, mp_in) and not s.ReprojectPoint(f, mp_out)
+    px = f.World2Pixel(mp_in.mPose)
+    assert len(s.mCells[int(px[1] / 25) * 26 + int(px[0] / 25)]) == 1
