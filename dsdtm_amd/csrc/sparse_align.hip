@@ -111,6 +111,11 @@ __device__ __forceinline__ SE3d load_se3(const double* q, const double* t) {
     return T;
 }
 
+// 12 bytes at a 4-byte aligned address as ONE global_load_dwordx3: a scattered wave-load costs ~64
+// L1 tag lookups whatever its width, so footprint rows are fetched with as few instructions as possible.
+struct __attribute__((packed, aligned(4))) U32x3 { uint32_t a, b, c; };
+struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a, b; };
+
 // byte k (0..3) of a dword as double (v_cvt_f32_ubyteK + v_cvt_f64_f32; exact)
 __device__ __forceinline__ double ub(uint32_t w, int k) {
     return (double)(float)((w >> (8 * k)) & 0xffu);
@@ -201,10 +206,14 @@ __device__ __forceinline__ FeatureRegs make_feature(const FeatureRaw& r, const d
 
 // Per-level part of GetJocabianMat for one feature (reference :89-100, :123-162), producing the
 // register-resident state.
+// `staged` (may be null) points at this lane's 7 footprint rows of this level in LDS, packed as
+// 2 dwords per row with stride `staged_stride` dwords (see stage_footprints); otherwise the rows are
+// gathered from the pyramid in HBM.
 template <typename GT>
 __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const LevelGeom& lg, int level,
                                                  const uint8_t* __restrict__ ref_base,  // pair's ref pyramid
-                                                 const FeatureRegs& F, PatchRegs<GT>& P) {
+                                                 const FeatureRegs& F, PatchRegs<GT>& P,
+                                                 const uint32_t* staged = nullptr, int staged_stride = 0) {
     P.valid = false;
     P.X[0] = F.X[0]; P.X[1] = F.X[1]; P.X[2] = F.X[2];
 #pragma unroll
@@ -237,13 +246,22 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
     double top[7], bot[7];
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-        const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
-        const uint32_t dw = o >> 2;
-        const uint32_t sh = (o & 3u) * 8u;
-        const uint32_t w0 = img32[dw], w1 = img32[dw + 1];
-        const uint32_t w2 = img32[min(dw + 2, last_dw)];
-        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);     // bytes 0..3
-        const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);     // bytes 4..7
+        uint32_t lo, hi;
+        if (staged) {
+            lo = staged[(2 * r) * staged_stride];
+            hi = staged[(2 * r + 1) * staged_stride];
+        } else {
+            const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
+            const uint32_t dw = o >> 2;
+            const uint32_t sh = (o & 3u) * 8u;
+            // (dw+2 may be the dword after the last pixel of the pyramid: shift the window back by one
+            // dword there; wave-uniformly false except at the very end of the allocation)
+            const uint32_t dwc = min(dw, last_dw - 2u);
+            const U32x3 w = *(const U32x3*)(img32 + dwc);
+            const uint32_t w0 = (dwc == dw) ? w.a : w.b, w1 = (dwc == dw) ? w.b : w.c, w2 = (dwc == dw) ? w.c : 0u;
+            lo = __builtin_amdgcn_alignbit(w1, w0, sh);                 // bytes 0..3
+            hi = __builtin_amdgcn_alignbit(w2, w1, sh);                 // bytes 4..7
+        }
         bot[0] = ub(lo, 0); bot[1] = ub(lo, 1); bot[2] = ub(lo, 2); bot[3] = ub(lo, 3);
         bot[4] = ub(hi, 0); bot[5] = ub(hi, 1); bot[6] = ub(hi, 2);
         if (r > 0) {
@@ -257,6 +275,61 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
         for (int c = 0; c < 7; ++c) top[c] = bot[c];
         __builtin_amdgcn_sched_barrier(0);   // same: one footprint row in flight
     }
+}
+
+// Prologue staging: the 7x7 reference footprints of the first STAGE_LEVELS pyramid levels of one
+// feature are gathered from HBM in ONE overlapped round trip (all loads issued before any is used)
+// and parked in LDS as 14 dwords per level ([level][k][lane], conflict-free). Each level's
+// precompute then starts from LDS instead of a cold, dependent gather (features -> address -> image).
+#ifndef SA_STAGE_LEVELS
+#define SA_STAGE_LEVELS 0
+#endif
+constexpr int STAGE_LEVELS = SA_STAGE_LEVELS;   // 0 = gather per level (default: measured faster)
+__device__ __forceinline__ bool level_valid(const FeatureRegs& F, const LevelGeom& lg, int level, double& px, double& py) {
+    const double scale = (double)(1.0f / (float)(1 << level));
+    px = (double)F.px * scale;
+    py = (double)F.py * scale;
+    return F.ok && !(px - 3.0 < 0 || py - 3.0 < 0 || px + 3.0 >= (double)lg.w || py + 3.0 >= (double)lg.h ||
+                     !(px == px) || !(py == py));
+}
+
+__device__ __forceinline__ void stage_footprints(const SAKernelArgs& a, const uint8_t* __restrict__ ref_base,
+                                                 float fpx, float fpy, bool ok, uint32_t* lds_lane, int stride) {
+    const uint32_t* __restrict__ img32 = (const uint32_t*)ref_base;
+    const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
+    FeatureRegs F;
+    F.px = fpx; F.py = fpy; F.ok = ok; F.X[0] = F.X[1] = F.X[2] = 0.0;
+    uint32_t lo[STAGE_LEVELS > 0 ? STAGE_LEVELS : 1][7], hi[STAGE_LEVELS > 0 ? STAGE_LEVELS : 1][7];
+#pragma unroll
+    for (int sl = 0; sl < STAGE_LEVELS; ++sl) {
+        const int level = a.max_level - 1 - sl;
+        const bool act = level >= a.min_level;
+        const LevelGeom lg = a.lv[act ? level : a.min_level];
+        double px, py;
+        const bool v = act && level_valid(F, lg, act ? level : a.min_level, px, py);
+        const int fu = v ? (int)floor(px) : 3, fv = v ? (int)floor(py) : 3;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
+            const uint32_t dw = o >> 2;
+            const uint32_t sh = (o & 3u) * 8u;
+            uint32_t w0 = 0, w1 = 0, w2 = 0;
+            if (v) {
+                const uint32_t dwc = min(dw, last_dw - 2u);
+                const U32x3 w = *(const U32x3*)(img32 + dwc);
+                w0 = (dwc == dw) ? w.a : w.b; w1 = (dwc == dw) ? w.b : w.c; w2 = (dwc == dw) ? w.c : 0u;
+            }
+            lo[sl][r] = __builtin_amdgcn_alignbit(w1, w0, sh);
+            hi[sl][r] = __builtin_amdgcn_alignbit(w2, w1, sh);
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < STAGE_LEVELS; ++sl)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            lds_lane[(sl * 14 + 2 * r) * stride] = lo[sl][r];
+            lds_lane[(sl * 14 + 2 * r + 1) * stride] = hi[sl][r];
+        }
 }
 
 // Per-patch Gauss-Newton matrix  Sxx A A^T + Sxy (A B^T + B A^T) + Syy B B^T  (upper triangle,
@@ -336,9 +409,9 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
         const uint32_t o = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 2);
         const uint32_t dw = o >> 2;
         const uint32_t sh = (o & 3u) * 8u;
-        const uint32_t w0 = img32[dw], w1 = img32[dw + 1];
-        wlo[r] = __builtin_amdgcn_alignbit(w1, w0, sh);   // bytes 0..3 of the row
-        whi[r] = w1 >> sh;                                 // byte 4 in bits 0..7
+        const U32x2 w = *(const U32x2*)(img32 + dw);        // one global_load_dwordx2
+        wlo[r] = __builtin_amdgcn_alignbit(w.b, w.a, sh);  // bytes 0..3 of the row
+        whi[r] = w.b >> sh;                                 // byte 4 in bits 0..7
     }
     double top[5], bot[5];
     top[0] = ub(wlo[0], 0); top[1] = ub(wlo[0], 1); top[2] = ub(wlo[0], 2); top[3] = ub(wlo[0], 3); top[4] = ub(whi[0], 0);
@@ -595,6 +668,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     constexpr int WPP = NPW + 1;           // waves per pair
     __shared__ WavePartial s_part_all[PPW][NP];
     __shared__ BlockState s_all[PPW];
+    __shared__ uint32_t s_foot[PPW][STAGE_LEVELS > 0 ? STAGE_LEVELS * 14 : 1][STAGE_LEVELS > 0 ? NPW * 64 : 1];   // staged reference footprints
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -672,6 +746,12 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
     const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
     const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + ltid, ltid < nf);
+    uint32_t* foot_lane = &s_foot[slot][0][STAGE_LEVELS > 0 ? ltid : 0];
+    constexpr int FOOT_STRIDE = NPW * 64;
+    if (STAGE_LEVELS > 0) {
+        const bool is_zero = (fraw.w0 == 0.0 && fraw.w1 == 0.0 && fraw.w2 == 0.0);
+        stage_footprints(a, ref_base, fraw.px, fraw.py, fraw.initial && !is_zero, foot_lane, FOOT_STRIDE);
+    }
     unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
     unsigned seen = 1;                                                 // states consumed so far
     if (PPW == 1) __syncthreads(); else pair_wait_seq(s, 1u);          // B0
@@ -691,7 +771,11 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         PatchRegs<GT> P;
         unsigned long long tp0 = 0;
         if (STAMPS) tp0 = __builtin_amdgcn_s_memtime();
-        precompute_patch<GT>(a, lg, level, ref_base, F, P);
+        {
+            const int sl = a.max_level - 1 - level;            // staged levels come first
+            precompute_patch<GT>(a, lg, level, ref_base, F, P, sl < STAGE_LEVELS ? foot_lane + sl * 14 * FOOT_STRIDE : nullptr,
+                                 FOOT_STRIDE);
+        }
         if (STAMPS) {
             pin_patch(P);   // make the stamp wait for the precompute results
             st_pre += __builtin_amdgcn_s_memtime() - tp0;
