@@ -44,6 +44,22 @@ def algorithmic_bytes(width, height, levels, n_patches):
     return 2 * pyr + n_patches * 57 + 292
 
 
+def pmc_traffic(pairs_per_launch, b_alg):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected with separate
+    --pmc runs of this same command; bench.py cannot sample PMCs itself). Returns None when the summary
+    is missing or was taken for another launch size."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_final.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        t = d["hbm_traffic_per_launch"]
+        if int(t["algorithmic_bytes_per_launch"]) != pairs_per_launch * b_alg:
+            return None
+        return float(t["fetch_bytes_gfx950_corrected"]) + float(t["write_bytes"])
+    except Exception:
+        return None
+
+
 def se3_exp_batch(xi):
     """numpy batch of SE(3) exponentials -> (n,4,4)."""
     from dsdtm_amd import synth
@@ -267,7 +283,10 @@ def main():
                        "pairs_per_gpu": args.pairs, "patches": args.patches, "levels": args.levels,
                        "max_iters": args.iters, "parallelism": f"independent pairs x{world} (no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.pairs, b_alg),
+                         "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE "
+                                         "from profiles/r01_bench_pmc_final.json; algorithmic bytes per launch = "
+                                         + str(args.pairs * b_alg),
                          "kernel": "sparse_align_reg_kernel", "kernel_ms_avg": k_avg,
                          "kernel_ms_min": float(np.min(kernel_ms)),
                          "algorithmic_bytes_per_alignment": b_alg, "alignments_per_launch": args.pairs},

@@ -206,9 +206,9 @@ __device__ __forceinline__ FeatureRegs make_feature(const FeatureRaw& r, const d
 
 // Per-level part of GetJocabianMat for one feature (reference :89-100, :123-162), producing the
 // register-resident state.
-// `staged` (may be null) points at this lane's 7 footprint rows of this level in LDS, packed as
-// 2 dwords per row with stride `staged_stride` dwords (see stage_footprints); otherwise the rows are
-// gathered from the pyramid in HBM.
+// `staged` (may be null) points at this lane's 3 dwords of footprint row 0 in LDS, rows
+// `staged_stride` dwords apart, as written by prefetch_ref_rows (LDS-DMA); the caller has waited for
+// the DMA (vmcnt). Otherwise the rows are gathered from the pyramid in HBM.
 template <typename GT>
 __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const LevelGeom& lg, int level,
                                                  const uint8_t* __restrict__ ref_base,  // pair's ref pyramid
@@ -248,8 +248,15 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
     for (int r = 0; r < 7; ++r) {
         uint32_t lo, hi;
         if (staged) {
-            lo = staged[(2 * r) * staged_stride];
-            hi = staged[(2 * r + 1) * staged_stride];
+            // rows prefetched by prefetch_ref_rows: 3 dwords starting at dword min(dw, last_dw-2)
+            const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
+            const uint32_t dw = o >> 2;
+            const uint32_t sh = (o & 3u) * 8u;
+            const uint32_t dwc = min(dw, last_dw - 2u);
+            const uint32_t a0 = staged[r * staged_stride], a1 = staged[r * staged_stride + 1], a2 = staged[r * staged_stride + 2];
+            const uint32_t w0 = (dwc == dw) ? a0 : a1, w1 = (dwc == dw) ? a1 : a2, w2 = (dwc == dw) ? a2 : 0u;
+            lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+            hi = __builtin_amdgcn_alignbit(w2, w1, sh);
         } else {
             const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
             const uint32_t dw = o >> 2;
@@ -277,59 +284,42 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
     }
 }
 
-// Prologue staging: the 7x7 reference footprints of the first STAGE_LEVELS pyramid levels of one
-// feature are gathered from HBM in ONE overlapped round trip (all loads issued before any is used)
-// and parked in LDS as 14 dwords per level ([level][k][lane], conflict-free). Each level's
-// precompute then starts from LDS instead of a cold, dependent gather (features -> address -> image).
-#ifndef SA_STAGE_LEVELS
-#define SA_STAGE_LEVELS 0
+// Asynchronous prefetch of one level's reference footprints (7 rows x 12 bytes per feature) into
+// LDS with LDS-DMA (global_load_lds_dwordx3: per-lane global address, 12 bytes per lane written at
+// a 16-byte lane stride behind a wave-uniform LDS base; no VGPR destination, nothing waits). It is issued a
+// whole pyramid level ahead — right after the current level's precompute — so the cold HBM gather
+// of the next level (features -> address -> image, ~10 k cycles when done on demand) runs under the
+// current level's Gauss-Newton iterations. The consumer is the same wave (s_waitcnt vmcnt(0)).
+// Measured: correct, but NOT faster at 2 pairs/CU — the cold gathers are bound by the
+// CU's memory-level parallelism, and in-order VMEM return makes the next pass wait behind the DMA —
+// so it is off by default (build with -DSA_DMA_PREFETCH=1 to enable).
+#ifndef SA_DMA_PREFETCH
+#define SA_DMA_PREFETCH 0
 #endif
-constexpr int STAGE_LEVELS = SA_STAGE_LEVELS;   // 0 = gather per level (default: measured faster)
-__device__ __forceinline__ bool level_valid(const FeatureRegs& F, const LevelGeom& lg, int level, double& px, double& py) {
+__device__ __forceinline__ bool level_valid(float fpx, float fpy, bool ok, const LevelGeom& lg, int level, double& px, double& py) {
     const double scale = (double)(1.0f / (float)(1 << level));
-    px = (double)F.px * scale;
-    py = (double)F.py * scale;
-    return F.ok && !(px - 3.0 < 0 || py - 3.0 < 0 || px + 3.0 >= (double)lg.w || py + 3.0 >= (double)lg.h ||
-                     !(px == px) || !(py == py));
+    px = (double)fpx * scale;
+    py = (double)fpy * scale;
+    return ok && !(px - 3.0 < 0 || py - 3.0 < 0 || px + 3.0 >= (double)lg.w || py + 3.0 >= (double)lg.h ||
+                   !(px == px) || !(py == py));
 }
 
-__device__ __forceinline__ void stage_footprints(const SAKernelArgs& a, const uint8_t* __restrict__ ref_base,
-                                                 float fpx, float fpy, bool ok, uint32_t* lds_lane, int stride) {
+__device__ __forceinline__ void prefetch_ref_rows(const SAKernelArgs& a, const uint8_t* __restrict__ ref_base,
+                                                  float fpx, float fpy, bool ok, int level,
+                                                  uint32_t* lds_wave_row0, int row_stride) {
     const uint32_t* __restrict__ img32 = (const uint32_t*)ref_base;
     const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
-    FeatureRegs F;
-    F.px = fpx; F.py = fpy; F.ok = ok; F.X[0] = F.X[1] = F.X[2] = 0.0;
-    uint32_t lo[STAGE_LEVELS > 0 ? STAGE_LEVELS : 1][7], hi[STAGE_LEVELS > 0 ? STAGE_LEVELS : 1][7];
+    const LevelGeom lg = a.lv[level];
+    double px, py;
+    const bool v = level_valid(fpx, fpy, ok, lg, level, px, py);
+    const int fu = v ? (int)floor(px) : 3, fv = v ? (int)floor(py) : 3;
 #pragma unroll
-    for (int sl = 0; sl < STAGE_LEVELS; ++sl) {
-        const int level = a.max_level - 1 - sl;
-        const bool act = level >= a.min_level;
-        const LevelGeom lg = a.lv[act ? level : a.min_level];
-        double px, py;
-        const bool v = act && level_valid(F, lg, act ? level : a.min_level, px, py);
-        const int fu = v ? (int)floor(px) : 3, fv = v ? (int)floor(py) : 3;
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
-            const uint32_t dw = o >> 2;
-            const uint32_t sh = (o & 3u) * 8u;
-            uint32_t w0 = 0, w1 = 0, w2 = 0;
-            if (v) {
-                const uint32_t dwc = min(dw, last_dw - 2u);
-                const U32x3 w = *(const U32x3*)(img32 + dwc);
-                w0 = (dwc == dw) ? w.a : w.b; w1 = (dwc == dw) ? w.b : w.c; w2 = (dwc == dw) ? w.c : 0u;
-            }
-            lo[sl][r] = __builtin_amdgcn_alignbit(w1, w0, sh);
-            hi[sl][r] = __builtin_amdgcn_alignbit(w2, w1, sh);
-        }
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
+        const uint32_t dwc = min(o >> 2, last_dw - 2u);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img32 + dwc),
+                                         (__attribute__((address_space(3))) void*)(lds_wave_row0 + r * row_stride), 12, 0, 0);
     }
-#pragma unroll
-    for (int sl = 0; sl < STAGE_LEVELS; ++sl)
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            lds_lane[(sl * 14 + 2 * r) * stride] = lo[sl][r];
-            lds_lane[(sl * 14 + 2 * r + 1) * stride] = hi[sl][r];
-        }
 }
 
 // Per-patch Gauss-Newton matrix  Sxx A A^T + Sxy (A B^T + B A^T) + Syy B B^T  (upper triangle,
@@ -666,9 +656,20 @@ template <int NPW, typename GT, int PPW, bool STAMPS = false>
 __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_align_reg_kernel(const SAKernelArgs a) {
     constexpr int NP = NPW * 4;            // one partial slot per 16-lane DPP row
     constexpr int WPP = NPW + 1;           // waves per pair
-    __shared__ WavePartial s_part_all[PPW][NP];
-    __shared__ BlockState s_all[PPW];
-    __shared__ uint32_t s_foot[PPW][STAGE_LEVELS > 0 ? STAGE_LEVELS * 14 : 1][STAGE_LEVELS > 0 ? NPW * 64 : 1];   // staged reference footprints
+    constexpr int FOOT_STRIDE = NPW * 64 * 4;   // dwords per footprint row: LDS-DMA dwordx3 puts lane l at +16*l bytes
+                                                // (measured on gfx950: 12 bytes written, 16-byte lane stride)
+    // One struct so that the layout is ours: the small, hot structures sit at the lowest LDS addresses
+    // (ds_read/ds_write immediate offsets reach 64 KB; behind a large array every access would need
+    // extra address arithmetic — measured: +75 % on the solver's partial sums), the DMA buffer last.
+    struct Smem {
+        BlockState st[PPW];
+        WavePartial part[PPW][NP];
+        uint32_t foot[PPW][SA_DMA_PREFETCH ? 7 * FOOT_STRIDE : 1];   // next level's reference footprints (LDS-DMA)
+    };
+    __shared__ Smem sm;
+    auto& s_all = sm.st;
+    auto& s_part_all = sm.part;
+    auto& s_foot = sm.foot;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -746,12 +747,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
     const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
     const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + ltid, ltid < nf);
-    uint32_t* foot_lane = &s_foot[slot][0][STAGE_LEVELS > 0 ? ltid : 0];
-    constexpr int FOOT_STRIDE = NPW * 64;
-    if (STAGE_LEVELS > 0) {
-        const bool is_zero = (fraw.w0 == 0.0 && fraw.w1 == 0.0 && fraw.w2 == 0.0);
-        stage_footprints(a, ref_base, fraw.px, fraw.py, fraw.initial && !is_zero, foot_lane, FOOT_STRIDE);
-    }
+    const bool feat_ok = fraw.initial && !(fraw.w0 == 0.0 && fraw.w1 == 0.0 && fraw.w2 == 0.0);
+    uint32_t* const foot_wave = &s_foot[slot][SA_DMA_PREFETCH ? wave * 64 * 4 : 0];   // wave-uniform DMA base
+    const uint32_t* const foot_lane = &s_foot[slot][SA_DMA_PREFETCH ? ltid * 4 : 0];
+    if (SA_DMA_PREFETCH) prefetch_ref_rows(a, ref_base, fraw.px, fraw.py, feat_ok, a.max_level - 1, foot_wave, FOOT_STRIDE);
     unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
     unsigned seen = 1;                                                 // states consumed so far
     if (PPW == 1) __syncthreads(); else pair_wait_seq(s, 1u);          // B0
@@ -771,10 +770,11 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         PatchRegs<GT> P;
         unsigned long long tp0 = 0;
         if (STAMPS) tp0 = __builtin_amdgcn_s_memtime();
-        {
-            const int sl = a.max_level - 1 - level;            // staged levels come first
-            precompute_patch<GT>(a, lg, level, ref_base, F, P, sl < STAGE_LEVELS ? foot_lane + sl * 14 * FOOT_STRIDE : nullptr,
-                                 FOOT_STRIDE);
+        if (SA_DMA_PREFETCH) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA rows have landed
+            precompute_patch<GT>(a, lg, level, ref_base, F, P, foot_lane, FOOT_STRIDE);
+        } else {
+            precompute_patch<GT>(a, lg, level, ref_base, F, P);
         }
         if (STAMPS) {
             pin_patch(P);   // make the stamp wait for the precompute results
@@ -819,6 +819,13 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
             unsigned long long tq2 = 0;
             if (STAMPS) { tq2 = __builtin_amdgcn_s_memtime(); st_h += tq2 - tq1; }
+            if (SA_DMA_PREFETCH && it == 0 && level > a.min_level) {
+                // Next level's footprints: issued after this level's first pass has consumed its own
+                // loads (vector-memory results return in order, so an earlier issue would stall that
+                // pass behind these cold misses); they land under the solves of this level.
+                // (the rows of this level were consumed by precompute_patch long ago)
+                prefetch_ref_rows(a, ref_base, F.px, F.py, F.ok, level - 1, foot_wave, FOOT_STRIDE);
+            }
             ++seen;
             if (PPW == 1) {
                 __syncthreads();                                       // B1
