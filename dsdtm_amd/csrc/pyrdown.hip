@@ -41,29 +41,41 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const PyrDownArgs a) {
     for (int k = 0; k < 5; ++k) rows[k] = reflect101(2 * y + k - 2, a.sh);
 
     int acc[4] = {0, 0, 0, 0};
-    const int xs = 2 * x4 - 2;                       // first input column needed
-    // x4 is a multiple of 4, so xs = 8t-2 and (xs & ~3) = xs - 2: the window starts at byte 2 of
-    // the aligned 16 bytes
-    const bool interior = (xs >= 0) && (xs + 13 < a.sw) && ((a.sstride & 3) == 0) && ((((size_t)src) & 3) == 0);
+    const int xs = 2 * x4 - 2;                       // first input column needed (x4 is a multiple of 4)
     const int wk[5] = {1, 4, 6, 4, 1};
-    if (interior) {
-        // columns xs..xs+10 lie in the aligned 16 bytes starting at (xs & ~3) = 8*t-4 .. 8*t+12
+    // Fast path: the 11 input columns xs..xs+10 of each of the 5 rows come from ONE aligned 16-byte
+    // load. Interior threads read columns (xs-2)..(xs+13) and use bytes 2..12; the left-border thread
+    // (xs = -2) reads columns 0..15 and mirrors columns -2,-1 -> 2,1; the right-border thread of an
+    // even-width image needs column sw -> sw-2 (BORDER_REFLECT_101). Keeping the border lanes on this
+    // path matters: one lane on the byte-wise path stalls its whole wave.
+    const bool aligned_ok = ((a.sstride & 3) == 0) && ((((size_t)src) & 3) == 0) && ((a.sw & 1) == 0) && a.sw >= 16 &&
+                            (x4 + 3 < a.dw);
+    const bool left = (x4 == 0);
+    const bool right = (xs + 10 >= a.sw);             // only column xs+10 == sw can be outside
+    if (aligned_ok && (!right || xs + 10 == a.sw)) {
+        const int base = left ? 0 : (xs - 2);         // multiple of 4
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const uint32_t* __restrict__ p32 =
-                (const uint32_t*)(src + (size_t)rows[k] * a.sstride + (xs & ~3));
-            const uint32_t d0 = p32[0], d1 = p32[1], d2 = p32[2], d3 = p32[3];
+            const uint32_t* __restrict__ p32 = (const uint32_t*)(src + (size_t)rows[k] * a.sstride + base);
+            const uint32_t d0 = p32[0], d1 = p32[1], d2 = p32[2];
+            // the 4th dword is only needed by interior/left threads (columns base+12..); for the
+            // right-border thread it would start past the row end, so it is not read there
+            const uint32_t d3 = right ? 0u : p32[3];
             int px[16];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 px[j] = (d0 >> (8 * j)) & 0xff; px[4 + j] = (d1 >> (8 * j)) & 0xff;
                 px[8 + j] = (d2 >> (8 * j)) & 0xff; px[12 + j] = (d3 >> (8 * j)) & 0xff;
             }
+            int w[11];                                // w[j] = pixel at column xs + j (reflected)
+#pragma unroll
+            for (int j = 0; j < 11; ++j) w[j] = left ? ((j < 2) ? px[2 - j] : px[j - 2]) : px[j + 2];
+            if (right) w[10] = w[8];                  // column sw -> sw-2
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 int h = 0;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) h += wk[j] * px[2 * o + j + 2];
+                for (int j = 0; j < 5; ++j) h += wk[j] * w[2 * o + j];
                 acc[o] += wk[k] * h;
             }
         }

@@ -1,0 +1,161 @@
+// dsdtm_host.hpp — C++ host side above the C ABI (include/dsdtm_amd.h), mirroring the reference's
+// class interface for the hot path: same class names, constructor arguments, method names,
+// argument order, return values and error behaviour as
+//   DSDTM::Sprase_ImgAlign      (reference include/Sprase_ImageAlign.h:20-69)
+//   DSDTM::Feature_Alignment    (reference include/Feature_alignment.h:23-99, the static
+//                                Align2DGaussNewton and its batch form)
+// over dependency-free stand-ins for the data the path reads (Frame / Feature / Camera / SE3): the
+// reference's own types need OpenCV, Eigen and Sophus, which this build image does not have
+// (INTEGRATION.md shows the adapter against the real types). All compute happens in
+// libdsdtm_amd.so (HIP, gfx950); there is no CPU path here.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dsdtm_amd.h"
+
+namespace DSDTM {
+
+static const int mHalf_PatchSize = 4;   // include/Feature_alignment.h:21
+
+// Config::Get<int>("Camera.Min_fts") etc. — only the keys the path reads
+struct Config {
+    static int& Min_fts() { static int v = 15; return v; }            // src/Sprase_ImageAlign.cpp:14
+};
+
+struct Image8 {                                   // cv::Mat CV_8UC1
+    int cols = 0, rows = 0, step = 0;
+    std::vector<uint8_t> data;
+    Image8() = default;
+    Image8(int w, int h) : cols(w), rows(h), step(w), data((size_t)w * h) {}
+};
+
+struct SE3 {                                      // Sophus::SE3 as [R|t] 3x4 row-major
+    std::array<double, 12> m{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};
+};
+
+struct Camera {                                   // include/Camera.h:138-142 (float members)
+    float mfx = 0, mfy = 0, mcx = 0, mcy = 0, mf = 0;
+    int mwidth = 0, mheight = 0;
+};
+typedef std::shared_ptr<Camera> CameraPtr;
+
+struct Feature {                                  // include/Feature.h:16-36 (+ the map point position)
+    float mpx_x = 0, mpx_y = 0;
+    int mlevel = 0;
+    bool mbInitial = false;
+    std::array<double, 3> mNormal{{0, 0, 0}};
+    std::array<double, 3> mMptPose{{0, 0, 0}};    // Mpt->Get_Pose()
+};
+
+struct Frame {                                    // include/Frame.h (what the path touches)
+    CameraPtr mCamera;
+    std::vector<Image8> mvImg_Pyr;
+    std::vector<Feature> mvFeatures;
+    SE3 mT_c2w;
+    const SE3& Get_Pose() const { return mT_c2w; }
+    void Set_Pose(const SE3& T) { mT_c2w = T; }   // src/Frame.cpp:167-174
+};
+typedef std::shared_ptr<Frame> FramePtr;
+
+namespace detail {
+inline dsdtm_ctx* ctx() {                         // one context per calling thread (tracking thread)
+    struct Holder {
+        dsdtm_ctx* c = nullptr;
+        Holder() {
+            if (dsdtm_create(0, &c) != DSDTM_OK)
+                throw std::runtime_error(std::string("dsdtm_create: ") + dsdtm_last_error(nullptr));
+        }
+        ~Holder() { dsdtm_destroy(c); }
+    };
+    static thread_local Holder h;
+    return h.c;
+}
+inline dsdtm_pyramid to_pyr(const std::vector<Image8>& v) {
+    dsdtm_pyramid p{};
+    p.levels = (int)v.size();
+    for (int l = 0; l < p.levels; ++l) {
+        p.data[l] = v[l].data.data(); p.width[l] = v[l].cols; p.height[l] = v[l].rows; p.stride[l] = v[l].step;
+    }
+    return p;
+}
+}  // namespace detail
+
+class Sprase_ImgAlign {
+public:
+    Sprase_ImgAlign(int tMaxLevel, int tMinLevel, int tMaxIterators)
+        : mnMaxLevel(tMaxLevel), mnMinLevel(tMinLevel), mnMaxIterators(tMaxIterators),
+          mnMinfts(Config::Min_fts()) {}
+
+    // int Run(FramePtr tCurFrame, FramePtr tRefFrame) — include/Sprase_ImageAlign.h:29
+    int Run(FramePtr tCurFrame, FramePtr tRefFrame) {
+        const std::vector<Feature>& f = tRefFrame->mvFeatures;
+        const int n = (int)f.size();
+        std::vector<float> px(2 * (size_t)n);
+        std::vector<double> bearing(3 * (size_t)n), pw(3 * (size_t)n);
+        std::vector<uint8_t> ini((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            px[2 * i] = f[i].mpx_x; px[2 * i + 1] = f[i].mpx_y; ini[i] = f[i].mbInitial ? 1 : 0;
+            for (int k = 0; k < 3; ++k) { bearing[3 * i + k] = f[i].mNormal[k]; pw[3 * i + k] = f[i].mMptPose[k]; }
+        }
+        const Camera& c = *tRefFrame->mCamera;
+        const dsdtm_camera cam{c.mfx, c.mfy, c.mcx, c.mcy, c.mf, c.mwidth, c.mheight};
+        const dsdtm_pyramid ref = detail::to_pyr(tRefFrame->mvImg_Pyr), cur = detail::to_pyr(tCurFrame->mvImg_Pyr);
+        SE3 Tc = tCurFrame->Get_Pose();
+        const dsdtm_align_params prm{mnMaxLevel, mnMinLevel, mnMaxIterators, mnMinfts};
+        int n_tracked = 0;
+        const int rc = dsdtm_sparse_align(detail::ctx(), &ref, &cur, &cam, px.data(), bearing.data(), pw.data(),
+                                          ini.data(), n, tRefFrame->Get_Pose().m.data(), Tc.m.data(), &prm,
+                                          &n_tracked, &last_stats);
+        if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_sparse_align: ") + dsdtm_last_error(detail::ctx()));
+        if (n < mnMinfts) {                                  // src/Sprase_ImageAlign.cpp:34-38
+            std::fprintf(stderr, "Too few features to track\n");
+            return 0;                                        // pose untouched
+        }
+        tCurFrame->Set_Pose(Tc);                             // :57
+        return n_tracked;                                    // :59
+    }
+
+    dsdtm_align_stats last_stats{};
+
+protected:
+    int mnMaxLevel, mnMinLevel, mnMaxIterators, mnMinfts;
+};
+
+class Feature_Alignment {
+public:
+    explicit Feature_Alignment(CameraPtr camera) : mCam(camera) {}
+
+    // static bool Align2DGaussNewton(const cv::Mat&, uchar*, uchar*, int, Eigen::Vector2d&)
+    // — include/Feature_alignment.h:85. tCurPx is written back also on failure (:414).
+    static bool Align2DGaussNewton(const Image8& tCurImg, uint8_t* tPatch_WithBoarder, uint8_t* tPatch,
+                                   int MaxIters, double tCurPx[2]) {
+        std::vector<Image8> one(1);
+        dsdtm_pyramid cur{};
+        cur.levels = 1; cur.data[0] = tCurImg.data.data(); cur.width[0] = tCurImg.cols; cur.height[0] = tCurImg.rows;
+        cur.stride[0] = tCurImg.step;
+        int32_t level = 0;
+        uint8_t ok = 0;
+        const int rc = dsdtm_align2d_batch(detail::ctx(), &cur, tPatch_WithBoarder, tPatch, &level, tCurPx, &ok, MaxIters, 1);
+        if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_align2d_batch: ") + dsdtm_last_error(detail::ctx()));
+        return ok != 0;
+    }
+
+    // all candidates of a frame at once (the speculative form SearchLocalPoints uses)
+    static void Align2DGaussNewtonBatch(const std::vector<Image8>& tCurPyr, const uint8_t* borders, const uint8_t* patches,
+                                        const int32_t* levels, double* px_xy, uint8_t* converged, int MaxIters, int m) {
+        const dsdtm_pyramid cur = detail::to_pyr(tCurPyr);
+        const int rc = dsdtm_align2d_batch(detail::ctx(), &cur, borders, patches, levels, px_xy, converged, MaxIters, m);
+        if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_align2d_batch: ") + dsdtm_last_error(detail::ctx()));
+    }
+
+private:
+    CameraPtr mCam;
+};
+
+}  // namespace DSDTM
