@@ -400,12 +400,22 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// row rotations read every lane of the row, so no "old" value is needed: mov_dpp saves the
+// v_mov that update_dpp needs to preload its old operand (one per DPP move)
+template <int CTRL>
+__device__ __forceinline__ double dpp_rot_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // Sum over the 16 lanes of each DPP row only; every lane of a row ends up holding its row's sum.
 __device__ __forceinline__ double row_sum16(double v) {
-    v += dpp_f64<0x128, 0xf>(v);  // row_ror:8
-    v += dpp_f64<0x124, 0xf>(v);  // row_ror:4
-    v += dpp_f64<0x122, 0xf>(v);  // row_ror:2
-    v += dpp_f64<0x121, 0xf>(v);  // row_ror:1
+    v += dpp_rot_f64<0x128>(v);  // row_ror:8
+    v += dpp_rot_f64<0x124>(v);  // row_ror:4
+    v += dpp_rot_f64<0x122>(v);  // row_ror:2
+    v += dpp_rot_f64<0x121>(v);  // row_ror:1
     return v;
 }
 

@@ -127,7 +127,8 @@ __device__ __forceinline__ double ub(uint32_t w, int k) {
 template <typename GT>
 struct PatchRegs {
     GT g[6][6];       // bilinear reference intensities on the 6x6 grid (corners unused)
-    double X[3];      // 3-D point in the reference camera: bearing * |P_w - C_ref| (:117-119)
+    double X[3];      // 3-D point in the reference camera, bearing * |P_w - C_ref| (:117-119), kept in
+                      // normalised form (x/z, y/z, 1/z)
     bool valid;
 };
 
@@ -150,28 +151,29 @@ __device__ __forceinline__ void pin_patch(PatchRegs<GT>& P) {
 
 // GetJocabianBA (:169-193) scaled by f*scale (:160; Camera.f, quirk Q1): the non-zero entries
 // of Jt.row(0)*fs = [a0,0,a1,a2,a3,a4] and Jt.row(1)*fs = [0,b0,b1,b2,b3,b4].
-__device__ __forceinline__ void patch_AB(double fs, const double* X, double* A, double* B) {
-    const double x = X[0], y = X[1];
-    const double z_inv = 1.0 / X[2];
-    const double z_inv2 = z_inv * z_inv;
-    const double j02 = x * z_inv2, j12 = y * z_inv2;
-    A[0] = -z_inv * fs;                  // J(0,0)
-    A[1] = j02 * fs;                     // J(0,2)
-    A[2] = y * j02 * fs;                 // J(0,3)
-    A[3] = -(1.0 + x * j02) * fs;        // J(0,4)
-    A[4] = y * z_inv * fs;               // J(0,5)
-    B[0] = -z_inv * fs;                  // J(1,1)
-    B[1] = j12 * fs;                     // J(1,2)
-    B[2] = (1.0 + y * j12) * fs;         // J(1,3)
-    B[3] = -x * j12 * fs;                // J(1,4)
-    B[4] = -x * z_inv * fs;              // J(1,5)
+// Xn is the point in normalised form (x/z, y/z, 1/z), computed once per alignment, so that neither
+// this nor the projection needs a division inside the Gauss-Newton loop:
+//   x/z^2 = xn*zi, x*y/z^2 = xn*yn, 1 + x^2/z^2 = 1 + xn^2, ...
+__device__ __forceinline__ void patch_AB(double fs, const double* Xn, double* A, double* B) {
+    const double xn = Xn[0], yn = Xn[1], zi = Xn[2];
+    const double zfs = zi * fs;
+    A[0] = -zfs;                         // J(0,0) = -1/z
+    A[1] = xn * zfs;                     // J(0,2) = x/z^2
+    A[2] = (xn * yn) * fs;               // J(0,3) = x*y/z^2
+    A[3] = -(1.0 + xn * xn) * fs;        // J(0,4) = -(1 + x^2/z^2)
+    A[4] = yn * fs;                      // J(0,5) = y/z
+    B[0] = -zfs;                         // J(1,1) = -1/z
+    B[1] = yn * zfs;                     // J(1,2) = y/z^2
+    B[2] = (1.0 + yn * yn) * fs;         // J(1,3) = 1 + y^2/z^2
+    B[3] = -(xn * yn) * fs;              // J(1,4) = -x*y/z^2
+    B[4] = -xn * fs;                     // J(1,5) = -x/z
 }
 
 // Level-independent part of GetJocabianMat (reference :84-119) for one feature: the feature
 // columns are read from HBM once per alignment, not once per level.
 struct FeatureRegs {
     float px, py;     // Feature::mpx
-    double X[3];      // bearing * |P_w - C_ref|  (:117-119)
+    double X[3];      // bearing * |P_w - C_ref|  (:117-119) as (x/z, y/z, 1/z)
     bool ok;          // mbInitial && P_w != 0 (:86, :95)
 };
 
@@ -200,7 +202,9 @@ __device__ __forceinline__ FeatureRegs make_feature(const FeatureRaw& r, const d
     f.ok = r.initial && !is_zero;
     const double d0 = r.w0 - Cref[0], d1 = r.w1 - Cref[1], d2 = r.w2 - Cref[2];
     const double depth = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-    f.X[0] = r.b0 * depth; f.X[1] = r.b1 * depth; f.X[2] = r.b2 * depth;
+    const double x = r.b0 * depth, y = r.b1 * depth, z = r.b2 * depth;
+    const double zi = 1.0 / z;           // the only division per feature and alignment
+    f.X[0] = x * zi; f.X[1] = y * zi; f.X[2] = zi;
     return f;
 }
 
@@ -373,10 +377,11 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = 0.0;
     if (!P.valid) return false;
-    // :254 tT_c2r * X  (R, t are LDS broadcasts)
-    const double pxc = sR[0] * P.X[0] + sR[1] * P.X[1] + sR[2] * P.X[2] + st[0];
-    const double pyc = sR[3] * P.X[0] + sR[4] * P.X[1] + sR[5] * P.X[2] + st[1];
-    const double pzc = sR[6] * P.X[0] + sR[7] * P.X[1] + sR[8] * P.X[2] + st[2];
+    // :254 tT_c2r * X, divided through by z > 0 (the projection below is scale invariant):
+    // (R X + t)/z = R (x/z, y/z, 1) + t/z   (R, t are LDS broadcasts)
+    const double pxc = sR[0] * P.X[0] + sR[1] * P.X[1] + sR[2] + st[0] * P.X[2];
+    const double pyc = sR[3] * P.X[0] + sR[4] * P.X[1] + sR[5] + st[1] * P.X[2];
+    const double pzc = sR[6] * P.X[0] + sR[7] * P.X[1] + sR[8] + st[2] * P.X[2];
     // Camera2Pixel (src/Camera.cpp:167-171), * tScale (:255)
     // one reciprocal for both coordinates (the reference divides twice; <= 1 ulp on u,v)
     const double izc = 1.0 / pzc;
@@ -403,11 +408,15 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
         wlo[r] = __builtin_amdgcn_alignbit(w.b, w.a, sh);  // bytes 0..3 of the row
         whi[r] = w.b >> sh;                                 // byte 4 in bits 0..7
     }
-    double top[5], bot[5];
-    top[0] = ub(wlo[0], 0); top[1] = ub(wlo[0], 1); top[2] = ub(wlo[0], 2); top[3] = ub(wlo[0], 3); top[4] = ub(whi[0], 0);
+    // two footprint rows in flight, ping-ponged by the (static) row parity so that no register
+    // copies are needed between rows
+    double rw[2][5];
+    rw[0][0] = ub(wlo[0], 0); rw[0][1] = ub(wlo[0], 1); rw[0][2] = ub(wlo[0], 2); rw[0][3] = ub(wlo[0], 3); rw[0][4] = ub(whi[0], 0);
     double c2a = 0.0, c2b = 0.0, gxa = 0.0, gxb = 0.0, gya = 0.0, gyb = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        double* top = rw[i & 1];
+        double* bot = rw[(i + 1) & 1];
         bot[0] = ub(wlo[i + 1], 0); bot[1] = ub(wlo[i + 1], 1); bot[2] = ub(wlo[i + 1], 2);
         bot[3] = ub(wlo[i + 1], 3); bot[4] = ub(whi[i + 1], 0);
 #pragma unroll
@@ -419,8 +428,6 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
             if (k & 1) { c2b += res * res; gxb += ddx * res; gyb += ddy * res; }
             else       { c2a += res * res; gxa += ddx * res; gya += ddy * res; }
         }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) top[k] = bot[k];
         // keep the rows in program order: without this the scheduler converts the whole 5x5
         // footprint to doubles up front (50 live VGPRs instead of the two rows in flight)
         __builtin_amdgcn_sched_barrier(0);
@@ -476,8 +483,9 @@ __device__ __forceinline__ void solver_init(const SAKernelArgs& a, int pair, Blo
 // it runs only when the visible set changed (about once per pyramid level), and keeping its ~60
 // live registers out of solver_step's allocation keeps the whole kernel inside the 168-VGPR budget
 // of a 12-wave workgroup without spills on the per-iteration path.
-__device__ __attribute__((noinline)) void factor_to_lds(BlockState* sp, int lane) {
-    BlockState& s = *sp;
+typedef __attribute__((address_space(3))) BlockState LdsBlockState;   // ds_read/ds_write instead of flat accesses
+__device__ __attribute__((noinline)) void factor_to_lds(LdsBlockState* sp, int lane) {
+    LdsBlockState& s = *sp;
     double H[21], Fm[21], Fdinv[6];
     int tr0, tr1, tr2, tr3, tr4;
     unsigned dmask;
@@ -545,7 +553,7 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     const double chi2New = chi2s / (double)(16 * cnt);     // :298 (0/0 -> NaN)
     // H.ldlt().solve(JRes) (:318). H is unchanged while the visible set is: factorise only when a
     // row reported a new ballot, otherwise reuse the cached factors (same factors => same x).
-    if (changed) factor_to_lds(&s, lane);    // out-of-line: ~4 calls per alignment
+    if (changed) factor_to_lds((LdsBlockState*)&s, lane);    // out-of-line: ~4 calls per alignment
     __builtin_amdgcn_sched_barrier(0);   // keep the solver's sub-steps in order: short live ranges, no spills
     double x[6];
     {
