@@ -67,9 +67,11 @@ struct BlockState {
     int ctrl;                   // 0 continue, 1 level finished
     int n_vis;
     // pair-local synchronisation (used when several pairs share a workgroup): monotonic counters
-    unsigned arrive;            // +1 per patch wave whose partials are in LDS
+    unsigned arrive;            // +1 per patch wave whose pass partials are in LDS (B1)
     unsigned seq;               // number of states published by the solver (1 after solver_init)
-    unsigned pad_[2];
+    unsigned arrive_h;          // +1 per patch wave whose all-visible H partials are in LDS (BH); a counter of
+                                // its own: a wave signals BH and B1 back to back without waiting in between
+    unsigned pad_;
 };
 
 // ---- pair-local synchronisation ------------------------------------------------------------
@@ -79,13 +81,13 @@ struct BlockState {
 // flight, and every spin is bounded (a broken protocol ends the kernel instead of hanging the GPU).
 constexpr unsigned SPIN_LIMIT = 1u << 24;
 
-__device__ __forceinline__ void pair_signal_arrive(BlockState& s, int lane) {
+__device__ __forceinline__ void pair_signal_arrive(unsigned* counter, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS stores first
-    if (lane == 0) __hip_atomic_fetch_add(&s.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void pair_wait_arrive(BlockState& s, unsigned target) {
+__device__ __forceinline__ void pair_wait_arrive(unsigned* counter, unsigned target) {
     unsigned spins = 0;
-    while (__hip_atomic_load(&s.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < SPIN_LIMIT)
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < SPIN_LIMIT)
         __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -505,6 +507,25 @@ __device__ __attribute__((noinline)) void factor_to_lds(LdsBlockState* sp, int l
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Sum the per-row H partials (lane q < 21 sums entry q over the NP slots in fixed order) and
+// factorise the total. Called once per level on the all-visible H — speculatively, while the patch
+// waves run the level's first pass — and again only if a row later reports a different visible set.
+template <int NP>
+__device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, BlockState& s, int lane) {
+    constexpr int WP = sizeof(WavePartial) / sizeof(double);
+    const double* base = (const double*)s_part;
+    if (lane < 21) {
+        double acc = 0.0;
+#pragma unroll 4
+        for (int w = 0; w < NP; ++w) acc += base[w * WP + 9 + lane];   // H[] starts at double 9 of a slot
+        s.Hsum[lane] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    factor_to_lds((LdsBlockState*)&s, lane);              // out-of-line; parks the factors in LDS
+}
+
 // Solver wave, one Gauss-Newton iteration (reference :310-343). Executed uniformly by all 64
 // lanes of the solver wave (same cost as one lane); lane 0 publishes. Returns ctrl.
 template <int NP>   // NP = number of partial slots (rows or waves)
@@ -529,17 +550,16 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     const int cnt = packed & 0xffff;
     const int n_ref = (packed >> 16) & 0xffff;
     const int changed = __ballot(chg) != 0ull;
+    if (changed) solver_refresh_H<NP>(s_part, s, lane);   // rare: a row's visible set differs from the cached one
     {
         constexpr int WP = sizeof(WavePartial) / sizeof(double);
         const double* base = (const double*)s_part;
-        // doubles inside WavePartial: b[0..5] at 0, chi2 at 6, H[] at 9 (after 4 ints)
-        const int off = lane < 21 ? (9 + lane) : (lane - 21);
-        if (lane < 28 && (changed || lane >= 21)) {
+        // doubles inside WavePartial: b[0..5] at 0, chi2 at 6
+        if (lane < 7) {
             double acc = 0.0;
 #pragma unroll 4
-            for (int w = 0; w < NP; ++w) acc += base[w * WP + off];   // fixed slot order: deterministic
-            if (lane < 21) s.Hsum[lane] = acc;
-            else s.bsum[lane - 21] = acc;
+            for (int w = 0; w < NP; ++w) acc += base[w * WP + lane];   // fixed slot order: deterministic
+            s.bsum[lane] = acc;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -553,7 +573,6 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     const double chi2New = chi2s / (double)(16 * cnt);     // :298 (0/0 -> NaN)
     // H.ldlt().solve(JRes) (:318). H is unchanged while the visible set is: factorise only when a
     // row reported a new ballot, otherwise reuse the cached factors (same factors => same x).
-    if (changed) factor_to_lds((LdsBlockState*)&s, lane);    // out-of-line: ~4 calls per alignment
     __builtin_amdgcn_sched_barrier(0);   // keep the solver's sub-steps in order: short live ranges, no spills
     double x[6];
     {
@@ -635,12 +654,15 @@ __device__ __forceinline__ void solver_finish(const SAKernelArgs& a, int pair, B
     }
 }
 
-// Barrier protocol (every wave executes exactly the same number of s_barrier):
-//   B0                      after solver_init                      (patch waves may read Cref/R/t)
-//   per iteration: B1       partials of all patch waves are in LDS (solver may read them)
-//                  B2       solver has published R/t/ctrl           (patch waves may read them)
-// The solver rewrites R/t/ctrl only after the next B1, which every patch wave reaches only after
-// it has read them, so no further barriers are needed at level boundaries.
+// Hand-over protocol of the register kernel (pair-local counters, see pair_signal_arrive & co.):
+//   B0                      solver_init done                       -> seq = 1 (patch waves may read Cref/R/t)
+//   per level:     BH       all-visible H partials are in LDS      -> arrive += NPW (solver sums + factorises
+//                                                                     them while the first pass runs)
+//   per iteration: B1       partials of all patch waves are in LDS -> arrive += NPW (solver may read them)
+//                  B2       solver has published R/t/ctrl           -> seq += 1 (patch waves may read them)
+// The solver rewrites R/t/ctrl only after the next B1, which every patch wave signals only after it
+// has read them, so nothing else is needed at level boundaries. The generic (workspace) kernel
+// below uses plain s_barrier for B0/B1/B2.
 
 // ---------------------------------------------------------------------------------------------
 // Register-resident kernel: NPW patch waves (one patch per lane, NPW*64 >= n_features) + 1 solver
@@ -686,10 +708,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     const int wave = gwave - slot * WPP;                       // wave inside the pair
     const int ltid = tid - slot * WPP * 64;                    // thread inside the pair
     const int pair = blockIdx.x * PPW + slot;
-    if (PPW > 1) {
+    {
         // LDS is uninitialised at kernel start: zero the pair-local counters and run the one real
         // workgroup barrier of this kernel while every wave is still present
-        if (tid < PPW) { s_all[tid].arrive = 0u; s_all[tid].seq = 0u; }
+        if (tid < PPW) { s_all[tid].arrive = 0u; s_all[tid].arrive_h = 0u; s_all[tid].seq = 0u; }
         __syncthreads();
     }
     if (pair >= a.n_pairs) return;                             // whole pair slot leaves together
@@ -708,12 +730,13 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0;
         unsigned long long t_sub[3] = {0, 0, 0};
         if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
-        unsigned round = 0;                                            // completed solver rounds
+        unsigned expected = 0, expected_h = 0;                         // B1 / BH arrivals consumed so far
+        unsigned published = 1;                                        // states published so far
         // The solve is the serial section of this pair's iteration, and this wave shares its SIMD
         // with patch waves of the workgroup's other pair: give it issue priority.
         if (PPW > 1) __builtin_amdgcn_s_setprio(2);
         solver_init(a, pair, s, lane);
-        if (PPW == 1) __syncthreads(); else pair_publish(s, 1u, lane); // B0
+        pair_publish(s, published, lane);                              // B0
         for (int level = a.max_level - 1; level >= a.min_level; --level) {
             if (lane == 0) {                                           // GaussNewtonSolver entry (:304-308)
                 s.chi2 = 0.0;
@@ -722,11 +745,16 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
 #pragma unroll
                 for (int i = 0; i < 3; ++i) s.to[i] = s.t[i];
             }
+            // speculative: the patch waves publish the all-visible H partials right after the level's
+            // precompute; sum + factorise them here while they run the first pass
+            expected_h += NPW;
+            pair_wait_arrive(&s.arrive_h, expected_h);                 // BH
+            solver_refresh_H<NP>(s_part, s, lane);
             for (int it = 0; it < a.max_iters; ++it) {
                 unsigned long long t0 = 0, t1 = 0, t2 = 0;
                 if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
-                ++round;
-                if (PPW == 1) __syncthreads(); else pair_wait_arrive(s, (unsigned)NPW * round);   // B1
+                expected += NPW;
+                pair_wait_arrive(&s.arrive, expected);                 // B1
                 if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
                 const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, STAMPS ? t_sub : nullptr);
                 if (STAMPS) {
@@ -735,7 +763,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     t_solve += t2 - t1;
                     n_it += 1;
                 }
-                if (PPW == 1) __syncthreads(); else pair_publish(s, 1u + round, lane);          // B2
+                pair_publish(s, ++published, lane);                    // B2
                 if (ctrl) break;
             }
         }
@@ -761,7 +789,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     if (SA_DMA_PREFETCH) prefetch_ref_rows(a, ref_base, fraw.px, fraw.py, feat_ok, a.max_level - 1, foot_wave, FOOT_STRIDE);
     unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
     unsigned seen = 1;                                                 // states consumed so far
-    if (PPW == 1) __syncthreads(); else pair_wait_seq(s, 1u);          // B0
+    pair_wait_seq(s, 1u);                                              // B0
     FeatureRegs F;
     {
         const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
@@ -788,9 +816,24 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             pin_patch(P);   // make the stamp wait for the precompute results
             st_pre += __builtin_amdgcn_s_memtime() - tp0;
         }
-        const int n_ref_row = __popc((unsigned)(__ballot(P.valid) >> (16 * row)) & 0xffffu);
-        unsigned long long cached_mask = 0ull;
-        bool first = true;   // forces the first H reduction of the level
+        const unsigned long long valid_mask = __ballot(P.valid);
+        const int n_ref_row = __popc((unsigned)(valid_mask >> (16 * row)) & 0xffffu);
+        // Speculative H of the level: every valid patch visible (what the first pass finds almost
+        // always). Published before the pass so that the solver can factorise it meanwhile.
+        unsigned long long cached_mask = valid_mask;
+        {
+            unsigned long long th0 = 0;
+            if (STAMPS) th0 = __builtin_amdgcn_s_memtime();
+            const PatchHess ph = patch_hess_factors<GT>(P, fs);
+            double* Hout = my_part.H;
+            patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
+                const double hs = row_sum16(P.valid ? v : 0.0);
+                if (row_writer) Hout[q] = hs;
+                __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
+            });
+            pair_signal_arrive(&s.arrive_h, lane);                     // BH
+            if (STAMPS) st_h += __builtin_amdgcn_s_memtime() - th0;
+        }
 
         for (int it = 0; it < a.max_iters; ++it) {
             double chi2, b[6];
@@ -812,7 +855,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 my_part.n_ref = n_ref_row;
             }
             if (STAMPS) { tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0; }
-            const bool h_changed = first || (vmask != cached_mask);   // wave-uniform
+            const bool h_changed = (vmask != cached_mask);            // wave-uniform, rare
             if (h_changed) {
                 const PatchHess ph = patch_hess_factors<GT>(P, fs);
                 double* Hout = my_part.H;
@@ -822,7 +865,6 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
                 });
                 cached_mask = vmask;
-                first = false;
             }
             if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
             unsigned long long tq2 = 0;
@@ -835,13 +877,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 prefetch_ref_rows(a, ref_base, F.px, F.py, F.ok, level - 1, foot_wave, FOOT_STRIDE);
             }
             ++seen;
-            if (PPW == 1) {
-                __syncthreads();                                       // B1
-                __syncthreads();                                       // B2
-            } else {
-                pair_signal_arrive(s, lane);                           // B1
-                pair_wait_seq(s, seen);                                // B2
-            }
+            pair_signal_arrive(&s.arrive, lane);                       // B1
+            pair_wait_seq(s, seen);                                    // B2
             if (STAMPS) st_bar += __builtin_amdgcn_s_memtime() - tq2;
             if (s.ctrl) break;
         }
