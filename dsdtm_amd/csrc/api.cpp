@@ -29,6 +29,9 @@ struct dsdtm_ctx {
     // workspace for the generic sparse-align kernel
     void* d_ws = nullptr;
     size_t ws_cap = 0;
+    // pair counter of the persistent sparse-align kernel (zeroed by a memset node before each launch)
+    unsigned* d_counter = nullptr;
+    int num_cus = 256;
 };
 
 static thread_local char g_create_err[512] = "";
@@ -97,6 +100,13 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
         delete ctx;
         return DSDTM_ERR_HIP;
     }
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipMalloc((void**)&ctx->d_counter, 256) != hipSuccess) {
+        set_err(nullptr, "hipMalloc failed on device %d", device);
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return DSDTM_ERR_NOMEM;
+    }
     *out = ctx;
     return DSDTM_OK;
 }
@@ -108,6 +118,7 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     delete ctx;
 }
 
@@ -193,10 +204,14 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     a.pyr_pitch = b->pyr_pitch; a.n_pairs = b->n_pairs; a.max_features = b->max_features;
     a.max_level = prm->max_level; a.min_level = prm->min_level; a.max_iters = prm->max_iters; a.min_fts = prm->min_fts;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy; a.f = cam->f;
+    // the persistent kernels pull pair indices from this word: reset it on the launch stream
+    // (a memset node when the stream is being captured into a hipGraph)
+    a.pair_counter = ctx->d_counter;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned), (hipStream_t)hip_stream));
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
         if (sparse_align_pick_variant(b->max_features) != SA_REG320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
         a.workspace = (double*)g_stamp_out;
-        HIP_TRY(ctx, sparse_align_launch_stamps(a, (hipStream_t)hip_stream));
+        HIP_TRY(ctx, sparse_align_launch_stamps(a, ctx->num_cus, (hipStream_t)hip_stream));
         return DSDTM_OK;
     }
     const SAVariant v = sparse_align_pick_variant(b->max_features);
@@ -213,7 +228,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         }
         a.workspace = (double*)ctx->d_ws;
     }
-    HIP_TRY(ctx, sparse_align_launch(a, v, (hipStream_t)hip_stream));
+    HIP_TRY(ctx, sparse_align_launch(a, v, ctx->num_cus, (hipStream_t)hip_stream));
     return DSDTM_OK;
 }
 

@@ -27,6 +27,7 @@ struct SAKernelArgs {
     int32_t* n_tracked;
     dsdtm_align_stats* stats;
     double* workspace;
+    unsigned* pair_counter;     // device word, zeroed before each launch: next pair index for the persistent slots
     unsigned long long pyr_pitch;
     int n_pairs, max_features;
     int max_level, min_level, max_iters, min_fts;
@@ -47,10 +48,10 @@ struct SAKernelArgs {
 enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2 };
 SAVariant sparse_align_pick_variant(int max_features);
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features);
-hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, hipStream_t stream);
+hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream);
 // diagnostic (in-kernel stamps) instantiation of the 5+1-wave register kernel; workspace = n_pairs*8 u64
 int sparse_align_occupancy(int variant);   // occupancy API answer (workgroups per CU)
-hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, hipStream_t stream);
+hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream);
 
 // Align2D: one wavefront per feature.
 struct A2DKernelArgs {

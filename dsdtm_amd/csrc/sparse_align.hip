@@ -71,7 +71,10 @@ struct BlockState {
     unsigned seq;               // number of states published by the solver (1 after solver_init)
     unsigned arrive_h;          // +1 per patch wave whose all-visible H partials are in LDS (BH); a counter of
                                 // its own: a wave signals BH and B1 back to back without waiting in between
-    unsigned pad_;
+    unsigned ack;               // +1 per patch wave that is completely done with the slot's current pair: the
+                                // solver waits for all of them before it rewrites pair/run/ctrl/R for the next one
+    int pair;                   // pair index this slot is working on (>= n_pairs: batch exhausted)
+    int run;                    // 0: the pair is skipped (Min_fts rule), handled by the solver alone
 };
 
 // ---- pair-local synchronisation ------------------------------------------------------------
@@ -655,7 +658,9 @@ __device__ __forceinline__ void solver_finish(const SAKernelArgs& a, int pair, B
 }
 
 // Hand-over protocol of the register kernel (pair-local counters, see pair_signal_arrive & co.):
-//   B0                      solver_init done                       -> seq = 1 (patch waves may read Cref/R/t)
+//   per pair:      ACK      all patch waves are done with the previous pair's state -> ack += NPW (the solver
+//                                                                     may rewrite pair/run/ctrl/R for the next pair)
+//                  B0       pair index published, solver_init done -> seq += 1 (patch waves may read pair/Cref/R/t)
 //   per level:     BH       all-visible H partials are in LDS      -> arrive += NPW (solver sums + factorises
 //                                                                     them while the first pass runs)
 //   per iteration: B1       partials of all patch waves are in LDS -> arrive += NPW (solver may read them)
@@ -697,195 +702,226 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         uint32_t foot[PPW][SA_DMA_PREFETCH ? 7 * FOOT_STRIDE : 1];   // next level's reference footprints (LDS-DMA)
     };
     __shared__ Smem sm;
-    auto& s_all = sm.st;
-    auto& s_part_all = sm.part;
-    auto& s_foot = sm.foot;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int gwave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = gwave / WPP;                              // which pair of this workgroup
-    const int wave = gwave - slot * WPP;                       // wave inside the pair
-    const int ltid = tid - slot * WPP * 64;                    // thread inside the pair
-    const int pair = blockIdx.x * PPW + slot;
+    const int slot = gwave / WPP;                              // which pair slot of this workgroup
+    const int wave = gwave - slot * WPP;                       // wave inside the slot
+    const int ltid = tid - slot * WPP * 64;                    // thread inside the slot
     {
-        // LDS is uninitialised at kernel start: zero the pair-local counters and run the one real
+        // LDS is uninitialised at kernel start: zero the slot-local counters and run the one real
         // workgroup barrier of this kernel while every wave is still present
-        if (tid < PPW) { s_all[tid].arrive = 0u; s_all[tid].arrive_h = 0u; s_all[tid].seq = 0u; }
+        if (tid < PPW) { sm.st[tid].arrive = 0u; sm.st[tid].arrive_h = 0u; sm.st[tid].seq = 0u; sm.st[tid].ack = 0u; }
         __syncthreads();
     }
-    if (pair >= a.n_pairs) return;                             // whole pair slot leaves together
-    WavePartial* s_part = s_part_all[slot];
-    BlockState& s = s_all[slot];
-    const int nf = a.n_features ? a.n_features[pair] : a.max_features;
+    WavePartial* s_part = sm.part[slot];
+    BlockState& s = sm.st[slot];
 
-    // Run(): "Too few features to track" (:34-38) -> return 0, pose untouched
-    if (nf < a.min_fts || a.max_level - 1 < a.min_level) {
-        if (ltid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
-        return;
-    }
-
+    // PERSISTENT SLOTS: the grid is one workgroup per CU; each slot (NPW patch waves + 1 solver wave)
+    // pulls pair indices from a global counter until the batch is exhausted, independently of the
+    // workgroup's other slot. A workgroup that held its CU until BOTH of its pairs finished lost
+    // ~11 % to the spread of pair durations (10..25 Gauss-Newton iterations). The slot-local
+    // counters are monotonic, so they simply keep counting from one pair to the next.
     if (wave == NPW) {
         // ------------------------------ solver wave ------------------------------
-        unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0;
-        unsigned long long t_sub[3] = {0, 0, 0};
-        if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
         unsigned expected = 0, expected_h = 0;                         // B1 / BH arrivals consumed so far
-        unsigned published = 1;                                        // states published so far
+        unsigned published = 0;                                        // states published so far
         // The solve is the serial section of this pair's iteration, and this wave shares its SIMD
-        // with patch waves of the workgroup's other pair: give it issue priority.
+        // with patch waves of the workgroup's other slot: give it issue priority.
         if (PPW > 1) __builtin_amdgcn_s_setprio(2);
-        solver_init(a, pair, s, lane);
-        pair_publish(s, published, lane);                              // B0
-        for (int level = a.max_level - 1; level >= a.min_level; --level) {
-            if (lane == 0) {                                           // GaussNewtonSolver entry (:304-308)
-                s.chi2 = 0.0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s.qo[i] = s.q[i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) s.to[i] = s.t[i];
+        // the first pair of every slot is assigned statically (no atomic round trip on the start-up
+        // path); the counter hands out the pairs behind those
+        const int first_dynamic = (int)gridDim.x * PPW;
+        auto fetch_pair = [&]() -> int {
+            int v = 0;
+            if (lane == 0) v = first_dynamic + (int)atomicAdd(a.pair_counter, 1u);
+            return __builtin_amdgcn_readfirstlane(v);
+        };
+        int pair = (int)blockIdx.x * PPW + slot;
+        unsigned acks = 0;                                             // acknowledgements expected so far
+        while (true) {
+            // every patch wave has finished reading the previous pair's state (pair/run, final ctrl)
+            pair_wait_arrive(&s.ack, acks);
+            const bool have = pair < a.n_pairs;
+            const int nf = have ? (a.n_features ? a.n_features[pair] : a.max_features) : 0;
+            // Run(): "Too few features to track" (:34-38) -> return 0, pose untouched
+            const bool run = have && nf >= a.min_fts && a.max_level - 1 >= a.min_level;
+            if (lane == 0) { s.pair = pair; s.run = run ? 1 : 0; }
+            if (!have) { pair_publish(s, ++published, lane); break; }  // B0 with "no more work"
+            acks += NPW;
+            if (!run) {
+                if (lane == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
+                pair_publish(s, ++published, lane);                    // B0 with "skip"
+                pair = fetch_pair();
+                continue;
             }
-            // speculative: the patch waves publish the all-visible H partials right after the level's
-            // precompute; sum + factorise them here while they run the first pass
-            expected_h += NPW;
-            pair_wait_arrive(&s.arrive_h, expected_h);                 // BH
-            solver_refresh_H<NP>(s_part, s, lane);
-            for (int it = 0; it < a.max_iters; ++it) {
-                unsigned long long t0 = 0, t1 = 0, t2 = 0;
-                if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
-                expected += NPW;
-                pair_wait_arrive(&s.arrive, expected);                 // B1
-                if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
-                const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, STAMPS ? t_sub : nullptr);
-                if (STAMPS) {
-                    t2 = __builtin_amdgcn_s_memtime();
-                    if (it == 0) t_first += t1 - t0; else t_wait += t1 - t0;
-                    t_solve += t2 - t1;
-                    n_it += 1;
+            const int next_pair = fetch_pair();                        // latency hidden under this pair
+            unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0;
+            unsigned long long t_sub[3] = {0, 0, 0};
+            if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
+            solver_init(a, pair, s, lane);
+            pair_publish(s, ++published, lane);                        // B0
+            for (int level = a.max_level - 1; level >= a.min_level; --level) {
+                if (lane == 0) {                                       // GaussNewtonSolver entry (:304-308)
+                    s.chi2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s.qo[i] = s.q[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) s.to[i] = s.t[i];
                 }
-                pair_publish(s, ++published, lane);                    // B2
-                if (ctrl) break;
+                // speculative: the patch waves publish the all-visible H partials right after the
+                // level's precompute; sum + factorise them here while they run the first pass
+                expected_h += NPW;
+                pair_wait_arrive(&s.arrive_h, expected_h);             // BH
+                solver_refresh_H<NP>(s_part, s, lane);
+                for (int it = 0; it < a.max_iters; ++it) {
+                    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+                    if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
+                    expected += NPW;
+                    pair_wait_arrive(&s.arrive, expected);             // B1
+                    if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
+                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, STAMPS ? t_sub : nullptr);
+                    if (STAMPS) {
+                        t2 = __builtin_amdgcn_s_memtime();
+                        if (it == 0) t_first += t1 - t0; else t_wait += t1 - t0;
+                        t_solve += t2 - t1;
+                        n_it += 1;
+                    }
+                    pair_publish(s, ++published, lane);                // B2
+                    if (ctrl) break;
+                }
             }
-        }
-        solver_finish(a, pair, s, lane);
-        if (STAMPS && lane == 0 && a.workspace) {
-            unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 8;
-            o[0] = t_first; o[1] = t_wait; o[2] = t_solve; o[3] = n_it;
-            o[4] = __builtin_amdgcn_s_memtime() - t_begin;
-            o[5] = t_sub[0];
-            o[6] = t_sub[1];
-            o[7] = t_sub[2];
+            solver_finish(a, pair, s, lane);
+            if (STAMPS && lane == 0 && a.workspace) {
+                unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 8;
+                o[0] = t_first; o[1] = t_wait; o[2] = t_solve; o[3] = n_it;
+                o[4] = __builtin_amdgcn_s_memtime() - t_begin;
+                o[5] = t_sub[0];
+                o[6] = t_sub[1];
+                o[7] = t_sub[2];
+            }
+            pair = next_pair;
         }
         return;
     }
 
     // ---------------------------------- patch waves ----------------------------------
-    const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
-    const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
-    const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + ltid, ltid < nf);
-    const bool feat_ok = fraw.initial && !(fraw.w0 == 0.0 && fraw.w1 == 0.0 && fraw.w2 == 0.0);
-    uint32_t* const foot_wave = &s_foot[slot][SA_DMA_PREFETCH ? wave * 64 * 4 : 0];   // wave-uniform DMA base
-    const uint32_t* const foot_lane = &s_foot[slot][SA_DMA_PREFETCH ? ltid * 4 : 0];
-    if (SA_DMA_PREFETCH) prefetch_ref_rows(a, ref_base, fraw.px, fraw.py, feat_ok, a.max_level - 1, foot_wave, FOOT_STRIDE);
-    unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
-    unsigned seen = 1;                                                 // states consumed so far
-    pair_wait_seq(s, 1u);                                              // B0
-    FeatureRegs F;
-    {
-        const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
-        F = make_feature(fraw, Cref);
-    }
+    unsigned seen = 0;                                                 // states consumed so far
     const int row = lane >> 4;
     const bool row_writer = (lane & 15) == 15;
     WavePartial& my_part = s_part[wave * 4 + row];
-
-    for (int level = a.max_level - 1; level >= a.min_level; --level) {
-        const LevelGeom lg = a.lv[level];
-        const double scale = (double)(1.0f / (float)(1 << level));
-        const double fs = (double)a.f * scale;
-        PatchRegs<GT> P;
-        unsigned long long tp0 = 0;
-        if (STAMPS) tp0 = __builtin_amdgcn_s_memtime();
-        if (SA_DMA_PREFETCH) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA rows have landed
-            precompute_patch<GT>(a, lg, level, ref_base, F, P, foot_lane, FOOT_STRIDE);
-        } else {
-            precompute_patch<GT>(a, lg, level, ref_base, F, P);
+    uint32_t* const foot_wave = &sm.foot[slot][SA_DMA_PREFETCH ? wave * 64 * 4 : 0];   // wave-uniform DMA base
+    const uint32_t* const foot_lane = &sm.foot[slot][SA_DMA_PREFETCH ? ltid * 4 : 0];
+    while (true) {
+        pair_wait_seq(s, ++seen);                                      // B0 of the slot's next pair
+        const int pair = __builtin_amdgcn_readfirstlane(s.pair);
+        if (pair >= a.n_pairs) break;                                  // batch exhausted
+        if (!s.run) {                                                  // Min_fts rule handled by the solver
+            pair_signal_arrive(&s.ack, lane);
+            continue;
         }
-        if (STAMPS) {
-            pin_patch(P);   // make the stamp wait for the precompute results
-            st_pre += __builtin_amdgcn_s_memtime() - tp0;
-        }
-        const unsigned long long valid_mask = __ballot(P.valid);
-        const int n_ref_row = __popc((unsigned)(valid_mask >> (16 * row)) & 0xffffu);
-        // Speculative H of the level: every valid patch visible (what the first pass finds almost
-        // always). Published before the pass so that the solver can factorise it meanwhile.
-        unsigned long long cached_mask = valid_mask;
+        const int nf = a.n_features ? a.n_features[pair] : a.max_features;
+        const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
+        const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
+        const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + ltid, ltid < nf);
+        const bool feat_ok = fraw.initial && !(fraw.w0 == 0.0 && fraw.w1 == 0.0 && fraw.w2 == 0.0);
+        if (SA_DMA_PREFETCH) prefetch_ref_rows(a, ref_base, fraw.px, fraw.py, feat_ok, a.max_level - 1, foot_wave, FOOT_STRIDE);
+        unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
+        FeatureRegs F;
         {
-            unsigned long long th0 = 0;
-            if (STAMPS) th0 = __builtin_amdgcn_s_memtime();
-            const PatchHess ph = patch_hess_factors<GT>(P, fs);
-            double* Hout = my_part.H;
-            patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
-                const double hs = row_sum16(P.valid ? v : 0.0);
-                if (row_writer) Hout[q] = hs;
-                __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
-            });
-            pair_signal_arrive(&s.arrive_h, lane);                     // BH
-            if (STAMPS) st_h += __builtin_amdgcn_s_memtime() - th0;
+            const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
+            F = make_feature(fraw, Cref);
         }
 
-        for (int it = 0; it < a.max_iters; ++it) {
-            double chi2, b[6];
-            unsigned long long tq0 = 0, tq1 = 0;
-            if (STAMPS) tq0 = __builtin_amdgcn_s_memtime();
-            pin_patch(P);
-            const bool vis = residual_patch<GT>(a, lg, scale, fs, cur_base, P, s.R, s.tt, chi2, b);
-            const unsigned long long vmask = __ballot(vis);
-            // reduce to the 16-lane DPP rows only (4 steps instead of 6); the solver's lane-parallel
-            // summation folds the 4*NPW row partials
-#pragma unroll
-            for (int i = 0; i < 6; ++i) b[i] = row_sum16(b[i]);
-            chi2 = row_sum16(chi2);
-            if (row_writer) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) my_part.b[i] = b[i];
-                my_part.chi2 = chi2;
-                my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
-                my_part.n_ref = n_ref_row;
+        for (int level = a.max_level - 1; level >= a.min_level; --level) {
+            const LevelGeom lg = a.lv[level];
+            const double scale = (double)(1.0f / (float)(1 << level));
+            const double fs = (double)a.f * scale;
+            PatchRegs<GT> P;
+            unsigned long long tp0 = 0;
+            if (STAMPS) tp0 = __builtin_amdgcn_s_memtime();
+            if (SA_DMA_PREFETCH) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA rows have landed
+                precompute_patch<GT>(a, lg, level, ref_base, F, P, foot_lane, FOOT_STRIDE);
+            } else {
+                precompute_patch<GT>(a, lg, level, ref_base, F, P);
             }
-            if (STAMPS) { tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0; }
-            const bool h_changed = (vmask != cached_mask);            // wave-uniform, rare
-            if (h_changed) {
+            if (STAMPS) {
+                pin_patch(P);   // make the stamp wait for the precompute results
+                st_pre += __builtin_amdgcn_s_memtime() - tp0;
+            }
+            const unsigned long long valid_mask = __ballot(P.valid);
+            const int n_ref_row = __popc((unsigned)(valid_mask >> (16 * row)) & 0xffffu);
+            // Speculative H of the level: every valid patch visible (what the first pass finds almost
+            // always). Published before the pass so that the solver can factorise it meanwhile.
+            unsigned long long cached_mask = valid_mask;
+            {
+                unsigned long long th0 = 0;
+                if (STAMPS) th0 = __builtin_amdgcn_s_memtime();
                 const PatchHess ph = patch_hess_factors<GT>(P, fs);
                 double* Hout = my_part.H;
                 patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
-                    const double hs = row_sum16(vis ? v : 0.0);
+                    const double hs = row_sum16(P.valid ? v : 0.0);
                     if (row_writer) Hout[q] = hs;
                     __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
                 });
-                cached_mask = vmask;
+                pair_signal_arrive(&s.arrive_h, lane);                 // BH
+                if (STAMPS) st_h += __builtin_amdgcn_s_memtime() - th0;
             }
-            if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
-            unsigned long long tq2 = 0;
-            if (STAMPS) { tq2 = __builtin_amdgcn_s_memtime(); st_h += tq2 - tq1; }
-            if (SA_DMA_PREFETCH && it == 0 && level > a.min_level) {
-                // Next level's footprints: issued after this level's first pass has consumed its own
-                // loads (vector-memory results return in order, so an earlier issue would stall that
-                // pass behind these cold misses); they land under the solves of this level.
-                // (the rows of this level were consumed by precompute_patch long ago)
-                prefetch_ref_rows(a, ref_base, F.px, F.py, F.ok, level - 1, foot_wave, FOOT_STRIDE);
+
+            for (int it = 0; it < a.max_iters; ++it) {
+                double chi2, b[6];
+                unsigned long long tq0 = 0, tq1 = 0;
+                if (STAMPS) tq0 = __builtin_amdgcn_s_memtime();
+                pin_patch(P);
+                const bool vis = residual_patch<GT>(a, lg, scale, fs, cur_base, P, s.R, s.tt, chi2, b);
+                const unsigned long long vmask = __ballot(vis);
+                // reduce to the 16-lane DPP rows only (4 steps instead of 6); the solver's lane-parallel
+                // summation folds the 4*NPW row partials
+#pragma unroll
+                for (int i = 0; i < 6; ++i) b[i] = row_sum16(b[i]);
+                chi2 = row_sum16(chi2);
+                if (row_writer) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) my_part.b[i] = b[i];
+                    my_part.chi2 = chi2;
+                    my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
+                    my_part.n_ref = n_ref_row;
+                }
+                if (STAMPS) { tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0; }
+                const bool h_changed = (vmask != cached_mask);        // wave-uniform, rare
+                if (h_changed) {
+                    const PatchHess ph = patch_hess_factors<GT>(P, fs);
+                    double* Hout = my_part.H;
+                    patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
+                        const double hs = row_sum16(vis ? v : 0.0);
+                        if (row_writer) Hout[q] = hs;
+                        __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
+                    });
+                    cached_mask = vmask;
+                }
+                if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
+                unsigned long long tq2 = 0;
+                if (STAMPS) { tq2 = __builtin_amdgcn_s_memtime(); st_h += tq2 - tq1; }
+                if (SA_DMA_PREFETCH && it == 0 && level > a.min_level) {
+                    // Next level's footprints: issued after this level's first pass has consumed its own
+                    // loads (vector-memory results return in order, so an earlier issue would stall that
+                    // pass behind these cold misses); they land under the solves of this level.
+                    prefetch_ref_rows(a, ref_base, F.px, F.py, F.ok, level - 1, foot_wave, FOOT_STRIDE);
+                }
+                ++seen;
+                pair_signal_arrive(&s.arrive, lane);                   // B1
+                pair_wait_seq(s, seen);                                // B2
+                if (STAMPS) st_bar += __builtin_amdgcn_s_memtime() - tq2;
+                if (s.ctrl) break;
             }
-            ++seen;
-            pair_signal_arrive(&s.arrive, lane);                       // B1
-            pair_wait_seq(s, seen);                                    // B2
-            if (STAMPS) st_bar += __builtin_amdgcn_s_memtime() - tq2;
-            if (s.ctrl) break;
         }
-    }
-    if (STAMPS && ltid == 0 && a.workspace) {
-        unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 4;
-        o[0] = st_pre; o[1] = st_pass; o[2] = st_h; o[3] = st_bar;
+        pair_signal_arrive(&s.ack, lane);                              // done with this pair's shared state
+        if (STAMPS && ltid == 0 && a.workspace) {
+            unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 4;
+            o[0] = st_pre; o[1] = st_pass; o[2] = st_h; o[3] = st_bar;
+        }
     }
 }
 
@@ -1059,25 +1095,31 @@ int sparse_align_occupancy(int variant) {
     return nb;
 }
 
-hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, hipStream_t stream) {
+// persistent grid: one workgroup per CU (fewer when the batch is small); slots pull pairs dynamically
+static unsigned persistent_grid(int n_pairs, int ppw, int num_cus) {
+    const int need = (n_pairs + ppw - 1) / ppw;
+    return (unsigned)(need < num_cus ? need : num_cus);
+}
+
+hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, true>), dim3((unsigned)((args.n_pairs + SA_PPW - 1) / SA_PPW)),
+    hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, true>), dim3(persistent_grid(args.n_pairs, SA_PPW, num_cus)),
                        dim3(SA_PPW * 6 * 64), 0, stream, args);
     return hipGetLastError();
 }
 
-hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, hipStream_t stream) {
+hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
     const dim3 grid((unsigned)args.n_pairs);
     // experiment knob: unused dynamic LDS to cap the number of resident workgroups per CU
     static const unsigned lds_pad = getenv("DSDTM_DEBUG_LDS_PAD") ? (unsigned)atoi(getenv("DSDTM_DEBUG_LDS_PAD")) : 0u;
     switch (variant) {
         case SA_REG320:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW>), dim3((unsigned)((args.n_pairs + SA_PPW - 1) / SA_PPW)),
+            hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW>), dim3(persistent_grid(args.n_pairs, SA_PPW, num_cus)),
                                dim3(SA_PPW * 6 * 64), lds_pad, stream, args);
             break;
         case SA_REG448:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<7, SA_GRID_T, 1>), grid, dim3(8 * 64), 0, stream, args);
+            hipLaunchKernelGGL((sparse_align_reg_kernel<7, SA_GRID_T, 1>), dim3(persistent_grid(args.n_pairs, 1, num_cus)), dim3(8 * 64), 0, stream, args);
             break;
         case SA_WS:
             hipLaunchKernelGGL((sparse_align_ws_kernel<7>), grid, dim3(8 * 64), 0, stream, args);

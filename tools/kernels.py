@@ -1,8 +1,8 @@
 """Device-resident timing of the secondary kernels (pyrDown, Align2D, warp prelude) with HIP events.
-Usage: python tools_kernels.py   (MI355X)"""
+Usage: python tools/kernels.py   (MI355X)"""
 import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dsdtm_amd import capi, synth
 from tests import helpers

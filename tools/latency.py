@@ -1,9 +1,9 @@
 """Single-pair latency of the HOST entry points (PCIe-inclusive): what Tracking would see per
 frame through the reference-shaped classes. Configs 2, 3 and 5 of BASELINE.md.
-Usage: python tools_latency.py"""
+Usage: python tools/latency.py"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dsdtm_amd import capi, synth, feature_alignment as FA
 from dsdtm_amd.frame import Config, frames_from_scene
 from dsdtm_amd.sparse_align import Sprase_ImgAlign

@@ -1,8 +1,8 @@
 """Diagnostic: where a Gauss-Newton iteration spends its cycles (in-kernel stamps, separate
-kernel instantiation; never used for timing claims). Usage: python tools_stamps.py [--pairs N]"""
+kernel instantiation; never used for timing claims). Usage: python tools/stamps.py [--pairs N]"""
 import argparse, ctypes as C, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from dsdtm_amd import capi, synth
