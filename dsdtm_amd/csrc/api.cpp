@@ -209,7 +209,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     a.pair_counter = ctx->d_counter;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned), (hipStream_t)hip_stream));
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
-        if (sparse_align_pick_variant(b->max_features) != SA_REG320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
+        if (b->max_features > 320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
         a.workspace = (double*)g_stamp_out;
         HIP_TRY(ctx, sparse_align_launch_stamps(a, ctx->num_cus, (hipStream_t)hip_stream));
         return DSDTM_OK;

@@ -1076,7 +1076,14 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+// Register-kernel shapes: NPW patch waves + 1 solver wave per pair slot, PPW slots per workgroup,
+// always <= 12 waves (3 per SIMD at 168 VGPRs = the whole register file of a CU):
+//   <= 128 features: 2+1 waves x 4 slots     <= 192: 3+1 x 3     <= 256: 4+1 x 2
+//   <= 320 features: 5+1 x 2 (BASELINE shape) <= 448: 7+1 x 1
 SAVariant sparse_align_pick_variant(int max_features) {
+    if (max_features <= 128) return SA_REG128;
+    if (max_features <= 192) return SA_REG192;
+    if (max_features <= 256) return SA_REG256;
     if (max_features <= 320) return SA_REG320;
     if (max_features <= 448) return SA_REG448;
     return SA_WS;
@@ -1089,9 +1096,9 @@ size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
 
 int sparse_align_occupancy(int variant) {
     int nb = -1;
-    if (variant == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, false>, SA_PPW * 6 * 64, 0);
-    else if (variant == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<7, SA_GRID_T, 1, false>, 8 * 64, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<7>, 8 * 64, 0);
+    if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, false>, SA_PPW * 6 * 64, 0);
+    else if (variant == SA_REG448) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<7, SA_GRID_T, 1, false>, 8 * 64, 0);
+    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<7>, 8 * 64, 0);
     return nb;
 }
 
@@ -1114,6 +1121,15 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
     // experiment knob: unused dynamic LDS to cap the number of resident workgroups per CU
     static const unsigned lds_pad = getenv("DSDTM_DEBUG_LDS_PAD") ? (unsigned)atoi(getenv("DSDTM_DEBUG_LDS_PAD")) : 0u;
     switch (variant) {
+        case SA_REG128:
+            hipLaunchKernelGGL((sparse_align_reg_kernel<2, SA_GRID_T, 4>), dim3(persistent_grid(args.n_pairs, 4, num_cus)), dim3(4 * 3 * 64), 0, stream, args);
+            break;
+        case SA_REG192:
+            hipLaunchKernelGGL((sparse_align_reg_kernel<3, SA_GRID_T, 3>), dim3(persistent_grid(args.n_pairs, 3, num_cus)), dim3(3 * 4 * 64), 0, stream, args);
+            break;
+        case SA_REG256:
+            hipLaunchKernelGGL((sparse_align_reg_kernel<4, SA_GRID_T, 2>), dim3(persistent_grid(args.n_pairs, 2, num_cus)), dim3(2 * 5 * 64), 0, stream, args);
+            break;
         case SA_REG320:
             hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW>), dim3(persistent_grid(args.n_pairs, SA_PPW, num_cus)),
                                dim3(SA_PPW * 6 * 64), lds_pad, stream, args);

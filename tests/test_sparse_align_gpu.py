@@ -243,3 +243,65 @@ def test_repeated_launches_are_bitwise_deterministic(gpu_ctx):
         for T, n, st in ref[1:]:
             assert np.array_equal(T, ref[0][0]) and n == ref[0][1] and st["iters"] == ref[0][2]["iters"]
             assert st["chi2"] == ref[0][2]["chi2"]
+
+
+def test_device_api_with_padded_rows(gpu_ctx, oracle):
+    """Device pyramids whose rows are `stride` > width bytes apart. The kernels index rows with
+    `stride` on both sides; the reference mixes `cols` and `step` on the current image (quirk Q7,
+    src/Sprase_ImageAlign.cpp:272-281), which is only self-consistent for continuous cv::Mats — so the
+    expected result is the oracle's on contiguous copies of the same images."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    L, N = 3, 180
+    scenes = [cached_scene(width=320, height=240, levels=L, n_patches=N, seed=900 + i, margin=12) for i in range(3)]
+    ws, hs = [320, 160, 80], [240, 120, 60]
+    st = [w + 12 for w in ws]
+    offs, off = [], 0
+    for l in range(L):
+        offs.append(off)
+        off += (st[l] * hs[l] + 63) // 64 * 64
+    pitch = (off + 255) // 256 * 256
+    P = len(scenes)
+    ref = np.full((P, pitch), 0xAB, np.uint8); cur = np.full((P, pitch), 0xCD, np.uint8)     # poison the padding
+    px = np.zeros((P, N, 2), np.float32); bear = np.zeros((P, N, 3)); pw = np.zeros((P, N, 3))
+    ini = np.zeros((P, N), np.uint8); Tr = np.zeros((P, 12)); Tc = np.zeros((P, 12))
+    for i, sc in enumerate(scenes):
+        for l in range(L):
+            for buf, pyr in ((ref, sc.ref_pyr), (cur, sc.cur_pyr)):
+                view = buf[i, offs[l]:offs[l] + st[l] * hs[l]].reshape(hs[l], st[l])
+                view[:, :ws[l]] = pyr[l]
+        px[i], bear[i], pw[i], ini[i] = sc.px, sc.bearing, sc.p_world, sc.initial
+        Tr[i] = sc.T_ref_w.reshape(12); Tc[i] = sc.T_cur_w_seed.reshape(12)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(ref=ref, cur=cur, px=px, bear=bear, pw=pw, ini=ini, Tr=Tr, Tc=Tc).items()}
+    t["nt"] = torch.zeros(P, dtype=torch.int32, device=dev)
+    b = capi.BatchDesc()
+    b.n_pairs, b.max_features, b.levels = P, N, L
+    for l in range(L):
+        b.width[l], b.height[l], b.stride[l], b.level_offset[l] = ws[l], hs[l], st[l], offs[l]
+    b.pyr_pitch = pitch
+    b.ref_pyr, b.cur_pyr, b.px_xy, b.bearing, b.p_world = (t[k].data_ptr() for k in ("ref", "cur", "px", "bear", "pw"))
+    b.initial, b.n_features, b.T_ref_w, b.T_cur_w = t["ini"].data_ptr(), None, t["Tr"].data_ptr(), t["Tc"].data_ptr()
+    b.n_tracked, b.stats = t["nt"].data_ptr(), None
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    stream = torch.cuda.Stream(device=dev)
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), stream.cuda_stream))
+    stream.synchronize()
+    Tg = t["Tc"].cpu().numpy(); ntg = t["nt"].cpu().numpy()
+    for i, sc in enumerate(scenes):
+        To, no, _ = oracle.sparse_align(sc, L, 0, 10)
+        H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"strided pair {i}")
+        assert ntg[i] == no
+
+
+@pytest.mark.parametrize("n_patches", [16, 100, 128, 129, 192, 193, 256, 257, 320])
+def test_every_register_kernel_shape(gpu_ctx, oracle, n_patches):
+    """Feature counts on both sides of every kernel-shape boundary (2+1x4, 3+1x3, 4+1x2, 5+1x2, 7+1x1 waves)."""
+    sc = cached_scene(width=320, height=240, levels=3, n_patches=n_patches, seed=300 + n_patches, margin=12)
+    To, no, so = oracle.sparse_align(sc, 3, 0, 10)
+    Tg, ng, sg = H.gpu_sparse_align(sc, 3, 0, 10, ctx=gpu_ctx)
+    H.assert_pose_close(Tg, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"N={n_patches}")
+    assert ng == no and sg["iters"] == so["iters"] and sg["exit_code"] == so["exit_code"]
+    assert sg["n_ref"] == so["n_ref"] and sg["n_vis"] == so["n_vis"]
