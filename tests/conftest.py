@@ -22,6 +22,16 @@ def pytest_configure(config):
             pass
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_artifacts():
+    """The suite needs the in-tree HIP library and the CPU oracle; build them when missing or stale
+    (no-ops otherwise). hipcc cross-compiles gfx950 without a GPU."""
+    from dsdtm_amd.csrc import build as hip_build
+    hip_build.build(verbose=False)
+    from tests import oracle_lib
+    oracle_lib.load()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from tests import oracle_lib
