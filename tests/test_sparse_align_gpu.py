@@ -305,3 +305,77 @@ def test_every_register_kernel_shape(gpu_ctx, oracle, n_patches):
     H.assert_pose_close(Tg, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"N={n_patches}")
     assert ng == no and sg["iters"] == so["iters"] and sg["exit_code"] == so["exit_code"]
     assert sg["n_ref"] == so["n_ref"] and sg["n_vis"] == so["n_vis"]
+
+
+def test_chained_sequence_like_tracking(gpu_ctx, oracle):
+    """BASELINE config 3's flow at test size: a sequence of frames aligned against one reference,
+    each result seeding the next Run (Test/test_SpraseImg_alignment.cpp:153-166,
+    src/Tracking.cpp:201) — through the workspace kernel (N = 600 > 448)."""
+    import copy
+    rng = np.random.default_rng(31)
+    base = cached_scene(width=320, height=240, levels=3, n_patches=600, seed=31, margin=12)
+    tex = synth.make_texture(240, 320, 31)
+    Tg = base.T_cur_w_seed.copy(); To = base.T_cur_w_seed.copy()
+    xi = np.zeros(6)
+    for k in range(6):
+        xi = xi + np.concatenate([rng.uniform(-0.006, 0.006, 3), rng.uniform(-0.003, 0.003, 3)])
+        sc = copy.copy(base)
+        T_cr = synth.se3_exp(xi)
+        sc.cur_pyr = synth.build_pyramid(synth.warp_plane(tex, base.cam, T_cr, base.depth), 3)
+        To, no, so = oracle.sparse_align(sc, 3, 0, 8, T_seed=To)
+        Tg, ng, sg = H.gpu_sparse_align(sc, 3, 0, 8, T_seed=Tg, ctx=gpu_ctx)
+        H.assert_pose_close(Tg, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"frame {k}")
+        assert ng == no and sg["iters"] == so["iters"]
+        truth = (T_cr @ np.vstack([base.T_ref_w, [0, 0, 0, 1]]))[:3]
+        ea, et = synth.pose_error(Tg, truth)
+        assert ea < 5e-4 and et < 1e-3, (k, ea, et)
+
+
+def test_batch_launch_is_graph_capturable(gpu_ctx, oracle):
+    """The device entry point only enqueues (a memset node + one kernel): it can be captured into a
+    hipGraph and replayed — no allocation, no synchronisation in the launch path."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N, P = 320, 240, 3, 200, 5
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=700 + i, margin=12) for i in range(P)]
+    ws, hs, st, offs, nbytes = capi.pyramid_layout(W, Hh, L)
+    pitch = (nbytes + 255) // 256 * 256
+    ref = np.zeros((P, pitch), np.uint8); cur = np.zeros((P, pitch), np.uint8)
+    for i, sc in enumerate(scenes):
+        for l in range(L):
+            ref[i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.ref_pyr[l].reshape(-1)
+            cur[i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.cur_pyr[l].reshape(-1)
+    arr = dict(ref=ref, cur=cur, px=np.stack([s.px for s in scenes]), bear=np.stack([s.bearing for s in scenes]),
+               pw=np.stack([s.p_world for s in scenes]), ini=np.stack([s.initial for s in scenes]),
+               Tr=np.stack([s.T_ref_w.reshape(12) for s in scenes]), seed=np.stack([s.T_cur_w_seed.reshape(12) for s in scenes]))
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in arr.items()}
+    t["Tc"] = torch.zeros((P, 12), dtype=torch.float64, device=dev)
+    t["nt"] = torch.zeros(P, dtype=torch.int32, device=dev)
+    b = capi.BatchDesc()
+    b.n_pairs, b.max_features, b.levels = P, N, L
+    for l in range(L):
+        b.width[l], b.height[l], b.stride[l], b.level_offset[l] = ws[l], hs[l], st[l], offs[l]
+    b.pyr_pitch = pitch
+    b.ref_pyr, b.cur_pyr, b.px_xy, b.bearing, b.p_world = (t[k].data_ptr() for k in ("ref", "cur", "px", "bear", "pw"))
+    b.initial, b.n_features, b.T_ref_w, b.T_cur_w = t["ini"].data_ptr(), None, t["Tr"].data_ptr(), t["Tc"].data_ptr()
+    b.n_tracked, b.stats = t["nt"].data_ptr(), None
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    side = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        t["Tc"].copy_(t["seed"])                                   # re-seed, then one launch: one "step"
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm),
+                                                                  torch.cuda.current_stream().cuda_stream))
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in scenes]
+    for rep in range(3):
+        t["Tc"].zero_(); t["nt"].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+        for i, (To, no, _) in enumerate(want):
+            H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"replay {rep} pair {i}")
+            assert ntg[i] == no
