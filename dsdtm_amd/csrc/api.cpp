@@ -326,6 +326,11 @@ extern "C" int dsdtm_sparse_align(dsdtm_ctx* ctx, const dsdtm_pyramid* ref, cons
     if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, ctx->stream)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        unsigned timeout_flag = 0;
+        HIP_TRY(ctx, sparse_align_take_timeout_flag(&timeout_flag));
+        if (timeout_flag) { set_err(ctx, "sparse-align kernel: intra-workgroup hand-over timed out"); return DSDTM_ERR_HIP; }
+    }
     memcpy(T_cur_w, h + o_tc, 96);
     *n_tracked = *(const int32_t*)(h + o_nt);
     if (stats) memcpy(stats, h + o_st, sizeof *stats);

@@ -1,36 +1,43 @@
-// sparse_align.hip — Sprase_ImgAlign::Run as ONE persistent workgroup per frame pair (gfx950).
+// sparse_align.hip — Sprase_ImgAlign::Run on gfx950: persistent pair slots, register-resident patches.
 //
 // Replaces reference src/Sprase_ImageAlign.cpp:29-60 (Run), :62-166 (GetJocabianMat),
 // :169-193 (GetJocabianBA), :240-299 (ComputeResiduals), :301-344 (GaussNewtonSolver).
 //
 // MI355X design (not a translation of the CPU loops):
+//  * One launch runs whole alignments — all levels, all Gauss-Newton iterations, the 6x6 solves and
+//    the accept/revert logic — with no host round trip and no global synchronisation. The grid is
+//    one workgroup per CU; a workgroup holds PPW independent PAIR SLOTS (NPW patch waves + 1 solver
+//    wave each, 12 waves = 3 per SIMD at 168 VGPRs = the CU's whole register file), and every slot
+//    pulls frame pairs from a global counter until the batch is exhausted.
 //  * lane = patch. A 4x4 patch needs the 6x6 grid of bilinearly interpolated reference
 //    intensities around it (reference intensity + the neighbours its central-difference
-//    gradients use, :147-158): 32 live doubles per patch. In the register-resident variant
-//    they stay in the lane's VGPRs for the whole pyramid level — the register file (512 KB
-//    per CU) is the largest on-chip memory, so the "reference patch + Jacobian cache" of the
-//    CPU code (896 B/patch in mRefPatch/mJocabianPatch) never exists in memory at all.
+//    gradients use, :147-158): 32 live doubles per patch, kept in the lane's VGPRs for the whole
+//    pyramid level — the register file (512 KB per CU) is the largest on-chip memory, so the
+//    "reference patch + Jacobian cache" of the CPU code (896 B/patch in mRefPatch/mJocabianPatch)
+//    never exists in memory at all.
 //  * inverse-compositional structure: J_px = dx*A + dy*B with A,B per patch (:160), so
 //      sum_px J J^T = Sxx A A^T + Sxy (A B^T + B A^T) + Syy B B^T     (per level constants)
 //      sum_px J r   = A * sum(dx r) + B * sum(dy r)
-//    H changes between Gauss-Newton iterations only when the set of visible patches does:
-//    each wave caches its H partial together with the 64-bit visibility ballot it was built
-//    for, and re-reduces the 21 entries only when the ballot changes. Per pixel the loop is
-//    4 bilinear FMAs + residual + 3 accumulations instead of the CPU's 36+6 MACs.
-//  * the 5x5 (cur) / 7x7 (ref) u8 footprints are fetched as aligned dwords straight from
-//    the packed pyramid in HBM/L2 (gather; nothing is re-read from memory inside a pass).
-//  * reductions: DPP row rotates + row broadcasts per wave (no LDS traffic), one LDS slot
-//    per wave. A dedicated SOLVER wave (the last wave of the workgroup, which owns no patches)
-//    runs the 6x6 pivoted LDLT, SE(3) exp and the accept/revert logic while the patch waves
-//    sleep on the barrier (their SIMD slots go to co-resident workgroups). Giving the solver
-//    its own control flow keeps the patch registers out of its live ranges and vice versa.
-//  * no host round trip inside an alignment: levels and iterations all run in this launch.
-//  * all decision-carrying arithmetic is FP64 (chi2 accept/revert compares values that
-//    differ in the 5th digit).
+//    Per pixel the loop is 4 bilinear FMAs + residual + 3 accumulations instead of the CPU's 36+6
+//    MACs. H changes between iterations only when the set of visible patches does: every 16-lane
+//    row caches its H partial with the visibility ballot it was built for; the all-visible H of a
+//    level is published right after the precompute and factorised by the solver WHILE the first
+//    pass runs, later iterations only re-run the substitution on the cached LDLT factors.
+//  * the 5x5 (cur) / 7x7 (ref) u8 footprints are gathered with one dwordx2 / dwordx3 load per row
+//    straight from the packed pyramid (a scattered wave-load costs ~64 L1 tag lookups whatever its
+//    width); nothing is re-read from memory inside a pass.
+//  * reductions: DPP row rotations inside 16-lane rows (no LDS traffic), one LDS slot per row; the
+//    slot's SOLVER wave (owns no patches, so its registers and the patch registers never share live
+//    ranges) sums the partials lane-parallel, runs the pivoted-LDLT substitution, a series SE(3) exp
+//    and the accept/revert logic, and publishes R|t + a control word through LDS.
+//  * hand-over between the waves of a slot uses monotonic LDS counters (B0/BH/B1/B2/ACK below), not
+//    s_barrier, so the slots of a workgroup run independently: one slot's solve overlaps the
+//    other's pass.
+//  * all decision-carrying arithmetic is FP64 (chi2 accept/revert compares values that differ in
+//    the 5th-6th digit).
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/dsdtm_amd.h"
 #include "device_math.h"
@@ -38,7 +45,7 @@
 
 namespace dsdtm {
 
-// per-wave partial slot in LDS
+// partial sums of one 16-lane DPP row (register kernel) or of one wave (workspace kernel) in LDS
 struct WavePartial {
     double b[6];
     double chi2;
@@ -83,6 +90,10 @@ struct BlockState {
 // counters instead. All waves of a workgroup are co-resident, every wait has its producer in
 // flight, and every spin is bounded (a broken protocol ends the kernel instead of hanging the GPU).
 constexpr unsigned SPIN_LIMIT = 1u << 24;
+// A spin that runs out means the protocol is broken: the wave leaves the wait (so the kernel always
+// terminates) and raises this device-global flag, which the host entry points turn into an error.
+__device__ unsigned g_handover_timeout = 0;
+__device__ __forceinline__ void spin_timeout() { atomicOr(&g_handover_timeout, 1u); }
 
 __device__ __forceinline__ void pair_signal_arrive(unsigned* counter, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS stores first
@@ -92,6 +103,7 @@ __device__ __forceinline__ void pair_wait_arrive(unsigned* counter, unsigned tar
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < SPIN_LIMIT)
         __builtin_amdgcn_s_sleep(1);
+    if (spins >= SPIN_LIMIT) spin_timeout();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void pair_publish(BlockState& s, unsigned seq, int lane) {
@@ -102,6 +114,7 @@ __device__ __forceinline__ void pair_wait_seq(BlockState& s, unsigned seq) {
     unsigned spins = 0;
     while (__hip_atomic_load(&s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq && ++spins < SPIN_LIMIT)
         __builtin_amdgcn_s_sleep(1);
+    if (spins >= SPIN_LIMIT) spin_timeout();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -1094,6 +1107,17 @@ size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
     return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
 }
 
+// reads (and clears) the hand-over timeout flag; synchronous, host entry points only
+hipError_t sparse_align_take_timeout_flag(unsigned* flag) {
+    hipError_t e = hipMemcpyFromSymbol(flag, HIP_SYMBOL(g_handover_timeout), sizeof(unsigned));
+    if (e != hipSuccess) return e;
+    if (*flag) {
+        const unsigned zero = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_handover_timeout), &zero, sizeof(unsigned));
+    }
+    return e;
+}
+
 int sparse_align_occupancy(int variant) {
     int nb = -1;
     if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, false>, SA_PPW * 6 * 64, 0);
@@ -1118,8 +1142,6 @@ hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hip
 hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
     const dim3 grid((unsigned)args.n_pairs);
-    // experiment knob: unused dynamic LDS to cap the number of resident workgroups per CU
-    static const unsigned lds_pad = getenv("DSDTM_DEBUG_LDS_PAD") ? (unsigned)atoi(getenv("DSDTM_DEBUG_LDS_PAD")) : 0u;
     switch (variant) {
         case SA_REG128:
             hipLaunchKernelGGL((sparse_align_reg_kernel<2, SA_GRID_T, 4>), dim3(persistent_grid(args.n_pairs, 4, num_cus)), dim3(4 * 3 * 64), 0, stream, args);
@@ -1132,7 +1154,7 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
             break;
         case SA_REG320:
             hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW>), dim3(persistent_grid(args.n_pairs, SA_PPW, num_cus)),
-                               dim3(SA_PPW * 6 * 64), lds_pad, stream, args);
+                               dim3(SA_PPW * 6 * 64), 0, stream, args);
             break;
         case SA_REG448:
             hipLaunchKernelGGL((sparse_align_reg_kernel<7, SA_GRID_T, 1>), dim3(persistent_grid(args.n_pairs, 1, num_cus)), dim3(8 * 64), 0, stream, args);
