@@ -29,8 +29,10 @@ struct dsdtm_ctx {
     // workspace for the generic sparse-align kernel
     void* d_ws = nullptr;
     size_t ws_cap = 0;
-    // pair counter of the persistent sparse-align kernel (zeroed by a memset node before each launch)
+    // pair counters of the persistent sparse-align kernel: a ring of 64 words, one per launch in flight
+    // (each zeroed by a memset node on the launch stream right before its kernel)
     unsigned* d_counter = nullptr;
+    unsigned launch_seq = 0;
     int num_cus = 256;
 };
 
@@ -206,8 +208,8 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy; a.f = cam->f;
     // the persistent kernels pull pair indices from this word: reset it on the launch stream
     // (a memset node when the stream is being captured into a hipGraph)
-    a.pair_counter = ctx->d_counter;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned), (hipStream_t)hip_stream));
+    a.pair_counter = ctx->d_counter + (ctx->launch_seq++ & 63u);
+    HIP_TRY(ctx, hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned), (hipStream_t)hip_stream));
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
         if (b->max_features > 320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
         a.workspace = (double*)g_stamp_out;
