@@ -64,9 +64,12 @@ struct BlockState {
     double chi2;
     double qr[4], tr[3];        // T_ref_w
     double Hsum[21];            // sum of the per-row H partials of the last change of the visible set
-    double Fm[21], Fdinv[6];    // cached LDLT factors of Hsum (ldlt6_factor), reused until the set changes
-    int Ftr[5];
+    double Fm[21], Fdinv[6];    // LDLT factors of Hsum (ldlt6_factor): used directly by the first solve after a
+    int Ftr[5];                 // (re)factorisation ...
     unsigned Fmask;
+    double Hinv[36];            // ... and turned into H^+ = P^T L^-T D^+ L^-1 P column by column (ldlt6_factor + ldlt6_apply on the
+                                // unit vectors, Eigen's pivoted LDLT with pseudo-inverse of D), formed once per
+                                // change of the visible set; every iteration then only needs x = H^+ b
     double bsum[7];             // b totals + chi2 total of the current iteration
     // published to the patch waves
     double R[9], tt[3];         // rotation matrix + translation of T_c2r for the residual pass
@@ -523,6 +526,36 @@ __device__ __attribute__((noinline)) void factor_to_lds(LdsBlockState* sp, int l
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// H^+ column j = solve(e_j): the same substitution the reference runs on b every iteration (:318),
+// done six times — after the first solve of the factorisation has been published, i.e. while the
+// patch waves run their next pass — so that the remaining iterations only need the matrix-vector
+// product. x = sum_j b_j * column_j is that substitution up to rounding (it is linear in b),
+// including the zeroed components of a rank-deficient system.
+__device__ __attribute__((noinline)) void hinv_to_lds(LdsBlockState* sp, int lane) {
+    LdsBlockState& s = *sp;
+    double Fm[21], Fdinv[6];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) Fm[i] = s.Fm[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Fdinv[i] = s.Fdinv[i];
+    const int tr0 = s.Ftr[0], tr1 = s.Ftr[1], tr2 = s.Ftr[2], tr3 = s.Ftr[3], tr4 = s.Ftr[4];
+    const unsigned dmask = s.Fmask;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double e[6], col[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) e[i] = (i == j) ? 1.0 : 0.0;
+        ldlt6_apply(Fm, Fdinv, tr0, tr1, tr2, tr3, tr4, dmask, e, col);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s.Hinv[j * 6 + i] = col[i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Sum the per-row H partials (lane q < 21 sums entry q over the NP slots in fixed order) and
 // factorise the total. Called once per level on the all-visible H — speculatively, while the patch
 // waves run the level's first pass — and again only if a row later reports a different visible set.
@@ -546,7 +579,7 @@ __device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, Bloc
 // lanes of the solver wave (same cost as one lane); lane 0 publishes. Returns ctrl.
 template <int NP>   // NP = number of partial slots (rows or waves)
 __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int level, int it,
-                                           const WavePartial* s_part, BlockState& s, int lane,
+                                           const WavePartial* s_part, BlockState& s, int lane, bool& hinv_valid,
                                            unsigned long long* tacc = nullptr /* diagnostic build only */) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     if (tacc) ts0 = __builtin_amdgcn_s_memtime();
@@ -566,32 +599,62 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     const int cnt = packed & 0xffff;
     const int n_ref = (packed >> 16) & 0xffff;
     const int changed = __ballot(chg) != 0ull;
-    if (changed) solver_refresh_H<NP>(s_part, s, lane);   // rare: a row's visible set differs from the cached one
+    if (changed) {                                        // rare: a row's visible set differs from the cached one
+        solver_refresh_H<NP>(s_part, s, lane);
+        hinv_valid = false;
+    }
+    double bs[6], chi2s;
     {
         constexpr int WP = sizeof(WavePartial) / sizeof(double);
         const double* base = (const double*)s_part;
         // doubles inside WavePartial: b[0..5] at 0, chi2 at 6
-        if (lane < 7) {
+        if constexpr (NP % 4 == 0) {
+            // lane = 4*v + c sums value v over the slots of chunk c (NP/4 each); the four chunk sums of a
+            // quad are folded with two DPP quad permutes; readlane broadcasts the totals. Fixed order
+            // => deterministic; no LDS round trip on the per-iteration path.
+            constexpr int CH = NP / 4;
+            const int v = (lane >> 2) < 7 ? (lane >> 2) : 6, c = lane & 3;
             double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) acc += base[(c * CH + k) * WP + v];
+            acc += dpp_f64<0xB1, 0xf>(acc);    // quad_perm [1,0,3,2]
+            acc += dpp_f64<0x4E, 0xf>(acc);    // quad_perm [2,3,0,1]
+            const int lo = __double2loint(acc), hi = __double2hiint(acc);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                bs[i] = __hiloint2double(__builtin_amdgcn_readlane(hi, 4 * i), __builtin_amdgcn_readlane(lo, 4 * i));
+            chi2s = __hiloint2double(__builtin_amdgcn_readlane(hi, 24), __builtin_amdgcn_readlane(lo, 24));
+        } else {
+            if (lane < 7) {
+                double acc = 0.0;
 #pragma unroll 4
-            for (int w = 0; w < NP; ++w) acc += base[w * WP + lane];   // fixed slot order: deterministic
-            s.bsum[lane] = acc;
+                for (int w = 0; w < NP; ++w) acc += base[w * WP + lane];   // fixed slot order: deterministic
+                s.bsum[lane] = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bs[i] = s.bsum[i];
+            chi2s = s.bsum[6];
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    double bs[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) bs[i] = s.bsum[i];
-    const double chi2s = s.bsum[6];
     if (tacc) { asm volatile("" : "+v"(bs[0])); ts1 = __builtin_amdgcn_s_memtime(); }
     const double chi2New = chi2s / (double)(16 * cnt);     // :298 (0/0 -> NaN)
-    // H.ldlt().solve(JRes) (:318). H is unchanged while the visible set is: factorise only when a
-    // row reported a new ballot, otherwise reuse the cached factors (same factors => same x).
+    // H.ldlt().solve(JRes) (:318): the substitution on the cached factors for the first solve after
+    // a (re)factorisation, x = H^+ b afterwards (H^+ is formed right after that first solve is
+    // published, see the caller)
     __builtin_amdgcn_sched_barrier(0);   // keep the solver's sub-steps in order: short live ranges, no spills
     double x[6];
-    {
+    if (hinv_valid) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] += s.Hinv[j * 6 + i] * bs[j];
+        }
+    } else {
         double Fm[21], Fdinv[6];
 #pragma unroll
         for (int i = 0; i < 21; ++i) Fm[i] = s.Fm[i];
@@ -788,13 +851,14 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 expected_h += NPW;
                 pair_wait_arrive(&s.arrive_h, expected_h);             // BH
                 solver_refresh_H<NP>(s_part, s, lane);
+                bool hinv_valid = false;
                 for (int it = 0; it < a.max_iters; ++it) {
                     unsigned long long t0 = 0, t1 = 0, t2 = 0;
                     if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
                     expected += NPW;
                     pair_wait_arrive(&s.arrive, expected);             // B1
                     if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
-                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, STAMPS ? t_sub : nullptr);
+                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hinv_valid, STAMPS ? t_sub : nullptr);
                     if (STAMPS) {
                         t2 = __builtin_amdgcn_s_memtime();
                         if (it == 0) t_first += t1 - t0; else t_wait += t1 - t0;
@@ -803,6 +867,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     }
                     pair_publish(s, ++published, lane);                // B2
                     if (ctrl) break;
+                    if (!hinv_valid) {                                 // under the patch waves' next pass
+                        hinv_to_lds((LdsBlockState*)&s, lane);
+                        hinv_valid = true;
+                    }
                 }
             }
             solver_finish(a, pair, s, lane);
@@ -1010,7 +1078,8 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
             }
             for (int it = 0; it < a.max_iters; ++it) {
                 __syncthreads();                                       // B1
-                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane);
+                bool hinv_valid = false;                               // this kernel refactorises every iteration
+                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hinv_valid);
                 __syncthreads();                                       // B2
                 if (ctrl) break;
             }
