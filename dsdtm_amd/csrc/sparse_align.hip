@@ -137,6 +137,11 @@ __device__ __forceinline__ SE3d load_se3(const double* q, const double* t) {
 struct __attribute__((packed, aligned(4))) U32x3 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a, b; };
 
+// Footprint gathers: plain loads (a timing-only experiment with sc1 / nt cache bits on these two
+// instructions made the residual pass longer, nt by ~85 %).
+__device__ __forceinline__ U32x3 gather_x3(const uint32_t* p) { return *(const U32x3*)p; }
+__device__ __forceinline__ U32x2 gather_x2(const uint32_t* p) { return *(const U32x2*)p; }
+
 // byte k (0..3) of a dword as double (v_cvt_f32_ubyteK + v_cvt_f64_f32; exact)
 __device__ __forceinline__ double ub(uint32_t w, int k) {
     return (double)(float)((w >> (8 * k)) & 0xffu);
@@ -268,11 +273,12 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
     // gradient neighbours are g[i+1][k], g[i+1][k+2], g[i][k+1], g[i+2][k+1] (:150-158).
     const uint32_t* __restrict__ img32 = (const uint32_t*)ref_base;
     const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
-    double top[7], bot[7];
+    // all seven row gathers are issued before the first one is consumed: the rows are cold (each
+    // its own cache line), and seven dependent round trips would be seven HBM latencies per level
+    uint32_t rlo[7], rhi[7];
+    if (staged) {
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        uint32_t lo, hi;
-        if (staged) {
+        for (int r = 0; r < 7; ++r) {
             // rows prefetched by prefetch_ref_rows: 3 dwords starting at dword min(dw, last_dw-2)
             const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
             const uint32_t dw = o >> 2;
@@ -280,20 +286,34 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
             const uint32_t dwc = min(dw, last_dw - 2u);
             const uint32_t a0 = staged[r * staged_stride], a1 = staged[r * staged_stride + 1], a2 = staged[r * staged_stride + 2];
             const uint32_t w0 = (dwc == dw) ? a0 : a1, w1 = (dwc == dw) ? a1 : a2, w2 = (dwc == dw) ? a2 : 0u;
-            lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-            hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-        } else {
+            rlo[r] = __builtin_amdgcn_alignbit(w1, w0, sh);
+            rhi[r] = __builtin_amdgcn_alignbit(w2, w1, sh);
+        }
+    } else {
+        U32x3 w[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
+            // (dw+2 may be the dword after the last pixel of the pyramid: shift the window back by one
+            // dword there; wave-uniformly false except at the very end of the allocation)
+            w[r] = gather_x3(img32 + min(o >> 2, last_dw - 2u));
+        }
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
             const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
             const uint32_t dw = o >> 2;
             const uint32_t sh = (o & 3u) * 8u;
-            // (dw+2 may be the dword after the last pixel of the pyramid: shift the window back by one
-            // dword there; wave-uniformly false except at the very end of the allocation)
             const uint32_t dwc = min(dw, last_dw - 2u);
-            const U32x3 w = *(const U32x3*)(img32 + dwc);
-            const uint32_t w0 = (dwc == dw) ? w.a : w.b, w1 = (dwc == dw) ? w.b : w.c, w2 = (dwc == dw) ? w.c : 0u;
-            lo = __builtin_amdgcn_alignbit(w1, w0, sh);                 // bytes 0..3
-            hi = __builtin_amdgcn_alignbit(w2, w1, sh);                 // bytes 4..7
+            const uint32_t w0 = (dwc == dw) ? w[r].a : w[r].b, w1 = (dwc == dw) ? w[r].b : w[r].c, w2 = (dwc == dw) ? w[r].c : 0u;
+            rlo[r] = __builtin_amdgcn_alignbit(w1, w0, sh);             // bytes 0..3
+            rhi[r] = __builtin_amdgcn_alignbit(w2, w1, sh);             // bytes 4..7
         }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double top[7], bot[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t lo = rlo[r], hi = rhi[r];
         bot[0] = ub(lo, 0); bot[1] = ub(lo, 1); bot[2] = ub(lo, 2); bot[3] = ub(lo, 3);
         bot[4] = ub(hi, 0); bot[5] = ub(hi, 1); bot[6] = ub(hi, 2);
         if (r > 0) {
@@ -420,14 +440,19 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
 
     const uint32_t* __restrict__ img32 = (const uint32_t*)cur_base;
     uint32_t wlo[5], whi[5];
+    U32x2 wr[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
         const uint32_t o = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 2);
         const uint32_t dw = o >> 2;
+        wr[r] = gather_x2(img32 + dw);                      // one global_load_dwordx2
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const uint32_t o = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 2);
         const uint32_t sh = (o & 3u) * 8u;
-        const U32x2 w = *(const U32x2*)(img32 + dw);        // one global_load_dwordx2
-        wlo[r] = __builtin_amdgcn_alignbit(w.b, w.a, sh);  // bytes 0..3 of the row
-        whi[r] = w.b >> sh;                                 // byte 4 in bits 0..7
+        wlo[r] = __builtin_amdgcn_alignbit(wr[r].b, wr[r].a, sh);  // bytes 0..3 of the row
+        whi[r] = wr[r].b >> sh;                                     // byte 4 in bits 0..7
     }
     // two footprint rows in flight, ping-ponged by the (static) row parity so that no register
     // copies are needed between rows
