@@ -129,6 +129,10 @@ def build_batch(torch, dev, ctx, cam, n_pairs, width, height, levels, n_patches,
     # features: Tracking's view of the reference frame (px f32, unit bearing, world point)
     px = np.stack([rng.uniform(30, width - 30, (n_pairs, n_patches)),
                    rng.uniform(30, height - 30, (n_pairs, n_patches))], axis=2).astype(np.float32)
+    if os.environ.get("DSDTM_BENCH_CLUSTER"):   # diagnostic (tools/stamps.py): all features of a pair inside a WxH window
+        cw, ch = (int(v) for v in os.environ["DSDTM_BENCH_CLUSTER"].split("x"))
+        px = np.stack([rng.uniform(width / 2 - cw / 2, width / 2 + cw / 2, (n_pairs, n_patches)),
+                       rng.uniform(height / 2 - ch / 2, height / 2 + ch / 2, (n_pairs, n_patches))], axis=2).astype(np.float32)
     bearing = synth.bearing_from_px(cam, px.reshape(-1, 2)).reshape(n_pairs, n_patches, 3)
     X_r = bearing * (depth[:, None, None] / bearing[:, :, 2:3])
     Rr, tr = T_ref[:, :3, :3], T_ref[:, :3, 3]

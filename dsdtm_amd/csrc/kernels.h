@@ -43,6 +43,14 @@ struct SAKernelArgs {
 #ifndef SA_PPW
 #define SA_PPW 2
 #endif
+// current-image footprint windows in LDS (residual_patch): on/off and rows per window (5 = no vertical
+// slack, 7 = the floor position may move by one row before a lane refills)
+#ifndef SA_WINDOW
+#define SA_WINDOW 1
+#endif
+#ifndef SA_WIN_ROWS
+#define SA_WIN_ROWS 5
+#endif
 #define DSDTM_STR2(x) #x
 #define DSDTM_STR(x) DSDTM_STR2(x)
 enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2, SA_REG128 = 3, SA_REG192 = 4, SA_REG256 = 5 };

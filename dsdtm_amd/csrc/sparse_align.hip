@@ -23,9 +23,12 @@
 //    row caches its H partial with the visibility ballot it was built for; the all-visible H of a
 //    level is published right after the precompute and factorised by the solver WHILE the first
 //    pass runs, later iterations only re-run the substitution on the cached LDLT factors.
-//  * the 5x5 (cur) / 7x7 (ref) u8 footprints are gathered with one dwordx2 / dwordx3 load per row
-//    straight from the packed pyramid (a scattered wave-load costs ~64 L1 tag lookups whatever its
-//    width); nothing is re-read from memory inside a pass.
+//  * the 7x7 (ref) u8 footprints are gathered with one dwordx3 load per row straight from the packed
+//    pyramid, all seven in flight together (a scattered wave-load costs ~64 L1 tag lookups whatever
+//    its width, and every row is its own cold cache line). The 5x5 (cur) footprint of a patch moves
+//    by a fraction of a pixel per iteration: it is gathered once per level into a 5-row x 12-byte
+//    window per patch in LDS and re-read from there; a lane refills its window only when the
+//    floor position leaves it (the CU's 32 KB L1 cannot hold the 1500 lines a pair-level touches).
 //  * reductions: DPP row rotations inside 16-lane rows (no LDS traffic), one LDS slot per row; the
 //    slot's SOLVER wave (owns no patches, so its registers and the patch registers never share live
 //    ranges) sums the partials lane-parallel, runs the pivoted-LDLT substitution, a series SE(3) exp
@@ -235,34 +238,25 @@ __device__ __forceinline__ FeatureRegs make_feature(const FeatureRaw& r, const d
 }
 
 // Per-level part of GetJocabianMat for one feature (reference :89-100, :123-162), producing the
-// register-resident state.
-// `staged` (may be null) points at this lane's 3 dwords of footprint row 0 in LDS, rows
-// `staged_stride` dwords apart, as written by prefetch_ref_rows (LDS-DMA); the caller has waited for
-// the DMA (vmcnt). Otherwise the rows are gathered from the pyramid in HBM.
+// register-resident state. Branch-free: lanes without a valid patch run the same instructions on a
+// harmless address (the level's first bytes) and end up with P.valid == false and an unused grid, so
+// the seven row gathers, the hooks and the arithmetic sit in straight-line code.
 template <typename GT>
 __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const LevelGeom& lg, int level,
                                                  const uint8_t* __restrict__ ref_base,  // pair's ref pyramid
-                                                 const FeatureRegs& F, PatchRegs<GT>& P,
-                                                 const uint32_t* staged = nullptr, int staged_stride = 0) {
-    P.valid = false;
+                                                 const FeatureRegs& F, PatchRegs<GT>& P) {
     P.X[0] = F.X[0]; P.X[1] = F.X[1]; P.X[2] = F.X[2];
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) P.g[r][c] = (GT)0;
-    if (!F.ok) return;
     const float scale_f = 1.0f / (float)(1 << level);                  // :65 tScale (float)
     const double scale = (double)scale_f;
     const double px = (double)F.px * scale;                            // :89-91
     const double py = (double)F.py * scale;
     const double boarder = 3.0;                                        // :67 int(0.5*4+1)
-    if (px - boarder < 0 || py - boarder < 0 || px + boarder >= (double)lg.w ||
-        py + boarder >= (double)lg.h || !(px == px) || !(py == py))
-        return;                                                        // :95-100
-    P.valid = true;
+    const bool valid = F.ok && !(px - boarder < 0 || py - boarder < 0 || px + boarder >= (double)lg.w ||
+                                 py + boarder >= (double)lg.h || !(px == px) || !(py == py));   // :86, :95-100
+    P.valid = valid;
     // :123-132
     const double fu_d = floor(px), fv_d = floor(py);
-    const int fu = (int)fu_d, fv = (int)fv_d;
+    const int fu = valid ? (int)fu_d : 3, fv = valid ? (int)fv_d : 3;
     const double su = px - fu_d, sv = py - fv_d;
     const double omx = 1.0 - su, omy = 1.0 - sv;
     const double w00 = omx * omy, w01 = su * omy, w10 = omx * sv, w11 = su * sv;
@@ -276,31 +270,18 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
     // all seven row gathers are issued before the first one is consumed: the rows are cold (each
     // its own cache line), and seven dependent round trips would be seven HBM latencies per level
     uint32_t rlo[7], rhi[7];
-    if (staged) {
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            // rows prefetched by prefetch_ref_rows: 3 dwords starting at dword min(dw, last_dw-2)
-            const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
-            const uint32_t dw = o >> 2;
-            const uint32_t sh = (o & 3u) * 8u;
-            const uint32_t dwc = min(dw, last_dw - 2u);
-            const uint32_t a0 = staged[r * staged_stride], a1 = staged[r * staged_stride + 1], a2 = staged[r * staged_stride + 2];
-            const uint32_t w0 = (dwc == dw) ? a0 : a1, w1 = (dwc == dw) ? a1 : a2, w2 = (dwc == dw) ? a2 : 0u;
-            rlo[r] = __builtin_amdgcn_alignbit(w1, w0, sh);
-            rhi[r] = __builtin_amdgcn_alignbit(w2, w1, sh);
-        }
-    } else {
+    {
         U32x3 w[7];
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
-            const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
             // (dw+2 may be the dword after the last pixel of the pyramid: shift the window back by one
             // dword there; wave-uniformly false except at the very end of the allocation)
+            const uint32_t o = valid ? lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3) : lg.off;
             w[r] = gather_x3(img32 + min(o >> 2, last_dw - 2u));
         }
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
-            const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
+            const uint32_t o = valid ? lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3) : lg.off;
             const uint32_t dw = o >> 2;
             const uint32_t sh = (o & 3u) * 8u;
             const uint32_t dwc = min(dw, last_dw - 2u);
@@ -319,51 +300,13 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
         if (r > 0) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                if ((r - 1 == 0 || r - 1 == 5) && (c == 0 || c == 5)) continue;
+                if ((r - 1 == 0 || r - 1 == 5) && (c == 0 || c == 5)) { P.g[r - 1][c] = (GT)0; continue; }   // corners: unused
                 P.g[r - 1][c] = (GT)(w00 * top[c] + w01 * top[c + 1] + w10 * bot[c] + w11 * bot[c + 1]);
             }
         }
 #pragma unroll
         for (int c = 0; c < 7; ++c) top[c] = bot[c];
-        __builtin_amdgcn_sched_barrier(0);   // same: one footprint row in flight
-    }
-}
-
-// Asynchronous prefetch of one level's reference footprints (7 rows x 12 bytes per feature) into
-// LDS with LDS-DMA (global_load_lds_dwordx3: per-lane global address, 12 bytes per lane written at
-// a 16-byte lane stride behind a wave-uniform LDS base; no VGPR destination, nothing waits). It is issued a
-// whole pyramid level ahead — right after the current level's precompute — so the cold HBM gather
-// of the next level (features -> address -> image, ~10 k cycles when done on demand) runs under the
-// current level's Gauss-Newton iterations. The consumer is the same wave (s_waitcnt vmcnt(0)).
-// Measured: correct, but NOT faster at 2 pairs/CU — the cold gathers are bound by the
-// CU's memory-level parallelism, and in-order VMEM return makes the next pass wait behind the DMA —
-// so it is off by default (build with -DSA_DMA_PREFETCH=1 to enable).
-#ifndef SA_DMA_PREFETCH
-#define SA_DMA_PREFETCH 0
-#endif
-__device__ __forceinline__ bool level_valid(float fpx, float fpy, bool ok, const LevelGeom& lg, int level, double& px, double& py) {
-    const double scale = (double)(1.0f / (float)(1 << level));
-    px = (double)fpx * scale;
-    py = (double)fpy * scale;
-    return ok && !(px - 3.0 < 0 || py - 3.0 < 0 || px + 3.0 >= (double)lg.w || py + 3.0 >= (double)lg.h ||
-                   !(px == px) || !(py == py));
-}
-
-__device__ __forceinline__ void prefetch_ref_rows(const SAKernelArgs& a, const uint8_t* __restrict__ ref_base,
-                                                  float fpx, float fpy, bool ok, int level,
-                                                  uint32_t* lds_wave_row0, int row_stride) {
-    const uint32_t* __restrict__ img32 = (const uint32_t*)ref_base;
-    const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
-    const LevelGeom lg = a.lv[level];
-    double px, py;
-    const bool v = level_valid(fpx, fpy, ok, lg, level, px, py);
-    const int fu = v ? (int)floor(px) : 3, fv = v ? (int)floor(py) : 3;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        const uint32_t o = lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3);
-        const uint32_t dwc = min(o >> 2, last_dw - 2u);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img32 + dwc),
-                                         (__attribute__((address_space(3))) void*)(lds_wave_row0 + r * row_stride), 12, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // one footprint row in flight
     }
 }
 
@@ -407,29 +350,87 @@ __device__ __forceinline__ void patch_hess_foreach(const PatchHess& h, F&& f) {
     else if constexpr (I < 5) patch_hess_foreach<I + 1, I + 1>(h, f);
 }
 
+// WIN_NL > 0: the current-image footprint is served from a per-patch WINDOW in LDS. Between two
+// Gauss-Newton iterations a patch moves by a fraction of a pixel, but every footprint row is its own
+// cache line and a pair-level touches far more lines (300 x 5 x 128 B) than the CU's 32 KB L1 holds,
+// so each pass would re-fetch all of them from L2 (measured: 5.5 k cycles per pass at levels 0/1
+// against 2.9 k when the gathers hit). The window holds WIN_ROWS rows x 12 bytes (3 aligned
+// dwords from column u0-3 of rows v0-(WIN_ROWS-1)/2 ..) around the position (u0, v0) of the pass that
+// filled it; a pass whose floor position is within [u0-1, u0+3] x [v0-t, v0+t], t = (WIN_ROWS-5)/2,
+// reads LDS only, otherwise the lane refills its window from the pyramid. Layout [row*3+dword][lane]
+// (`win` points at this lane's column, planes are WIN_NL dwords apart): conflict-free.
+constexpr int WIN_ROWS = SA_WIN_ROWS;
+constexpr uint32_t WIN_EMPTY = 0xffffffffu;
+typedef __attribute__((address_space(3))) uint32_t LdsU32;
+
+
+// tT_c2r * X -> pixel of the current level (reference :254-262). Returns the visibility test of :262.
+__device__ __forceinline__ bool project_patch(const SAKernelArgs& a, const LevelGeom& lg, double scale, const double* X,
+                                              const double* __restrict__ sR, const double* __restrict__ st,
+                                              double& u, double& v) {
+    // :254 tT_c2r * X, divided through by z > 0 (the projection below is scale invariant):
+    // (R X + t)/z = R (x/z, y/z, 1) + t/z   (R, t are LDS broadcasts)
+    const double pxc = sR[0] * X[0] + sR[1] * X[1] + sR[2] + st[0] * X[2];
+    const double pyc = sR[3] * X[0] + sR[4] * X[1] + sR[5] + st[1] * X[2];
+    const double pzc = sR[6] * X[0] + sR[7] * X[1] + sR[8] + st[2] * X[2];
+    // Camera2Pixel (src/Camera.cpp:167-171), * tScale (:255)
+    // one reciprocal for both coordinates (the reference divides twice; <= 1 ulp on u,v)
+    const double izc = 1.0 / pzc;
+    u = ((double)a.fx * pxc * izc + (double)a.cx) * scale;
+    v = ((double)a.fy * pyc * izc + (double)a.cy) * scale;
+    // :262 with mnboarder = 3 on floored ints: floor(u) >= 3 && floor(u)+3 < cols (NaN fails)
+    return u >= 3.0 && u < (double)(lg.w - 3) && v >= 3.0 && v < (double)(lg.h - 3);
+}
+
+// A window fill in flight: the row gathers have been issued, window_commit parks them in LDS.
+struct WinFill {
+    U32x3 w[WIN_ROWS];
+    int u_i, v_i;
+};
+
+__device__ __forceinline__ void window_issue(const SAKernelArgs& a, const LevelGeom& lg, const uint8_t* __restrict__ cur_base,
+                                             int u_i, int v_i, WinFill& f) {
+    constexpr int HR = (WIN_ROWS - 1) / 2;
+    const uint32_t* __restrict__ img32 = (const uint32_t*)cur_base;
+    const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
+    f.u_i = u_i; f.v_i = v_i;
+    // (u_i >= 3, HR <= v_i < h - HR: in range; the last dword of the allocation is handled as in
+    // precompute_patch)
+#pragma unroll
+    for (int r = 0; r < WIN_ROWS; ++r) {
+        const uint32_t o = lg.off + (uint32_t)(v_i - HR + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 3);
+        f.w[r] = gather_x3(img32 + min(o >> 2, last_dw - 2u));
+    }
+}
+
+template <int WIN_NL>
+__device__ __forceinline__ void window_commit(const SAKernelArgs& a, const LevelGeom& lg, const WinFill& f, LdsU32* win, uint32_t& worg) {
+    constexpr int HR = (WIN_ROWS - 1) / 2;
+    const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
+#pragma unroll
+    for (int r = 0; r < WIN_ROWS; ++r) {
+        const uint32_t o = lg.off + (uint32_t)(f.v_i - HR + r) * (uint32_t)lg.stride + (uint32_t)(f.u_i - 3);
+        const bool in = min(o >> 2, last_dw - 2u) == (o >> 2);
+        win[(r * 3 + 0) * WIN_NL] = in ? f.w[r].a : f.w[r].b;
+        win[(r * 3 + 1) * WIN_NL] = in ? f.w[r].b : f.w[r].c;
+        win[(r * 3 + 2) * WIN_NL] = in ? f.w[r].c : 0u;
+    }
+    worg = (uint32_t)f.u_i | ((uint32_t)f.v_i << 16);
+}
+
 // ComputeResiduals for one patch (reference :252-296). Returns visibility; produces chi2 and
 // b = sum_px J*res (as A*gx + B*gy) of this patch.
-template <typename GT>
+template <typename GT, int WIN_NL = 0>
 __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const LevelGeom& lg, double scale, double fs,
                                                const uint8_t* __restrict__ cur_base, const PatchRegs<GT>& P,
                                                const double* __restrict__ sR, const double* __restrict__ st,
-                                               double& chi2, double* b) {
+                                               double& chi2, double* b, LdsU32* win = nullptr, uint32_t* worg = nullptr) {
     chi2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = 0.0;
     if (!P.valid) return false;
-    // :254 tT_c2r * X, divided through by z > 0 (the projection below is scale invariant):
-    // (R X + t)/z = R (x/z, y/z, 1) + t/z   (R, t are LDS broadcasts)
-    const double pxc = sR[0] * P.X[0] + sR[1] * P.X[1] + sR[2] + st[0] * P.X[2];
-    const double pyc = sR[3] * P.X[0] + sR[4] * P.X[1] + sR[5] + st[1] * P.X[2];
-    const double pzc = sR[6] * P.X[0] + sR[7] * P.X[1] + sR[8] + st[2] * P.X[2];
-    // Camera2Pixel (src/Camera.cpp:167-171), * tScale (:255)
-    // one reciprocal for both coordinates (the reference divides twice; <= 1 ulp on u,v)
-    const double izc = 1.0 / pzc;
-    const double u = ((double)a.fx * pxc * izc + (double)a.cx) * scale;
-    const double v = ((double)a.fy * pyc * izc + (double)a.cy) * scale;
-    // :262 with mnboarder = 3 on floored ints: floor(u) >= 3 && floor(u)+3 < cols (NaN fails)
-    if (!(u >= 3.0 && u < (double)(lg.w - 3) && v >= 3.0 && v < (double)(lg.h - 3))) return false;
+    double u, v;
+    if (!project_patch(a, lg, scale, P.X, sR, st, u, v)) return false;
     const double fu_d = floor(u), fv_d = floor(v);
     const int u_i = (int)fu_d, v_i = (int)fv_d;
     const double su = u - fu_d, sv = v - fv_d;
@@ -440,19 +441,41 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
 
     const uint32_t* __restrict__ img32 = (const uint32_t*)cur_base;
     uint32_t wlo[5], whi[5];
-    U32x2 wr[5];
+    if constexpr (WIN_NL > 0) {
+        constexpr int T = (WIN_ROWS - 5) / 2, HR = (WIN_ROWS - 1) / 2;
+        int u0 = (int)(*worg & 0xffffu), v0 = (int)(*worg >> 16);
+        const bool covered = (unsigned)(u_i - u0 + 1) <= 4u && (unsigned)(v_i - v0 + T) <= (unsigned)(2 * T);
+        if (!covered) {
+            WinFill f;
+            window_issue(a, lg, cur_base, u_i, v_i, f);
+            window_commit<WIN_NL>(a, lg, f, win, *worg);
+            u0 = u_i; v0 = v_i;
+        }
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const uint32_t o = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 2);
-        const uint32_t dw = o >> 2;
-        wr[r] = gather_x2(img32 + dw);                      // one global_load_dwordx2
-    }
+        for (int r = 0; r < 5; ++r) {
+            const uint32_t rowb = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride;
+            const uint32_t o = rowb + (uint32_t)(u_i - 2);
+            const uint32_t c = (o >> 2) - ((rowb + (uint32_t)(u0 - 3)) >> 2);      // 0 or 1
+            const uint32_t plane = (uint32_t)(v_i - 2 + r - (v0 - HR)) * 3u + c;
+            const uint32_t lo = win[plane * WIN_NL], hi = win[(plane + 1u) * WIN_NL];
+            const uint32_t sh = (o & 3u) * 8u;
+            wlo[r] = __builtin_amdgcn_alignbit(hi, lo, sh);     // bytes 0..3 of the row
+            whi[r] = hi >> sh;                                  // byte 4 in bits 0..7
+        }
+    } else {
+        U32x2 wr[5];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const uint32_t o = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 2);
-        const uint32_t sh = (o & 3u) * 8u;
-        wlo[r] = __builtin_amdgcn_alignbit(wr[r].b, wr[r].a, sh);  // bytes 0..3 of the row
-        whi[r] = wr[r].b >> sh;                                     // byte 4 in bits 0..7
+        for (int r = 0; r < 5; ++r) {
+            const uint32_t o = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 2);
+            wr[r] = gather_x2(img32 + (o >> 2));                // one global_load_dwordx2
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const uint32_t o = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 2);
+            const uint32_t sh = (o & 3u) * 8u;
+            wlo[r] = __builtin_amdgcn_alignbit(wr[r].b, wr[r].a, sh);  // bytes 0..3 of the row
+            whi[r] = wr[r].b >> sh;                                     // byte 4 in bits 0..7
+        }
     }
     // two footprint rows in flight, ping-ponged by the (static) row parity so that no register
     // copies are needed between rows
@@ -792,15 +815,13 @@ template <int NPW, typename GT, int PPW, bool STAMPS = false>
 __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_align_reg_kernel(const SAKernelArgs a) {
     constexpr int NP = NPW * 4;            // one partial slot per 16-lane DPP row
     constexpr int WPP = NPW + 1;           // waves per pair
-    constexpr int FOOT_STRIDE = NPW * 64 * 4;   // dwords per footprint row: LDS-DMA dwordx3 puts lane l at +16*l bytes
-                                                // (measured on gfx950: 12 bytes written, 16-byte lane stride)
     // One struct so that the layout is ours: the small, hot structures sit at the lowest LDS addresses
     // (ds_read/ds_write immediate offsets reach 64 KB; behind a large array every access would need
     // extra address arithmetic — measured: +75 % on the solver's partial sums), the DMA buffer last.
     struct Smem {
         BlockState st[PPW];
         WavePartial part[PPW][NP];
-        uint32_t foot[PPW][SA_DMA_PREFETCH ? 7 * FOOT_STRIDE : 1];   // next level's reference footprints (LDS-DMA)
+        uint32_t win[PPW][SA_WINDOW ? WIN_ROWS * 3 * NPW * 64 : 1];  // current-image footprint windows (residual_patch)
     };
     __shared__ Smem sm;
 
@@ -917,8 +938,6 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     const int row = lane >> 4;
     const bool row_writer = (lane & 15) == 15;
     WavePartial& my_part = s_part[wave * 4 + row];
-    uint32_t* const foot_wave = &sm.foot[slot][SA_DMA_PREFETCH ? wave * 64 * 4 : 0];   // wave-uniform DMA base
-    const uint32_t* const foot_lane = &sm.foot[slot][SA_DMA_PREFETCH ? ltid * 4 : 0];
     while (true) {
         pair_wait_seq(s, ++seen);                                      // B0 of the slot's next pair
         const int pair = __builtin_amdgcn_readfirstlane(s.pair);
@@ -931,9 +950,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
         const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
         const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + ltid, ltid < nf);
-        const bool feat_ok = fraw.initial && !(fraw.w0 == 0.0 && fraw.w1 == 0.0 && fraw.w2 == 0.0);
-        if (SA_DMA_PREFETCH) prefetch_ref_rows(a, ref_base, fraw.px, fraw.py, feat_ok, a.max_level - 1, foot_wave, FOOT_STRIDE);
         unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
+        unsigned long long st_lvl[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pass cycles / pass count of levels 0..3
         FeatureRegs F;
         {
             const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
@@ -945,14 +963,11 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             const double scale = (double)(1.0f / (float)(1 << level));
             const double fs = (double)a.f * scale;
             PatchRegs<GT> P;
+            uint32_t worg = WIN_EMPTY;                                 // the level's window is filled by its first pass
             unsigned long long tp0 = 0;
             if (STAMPS) tp0 = __builtin_amdgcn_s_memtime();
-            if (SA_DMA_PREFETCH) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA rows have landed
-                precompute_patch<GT>(a, lg, level, ref_base, F, P, foot_lane, FOOT_STRIDE);
-            } else {
-                precompute_patch<GT>(a, lg, level, ref_base, F, P);
-            }
+            LdsU32* const win = (LdsU32*)&sm.win[slot][SA_WINDOW ? ltid : 0];
+            precompute_patch<GT>(a, lg, level, ref_base, F, P);
             if (STAMPS) {
                 pin_patch(P);   // make the stamp wait for the precompute results
                 st_pre += __builtin_amdgcn_s_memtime() - tp0;
@@ -981,7 +996,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 unsigned long long tq0 = 0, tq1 = 0;
                 if (STAMPS) tq0 = __builtin_amdgcn_s_memtime();
                 pin_patch(P);
-                const bool vis = residual_patch<GT>(a, lg, scale, fs, cur_base, P, s.R, s.tt, chi2, b);
+                const bool vis = residual_patch<GT, SA_WINDOW ? NPW * 64 : 0>(a, lg, scale, fs, cur_base, P, s.R, s.tt, chi2, b,
+                                                                              win, &worg);
                 const unsigned long long vmask = __ballot(vis);
                 // reduce to the 16-lane DPP rows only (4 steps instead of 6); the solver's lane-parallel
                 // summation folds the 4*NPW row partials
@@ -995,7 +1011,11 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
                     my_part.n_ref = n_ref_row;
                 }
-                if (STAMPS) { tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0; }
+                if (STAMPS) {
+                    tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0;
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) if (l == level) { st_lvl[l] += tq1 - tq0; st_lvl[4 + l] += 1; }
+                }
                 const bool h_changed = (vmask != cached_mask);        // wave-uniform, rare
                 if (h_changed) {
                     const PatchHess ph = patch_hess_factors<GT>(P, fs);
@@ -1010,12 +1030,6 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
                 unsigned long long tq2 = 0;
                 if (STAMPS) { tq2 = __builtin_amdgcn_s_memtime(); st_h += tq2 - tq1; }
-                if (SA_DMA_PREFETCH && it == 0 && level > a.min_level) {
-                    // Next level's footprints: issued after this level's first pass has consumed its own
-                    // loads (vector-memory results return in order, so an earlier issue would stall that
-                    // pass behind these cold misses); they land under the solves of this level.
-                    prefetch_ref_rows(a, ref_base, F.px, F.py, F.ok, level - 1, foot_wave, FOOT_STRIDE);
-                }
                 ++seen;
                 pair_signal_arrive(&s.arrive, lane);                   // B1
                 pair_wait_seq(s, seen);                                // B2
@@ -1025,8 +1039,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         }
         pair_signal_arrive(&s.ack, lane);                              // done with this pair's shared state
         if (STAMPS && ltid == 0 && a.workspace) {
-            unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 4;
+            unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 12;
             o[0] = st_pre; o[1] = st_pass; o[2] = st_h; o[3] = st_bar;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) o[4 + l] = st_lvl[l];
         }
     }
 }

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0); ctx = capi.Context(0)
 cam = synth.Camera.tum(640, 480); cs = capi.camera_struct(cam); prm = capi.AlignParams(4, 0, 10, 15)
 st = torch.cuda.Stream(device=dev)
 d = bench.build_batch(torch, dev, ctx, cam, a.pairs, 640, 480, 4, 300, seed=0xD5D7, stream=st)
-stamps = torch.zeros((a.pairs * 12,), dtype=torch.int64, device=dev)
+stamps = torch.zeros((a.pairs * 20,), dtype=torch.int64, device=dev)
 f = ctx.lib.dsdtm_debug_sparse_align_stamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.POINTER(capi.BatchDesc), C.POINTER(capi.Camera), C.POINTER(capi.AlignParams), C.c_void_p, C.c_void_p]
 for rep in range(3):
@@ -20,10 +20,54 @@ for rep in range(3):
     ctx.check(f(ctx.handle, C.byref(d["desc"]), C.byref(cs), C.byref(prm), stamps.data_ptr(), st.cuda_stream)); st.synchronize()
 allst = stamps.cpu().numpy().astype(np.float64)
 s = allst[:a.pairs*8].reshape(a.pairs, 8)
-w = allst[a.pairs*8:].reshape(a.pairs, 4)
+w = allst[a.pairs*8:].reshape(a.pairs, 12)
 n_it = s[:, 3]
 print("pairs", a.pairs, "iterations/pair mean", n_it.mean())
 print("cycles per block: total %.0f | first-pass waits (4 levels) %.0f | later-pass waits %.0f | solve %.0f" % (s[:,4].mean(), s[:,0].mean(), s[:,1].mean(), s[:,2].mean()))
 print("per first pass %.0f | per later pass %.0f | per solve %.0f cycles" % ((s[:,0]/4).mean(), (s[:,1]/np.maximum(n_it-4,1)).mean(), (s[:,2]/n_it).mean()))
 print("solve sub-phases per solve: sums+LDS %.0f | factor/apply %.0f | exp+compose+publish %.0f" % ((s[:,5]/n_it).mean(), (s[:,6]/n_it).mean(), (s[:,7]/n_it).mean()))
 print("wave0: precompute %.0f (per level %.0f) | passes %.0f (per pass %.0f) | H-block+store %.0f | barriers(wait for solver) %.0f" % (w[:,0].mean(), (w[:,0]/4).mean(), w[:,1].mean(), (w[:,1]/n_it).mean(), w[:,2].mean(), w[:,3].mean()))
+print("wave0 pass cycles by level 0..3: " + " | ".join("%.0f (%.1f passes)" % ((w[:,4+l]/np.maximum(w[:,8+l],1)).mean(), w[:,8+l].mean()) for l in range(4)))
+# pair-duration spread and what it costs a 2-pairs-per-slot launch (list scheduling on 512 slots)
+dur = s[:, 4]
+print("pair cycles: mean %.0f | p5 %.0f | p50 %.0f | p95 %.0f | max %.0f" % (dur.mean(), *np.percentile(dur, [5, 50, 95]), dur.max()))
+def makespan(order, slots=512):
+    import heapq
+    h = [0.0] * slots
+    for i in order:
+        t = heapq.heappop(h); heapq.heappush(h, t + dur[i])
+    return max(h)
+n = len(dur)
+print("list-scheduling makespan / (2*mean): batch order %.3f | longest first %.3f | ideal 1.000" % (
+    makespan(range(n)) / (n / 512 * dur.mean()), makespan(np.argsort(-dur)) / (n / 512 * dur.mean())))
+# level-granular scheduling model: unit (pair, level) ~ c0 + c1*iters[level], units of a pair in sequence,
+# any slot may continue any pair (the carried state is the 7-double pose)
+stats = np.frombuffer(d["stats"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
+it = stats["iters"][:, :4].astype(np.float64)
+A = np.stack([np.full(n, 4.0), it.sum(axis=1)], axis=1)
+c0, c1 = np.linalg.lstsq(A, dur, rcond=None)[0]
+print("fit: pair cycles ~ 4*%.0f + %.0f*iterations (residual rms %.0f)" % (c0, c1, np.sqrt(np.mean((A @ [c0, c1] - dur) ** 2))))
+def makespan_levels(slots=512):
+    import heapq
+    from collections import deque
+    ready = deque((i, 3) for i in range(n))          # FIFO of ready units
+    free = [(0.0, k) for k in range(slots)]            # (time the slot is free, slot)
+    heapq.heapify(free)
+    pending = []                                       # (finish time, pair, level) of running units
+    t_end = 0.0
+    while ready or pending:
+        if ready and free and (not pending or free[0][0] <= pending[0][0]):
+            t, k = heapq.heappop(free)
+            i, l = ready.popleft()
+            f = t + c0 + c1 * it[i, l]
+            heapq.heappush(pending, (f, i, l, k))
+        else:
+            f, i, l, k = heapq.heappop(pending)
+            t_end = max(t_end, f)
+            heapq.heappush(free, (f, k))
+            if l > 0: ready.append((i, l - 1))
+            # a slot that is free earlier than f must not start the new unit before f
+            free = [(max(tt, f) if not ready else tt, kk) for tt, kk in free]; heapq.heapify(free)
+    return t_end
+print("model makespan / ideal: whole pairs %.3f | level-granular FIFO %.3f" % (
+    makespan(range(n)) / (n / 512 * dur.mean()), makespan_levels() / (n / 512 * dur.mean())))
