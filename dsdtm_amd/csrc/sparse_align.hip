@@ -60,12 +60,22 @@ struct WavePartial {
 };
 static_assert(offsetof(WavePartial, chi2) == 48 && offsetof(WavePartial, H) == 72, "solver_step indexes WavePartial as doubles");
 
-struct BlockState {
-    // solver-private state
+// Pose block of a pair: what solver_init computes. BlockState holds the live one (`u`) and a staged
+// one (`nx`) that the solver prepares for its slot's next pair while the current one is running.
+struct UnitPose {
     double q[4], t[3];          // T_c2r
+    double qr[4], tr[3];        // T_ref_w
+    double Cref[3];             // reference camera centre in world (Frame::mOw)          | published to the
+    double R[9], tt[3];         // rotation matrix + translation of T_c2r for the pass    | patch waves
+};
+constexpr int UNIT_POSE_DOUBLES = sizeof(UnitPose) / sizeof(double);
+static_assert(UNIT_POSE_DOUBLES == 29, "commit_next copies UnitPose lane-parallel");
+
+struct BlockState {
+    UnitPose u;                 // live: q/t/qr/tr solver-private, Cref/R/tt read by the patch waves
+    // solver-private state
     double qo[4], to[3];        // T_c2r before the last accepted step (tT_c2rOld)
     double chi2;
-    double qr[4], tr[3];        // T_ref_w
     double Hsum[21];            // sum of the per-row H partials of the last change of the visible set
     double Fm[21], Fdinv[6];    // LDLT factors of Hsum (ldlt6_factor): used directly by the first solve after a
     int Ftr[5];                 // (re)factorisation ...
@@ -74,9 +84,9 @@ struct BlockState {
                                 // unit vectors, Eigen's pivoted LDLT with pseudo-inverse of D), formed once per
                                 // change of the visible set; every iteration then only needs x = H^+ b
     double bsum[7];             // b totals + chi2 total of the current iteration
+    UnitPose nx;                // staged pose block of pair nx_pair (prepare_next)
+    int nx_pair;                // -1: nothing staged
     // published to the patch waves
-    double R[9], tt[3];         // rotation matrix + translation of T_c2r for the residual pass
-    double Cref[3];             // reference camera centre in world (Frame::mOw)
     int ctrl;                   // 0 continue, 1 level finished
     int n_vis;
     // pair-local synchronisation (used when several pairs share a workgroup): monotonic counters
@@ -524,35 +534,97 @@ __device__ __forceinline__ void stats_clear(const SAKernelArgs& a, int pair) {
     }
 }
 
-// Solver wave, prologue: mT_c2r = cur.pose * ref.pose^-1 (:43); C_ref = (T_ref_w^-1).translation
+typedef __attribute__((address_space(3))) BlockState LdsBlockState;   // ds_read/ds_write instead of flat accesses
+
+// Solver wave, pair prologue: mT_c2r = cur.pose * ref.pose^-1 (:43); C_ref = (T_ref_w^-1).translation
 // (Frame::Set_Pose, src/Frame.cpp:167-174).
-__device__ __forceinline__ void solver_init(const SAKernelArgs& a, int pair, BlockState& s, int lane) {
-    const SE3d Tc = se3_from_rt(a.T_cur_w + 12 * (size_t)pair);
-    const SE3d Tr = se3_from_rt(a.T_ref_w + 12 * (size_t)pair);
+// The pose block of a pair from its inputs, into `dst` (LDS). Its callers are out of line, data in
+// and out through memory only (like factor_to_lds): they run once per pair and their SE(3)
+// temporaries stay out of the register allocation of the per-iteration solver loop.
+typedef __attribute__((address_space(3))) UnitPose LdsUnitPose;
+__device__ __forceinline__ void unit_pose_compute(const double* T_ref_w_pair, const double* T_cur_w_pair,
+                                                  LdsUnitPose* dst, int lane) {
+    const SE3d Tr = se3_from_rt(T_ref_w_pair);
     const SE3d Tri = se3_inverse(Tr);
+    const SE3d Tc = se3_from_rt(T_cur_w_pair);
     const SE3d T = se3_mul(Tc, Tri);
     double R[9];
     quat_to_matrix(T, R);
     if (lane == 0) {
-        store_se3(s.q, s.t, T);
-        store_se3(s.qo, s.to, T);
-        store_se3(s.qr, s.tr, Tr);
-        s.Cref[0] = Tri.tx; s.Cref[1] = Tri.ty; s.Cref[2] = Tri.tz;
+        LdsUnitPose& u = *dst;
+        u.q[0] = T.qw; u.q[1] = T.qx; u.q[2] = T.qy; u.q[3] = T.qz; u.t[0] = T.tx; u.t[1] = T.ty; u.t[2] = T.tz;
+        u.qr[0] = Tr.qw; u.qr[1] = Tr.qx; u.qr[2] = Tr.qy; u.qr[3] = Tr.qz; u.tr[0] = Tr.tx; u.tr[1] = Tr.ty; u.tr[2] = Tr.tz;
+        u.Cref[0] = Tri.tx; u.Cref[1] = Tri.ty; u.Cref[2] = Tri.tz;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) s.R[i] = R[i];
-        s.tt[0] = T.tx; s.tt[1] = T.ty; s.tt[2] = T.tz;
-        s.chi2 = 0.0;
-        s.n_vis = 0;
-        s.ctrl = 0;
-        stats_clear(a, pair);
+        for (int i = 0; i < 9; ++i) u.R[i] = R[i];
+        u.tt[0] = T.tx; u.tt[1] = T.ty; u.tt[2] = T.tz;
     }
+}
+
+// the solver-private rest of a pair start; `u` is in place
+__device__ __forceinline__ void unit_state_reset(LdsBlockState& s, int lane) {
+    if (lane < 7) {
+        const double v = lane < 4 ? s.u.q[lane] : s.u.t[lane - 4];    // tT_c2rOld = T_c2r
+        if (lane < 4) s.qo[lane] = v; else s.to[lane - 4] = v;
+    }
+    if (lane == 0) { s.chi2 = 0.0; s.n_vis = 0; s.ctrl = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Pair prologue on the spot (nothing was staged): the slow path, ~10 k cycles of HBM latency + SE(3) math
+__device__ __attribute__((noinline)) void solver_init(const double* T_ref_w_pair, const double* T_cur_w_pair,
+                                                      LdsBlockState* sp, int lane) {
+    unit_pose_compute(T_ref_w_pair, T_cur_w_pair, (LdsUnitPose*)&sp->u, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    unit_state_reset(*sp, lane);
+}
+
+// Pair prologue ahead of time: called by the solver wave for its slot's NEXT pair in the idle window
+// of an iteration of the current one, i.e. while the patch waves run a pass. Stages the pose block
+// in s.nx and pulls the pair's feature columns towards this CU (LDS-DMA into a sink: no destination
+// registers, nothing waits for them), so that the pair later starts on a 29-double LDS copy and cache
+// hits instead of dependent HBM round trips (~15 k cycles per pair start otherwise).
+typedef __attribute__((address_space(3))) void LdsVoid;
+__device__ __forceinline__ void touch_range(const void* base, size_t bytes, int lane, LdsVoid* sink) {
+    const char* p = (const char*)base;
+    for (size_t off = (size_t)lane * 64; off < bytes; off += 64 * 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + off), sink, 4, 0, 0);
+}
+__device__ __attribute__((noinline)) void prepare_next(const double* T_ref_w_pair, const double* T_cur_w_pair,
+                                                       const float* px, const double* be, const double* pw, const uint8_t* ini,
+                                                       int nfm, int pair, LdsBlockState* sp, LdsVoid* sink, int lane) {
+    touch_range(px, 8 * (size_t)nfm, lane, sink);
+    touch_range(be, 24 * (size_t)nfm, lane, sink);
+    touch_range(pw, 24 * (size_t)nfm, lane, sink);
+    touch_range(ini, (size_t)nfm, lane, sink);
+    unit_pose_compute(T_ref_w_pair, T_cur_w_pair, (LdsUnitPose*)&sp->nx, lane);
+    if (lane == 0) sp->nx_pair = pair;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// staged pose block -> live one (lane-parallel LDS copy)
+__device__ __forceinline__ void commit_next(LdsBlockState& s, int lane) {
+    if (lane < UNIT_POSE_DOUBLES) {
+        const __attribute__((address_space(3))) double* src = (const __attribute__((address_space(3))) double*)&s.nx;
+        __attribute__((address_space(3))) double* dst = (__attribute__((address_space(3))) double*)&s.u;
+        dst[lane] = src[lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    unit_state_reset(s, lane);
 }
 
 // Factorise BlockState::Hsum and park the factors in BlockState (LDS). Deliberately NOT inlined:
 // it runs only when the visible set changed (about once per pyramid level), and keeping its ~60
 // live registers out of solver_step's allocation keeps the whole kernel inside the 168-VGPR budget
 // of a 12-wave workgroup without spills on the per-iteration path.
-typedef __attribute__((address_space(3))) BlockState LdsBlockState;   // ds_read/ds_write instead of flat accesses
 __device__ __attribute__((noinline)) void factor_to_lds(LdsBlockState* sp, int lane) {
     LdsBlockState& s = *sp;
     double H[21], Fm[21], Fdinv[6];
@@ -628,6 +700,7 @@ __device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, Bloc
 template <int NP>   // NP = number of partial slots (rows or waves)
 __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int level, int it,
                                            const WavePartial* s_part, BlockState& s, int lane, bool& hinv_valid,
+                                           const double* hrow /* lane i < 6: row i of H^+ while hinv_valid */,
                                            unsigned long long* tacc = nullptr /* diagnostic build only */) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     if (tacc) ts0 = __builtin_amdgcn_s_memtime();
@@ -695,13 +768,15 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     __builtin_amdgcn_sched_barrier(0);   // keep the solver's sub-steps in order: short live ranges, no spills
     double x[6];
     if (hinv_valid) {
+        // lane i < 6 holds row i of H^+ (hrow, loaded by the caller when H^+ was formed) and computes
+        // x_i; readlane broadcasts the six results
+        double xr = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) x[i] = 0.0;
+        for (int j = 0; j < 6; ++j) xr += hrow[j] * bs[j];
+        const int lo = __double2loint(xr), hi = __double2hiint(xr);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) x[i] += s.Hinv[j * 6 + i] * bs[j];
-        }
+        for (int i = 0; i < 6; ++i)
+            x[i] = __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
     } else {
         double Fm[21], Fdinv[6];
 #pragma unroll
@@ -720,17 +795,17 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
         double Rn[9];
         quat_to_matrix(To, Rn);
         if (lane == 0) {
-            store_se3(s.q, s.t, To);
+            store_se3(s.u.q, s.u.t, To);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) s.R[i] = Rn[i];
-            s.tt[0] = To.tx; s.tt[1] = To.ty; s.tt[2] = To.tz;
+            for (int i = 0; i < 9; ++i) s.u.R[i] = Rn[i];
+            s.u.tt[0] = To.tx; s.u.tt[1] = To.ty; s.u.tt[2] = To.tz;
         }
         ctrl = 1;
         exit_code = stop ? 3 : 1;
     } else {
         const SE3d dT = se3_exp(x);
         __builtin_amdgcn_sched_barrier(0);
-        const SE3d Tcur = load_se3(s.q, s.t);
+        const SE3d Tcur = load_se3(s.u.q, s.u.t);
         const SE3d Tn = se3_mul(Tcur, dT);                 // :335 right-multiply
         __builtin_amdgcn_sched_barrier(0);
         double Rn[9];
@@ -740,10 +815,10 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
         for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(x[i]));
         if (lane == 0) {
             store_se3(s.qo, s.to, Tcur);
-            store_se3(s.q, s.t, Tn);
+            store_se3(s.u.q, s.u.t, Tn);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) s.R[i] = Rn[i];
-            s.tt[0] = Tn.tx; s.tt[1] = Tn.ty; s.tt[2] = Tn.tz;
+            for (int i = 0; i < 9; ++i) s.u.R[i] = Rn[i];
+            s.u.tt[0] = Tn.tx; s.u.tt[1] = Tn.ty; s.u.tt[2] = Tn.tz;
             s.chi2 = chi2New;
         }
         if (mx <= 1e-8) { ctrl = 1; exit_code = 2; }        // :341
@@ -766,26 +841,28 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
 }
 
 // Solver wave, epilogue: tCurFrame->Set_Pose(mT_c2r * tRefFrame->Get_Pose()) (:57), return mnPts (:59)
-__device__ __forceinline__ void solver_finish(const SAKernelArgs& a, int pair, BlockState& s, int lane) {
-    const SE3d T = load_se3(s.q, s.t);
-    const SE3d Tr = load_se3(s.qr, s.tr);
+__device__ __attribute__((noinline)) void solver_finish(double* T_cur_w_pair, int32_t* n_tracked_pair, LdsBlockState* sp, int lane) {
+    LdsBlockState& s = *sp;
+    SE3d T, Tr;
+    T.qw = s.u.q[0]; T.qx = s.u.q[1]; T.qy = s.u.q[2]; T.qz = s.u.q[3]; T.tx = s.u.t[0]; T.ty = s.u.t[1]; T.tz = s.u.t[2];
+    Tr.qw = s.u.qr[0]; Tr.qx = s.u.qr[1]; Tr.qy = s.u.qr[2]; Tr.qz = s.u.qr[3]; Tr.tx = s.u.tr[0]; Tr.ty = s.u.tr[1]; Tr.tz = s.u.tr[2];
     const SE3d To = se3_mul(T, Tr);
     double R[9];
     quat_to_matrix(To, R);
     if (lane == 0) {
-        double* out = a.T_cur_w + 12 * (size_t)pair;
+        double* out = T_cur_w_pair;
         out[0] = R[0]; out[1] = R[1]; out[2] = R[2];  out[3] = To.tx;
         out[4] = R[3]; out[5] = R[4]; out[6] = R[5];  out[7] = To.ty;
         out[8] = R[6]; out[9] = R[7]; out[10] = R[8]; out[11] = To.tz;
-        a.n_tracked[pair] = s.n_vis;
+        *n_tracked_pair = s.n_vis;
     }
 }
 
 // Hand-over protocol of the register kernel (pair-local counters, see pair_signal_arrive & co.):
 //   per pair:      ACK      all patch waves are done with the previous pair's state -> ack += NPW (the solver
 //                                                                     may rewrite pair/run/ctrl/R for the next pair)
-//                  B0       pair index published, solver_init done -> seq += 1 (patch waves may read pair/Cref/R/t)
-//   per level:     BH       all-visible H partials are in LDS      -> arrive += NPW (solver sums + factorises
+//                  B0       pair index published, pose block live  -> seq += 1 (patch waves may read pair/Cref/R/t)
+//   per level:     BH       all-visible H partials are in LDS      -> arrive_h += NPW (solver sums + factorises
 //                                                                     them while the first pass runs)
 //   per iteration: B1       partials of all patch waves are in LDS -> arrive += NPW (solver may read them)
 //                  B2       solver has published R/t/ctrl           -> seq += 1 (patch waves may read them)
@@ -822,6 +899,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         BlockState st[PPW];
         WavePartial part[PPW][NP];
         uint32_t win[PPW][SA_WINDOW ? WIN_ROWS * 3 * NPW * 64 : 1];  // current-image footprint windows (residual_patch)
+        uint32_t sink[PPW][64];                                      // LDS-DMA target of prepare_next's cache warm-up (never read)
     };
     __shared__ Smem sm;
 
@@ -834,7 +912,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     {
         // LDS is uninitialised at kernel start: zero the slot-local counters and run the one real
         // workgroup barrier of this kernel while every wave is still present
-        if (tid < PPW) { sm.st[tid].arrive = 0u; sm.st[tid].arrive_h = 0u; sm.st[tid].seq = 0u; sm.st[tid].ack = 0u; }
+        if (tid < PPW) { sm.st[tid].arrive = 0u; sm.st[tid].arrive_h = 0u; sm.st[tid].seq = 0u; sm.st[tid].ack = 0u; sm.st[tid].nx_pair = -1; }
         __syncthreads();
     }
     WavePartial* s_part = sm.part[slot];
@@ -845,6 +923,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
     // workgroup's other slot. A workgroup that held its CU until BOTH of its pairs finished lost
     // ~11 % to the spread of pair durations (10..25 Gauss-Newton iterations). The slot-local
     // counters are monotonic, so they simply keep counting from one pair to the next.
+    // (Finer work units — a pair cut at a pyramid level, the 7-double pose handed from CU to CU
+    // through a completion-ordered queue — were built and measured: the tail of a 1024-pair launch
+    // is bounded by the finest level, which cannot be cut, and the idle time at the end only fell
+    // from ~12 % to ~9.5 %, which the hand-over cost ate. Whole pairs stay the unit.)
     if (wave == NPW) {
         // ------------------------------ solver wave ------------------------------
         unsigned expected = 0, expected_h = 0;                         // B1 / BH arrivals consumed so far
@@ -853,13 +935,15 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         // with patch waves of the workgroup's other slot: give it issue priority.
         if (PPW > 1) __builtin_amdgcn_s_setprio(2);
         // the first pair of every slot is assigned statically (no atomic round trip on the start-up
-        // path); the counter hands out the pairs behind those
+        // path); the counter hands out the pairs behind those. claim_issue only starts the atomic, its
+        // value is waited for where claim_value reads it.
         const int first_dynamic = (int)gridDim.x * PPW;
-        auto fetch_pair = [&]() -> int {
+        auto claim_issue = [&]() -> int {
             int v = 0;
             if (lane == 0) v = first_dynamic + (int)atomicAdd(a.pair_counter, 1u);
-            return __builtin_amdgcn_readfirstlane(v);
+            return v;
         };
+        auto claim_value = [&](int raw) -> int { return __builtin_amdgcn_readfirstlane(raw); };
         int pair = (int)blockIdx.x * PPW + slot;
         unsigned acks = 0;                                             // acknowledgements expected so far
         while (true) {
@@ -869,28 +953,32 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             const int nf = have ? (a.n_features ? a.n_features[pair] : a.max_features) : 0;
             // Run(): "Too few features to track" (:34-38) -> return 0, pose untouched
             const bool run = have && nf >= a.min_fts && a.max_level - 1 >= a.min_level;
-            if (lane == 0) { s.pair = pair; s.run = run ? 1 : 0; }
+            const bool staged = have && __builtin_amdgcn_readfirstlane(s.nx_pair) == pair;
+            if (lane == 0) { s.pair = pair; s.run = run ? 1 : 0; s.nx_pair = -1; }
             if (!have) { pair_publish(s, ++published, lane); break; }  // B0 with "no more work"
             acks += NPW;
             if (!run) {
                 if (lane == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
                 pair_publish(s, ++published, lane);                    // B0 with "skip"
-                pair = fetch_pair();
+                pair = claim_value(claim_issue());
                 continue;
             }
-            const int next_pair = fetch_pair();                        // latency hidden under this pair
+            const int next_raw = claim_issue();                        // latency hidden under this pair
             unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0;
             unsigned long long t_sub[3] = {0, 0, 0};
             if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
-            solver_init(a, pair, s, lane);
+            if (staged) commit_next(*(LdsBlockState*)&s, lane);        // prepared while the previous pair was running
+            else solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
+            if (lane == 0) stats_clear(a, pair);
             pair_publish(s, ++published, lane);                        // B0
+            bool prepared = false;
             for (int level = a.max_level - 1; level >= a.min_level; --level) {
                 if (lane == 0) {                                       // GaussNewtonSolver entry (:304-308)
                     s.chi2 = 0.0;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) s.qo[i] = s.q[i];
+                    for (int i = 0; i < 4; ++i) s.qo[i] = s.u.q[i];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) s.to[i] = s.t[i];
+                    for (int i = 0; i < 3; ++i) s.to[i] = s.u.t[i];
                 }
                 // speculative: the patch waves publish the all-visible H partials right after the
                 // level's precompute; sum + factorise them here while they run the first pass
@@ -898,13 +986,14 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 pair_wait_arrive(&s.arrive_h, expected_h);             // BH
                 solver_refresh_H<NP>(s_part, s, lane);
                 bool hinv_valid = false;
+                double hrow[6] = {0, 0, 0, 0, 0, 0};
                 for (int it = 0; it < a.max_iters; ++it) {
                     unsigned long long t0 = 0, t1 = 0, t2 = 0;
                     if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
                     expected += NPW;
                     pair_wait_arrive(&s.arrive, expected);             // B1
                     if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
-                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hinv_valid, STAMPS ? t_sub : nullptr);
+                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hinv_valid, hrow, STAMPS ? t_sub : nullptr);
                     if (STAMPS) {
                         t2 = __builtin_amdgcn_s_memtime();
                         if (it == 0) t_first += t1 - t0; else t_wait += t1 - t0;
@@ -913,13 +1002,28 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     }
                     pair_publish(s, ++published, lane);                // B2
                     if (ctrl) break;
-                    if (!hinv_valid) {                                 // under the patch waves' next pass
+                    // the rest of this iteration's window (the patch waves are running their next pass)
+                    if (!hinv_valid) {
                         hinv_to_lds((LdsBlockState*)&s, lane);
                         hinv_valid = true;
+                        const int li = lane < 6 ? lane : 5;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) hrow[j] = s.Hinv[j * 6 + li];   // row li of H^+ (stored by columns)
+                    } else if (!prepared && level < a.max_level - 1) {
+                        // once per pair, not on its first level (the claim has long returned by now): the
+                        // next pair's prologue
+                        prepared = true;
+                        const int np = claim_value(next_raw);
+                        if (np < a.n_pairs) {
+                            const size_t nfm = (size_t)a.max_features;
+                            prepare_next(a.T_ref_w + 12 * (size_t)np, a.T_cur_w + 12 * (size_t)np, a.px_xy + 2 * np * nfm,
+                                         a.bearing + 3 * np * nfm, a.p_world + 3 * np * nfm, a.initial + np * nfm,
+                                         a.max_features, np, (LdsBlockState*)&s, (LdsVoid*)sm.sink[slot], lane);
+                        }
                     }
                 }
             }
-            solver_finish(a, pair, s, lane);
+            solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
             if (STAMPS && lane == 0 && a.workspace) {
                 unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 8;
                 o[0] = t_first; o[1] = t_wait; o[2] = t_solve; o[3] = n_it;
@@ -928,7 +1032,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 o[6] = t_sub[1];
                 o[7] = t_sub[2];
             }
-            pair = next_pair;
+            pair = claim_value(next_raw);
         }
         return;
     }
@@ -954,10 +1058,9 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         unsigned long long st_lvl[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pass cycles / pass count of levels 0..3
         FeatureRegs F;
         {
-            const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
+            const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
             F = make_feature(fraw, Cref);
         }
-
         for (int level = a.max_level - 1; level >= a.min_level; --level) {
             const LevelGeom lg = a.lv[level];
             const double scale = (double)(1.0f / (float)(1 << level));
@@ -996,7 +1099,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 unsigned long long tq0 = 0, tq1 = 0;
                 if (STAMPS) tq0 = __builtin_amdgcn_s_memtime();
                 pin_patch(P);
-                const bool vis = residual_patch<GT, SA_WINDOW ? NPW * 64 : 0>(a, lg, scale, fs, cur_base, P, s.R, s.tt, chi2, b,
+                const bool vis = residual_patch<GT, SA_WINDOW ? NPW * 64 : 0>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b,
                                                                               win, &worg);
                 const unsigned long long vmask = __ballot(vis);
                 // reduce to the 16-lane DPP rows only (4 steps instead of 6); the solver's lane-parallel
@@ -1107,25 +1210,26 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
     }
 
     if (wave == NPW) {
-        solver_init(a, pair, s, lane);
+        solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
+        if (lane == 0) stats_clear(a, pair);
         __syncthreads();                                               // B0
         for (int level = a.max_level - 1; level >= a.min_level; --level) {
             if (lane == 0) {
                 s.chi2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s.qo[i] = s.q[i];
+                for (int i = 0; i < 4; ++i) s.qo[i] = s.u.q[i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) s.to[i] = s.t[i];
+                for (int i = 0; i < 3; ++i) s.to[i] = s.u.t[i];
             }
             for (int it = 0; it < a.max_iters; ++it) {
                 __syncthreads();                                       // B1
                 bool hinv_valid = false;                               // this kernel refactorises every iteration
-                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hinv_valid);
+                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hinv_valid, nullptr);
                 __syncthreads();                                       // B2
                 if (ctrl) break;
             }
         }
-        solver_finish(a, pair, s, lane);
+        solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
         return;
     }
 
@@ -1141,7 +1245,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
         const double fs = (double)a.f * scale;
         int n_valid_lane = 0;
         {
-            const double Cref[3] = {s.Cref[0], s.Cref[1], s.Cref[2]};
+            const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
             for (int p = tid; p < (int)npad; p += PT) {
                 PatchRegs<double> P;
                 const FeatureRegs F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + p, p < nf), Cref);
@@ -1163,7 +1267,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
                 PatchRegs<double> P;
                 ws_load(ws, npad, p, P);
                 double c2, bp[6];
-                const bool vis = residual_patch<double>(a, lg, scale, fs, cur_base, P, s.R, s.tt, c2, bp);
+                const bool vis = residual_patch<double>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp);
                 if (vis) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) b[i] += bp[i];

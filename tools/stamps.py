@@ -16,7 +16,7 @@ stamps = torch.zeros((a.pairs * 20,), dtype=torch.int64, device=dev)
 f = ctx.lib.dsdtm_debug_sparse_align_stamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.POINTER(capi.BatchDesc), C.POINTER(capi.Camera), C.POINTER(capi.AlignParams), C.c_void_p, C.c_void_p]
 for rep in range(3):
-    d["T_cur_w"].copy_(d["T_seed"]); torch.cuda.synchronize()
+    d["T_cur_w"].copy_(d["T_seed"]); stamps.zero_(); torch.cuda.synchronize()
     ctx.check(f(ctx.handle, C.byref(d["desc"]), C.byref(cs), C.byref(prm), stamps.data_ptr(), st.cuda_stream)); st.synchronize()
 allst = stamps.cpu().numpy().astype(np.float64)
 s = allst[:a.pairs*8].reshape(a.pairs, 8)
