@@ -77,12 +77,9 @@ struct BlockState {
     double qo[4], to[3];        // T_c2r before the last accepted step (tT_c2rOld)
     double chi2;
     double Hsum[21];            // sum of the per-row H partials of the last change of the visible set
-    double Fm[21], Fdinv[6];    // LDLT factors of Hsum (ldlt6_factor): used directly by the first solve after a
-    int Ftr[5];                 // (re)factorisation ...
-    unsigned Fmask;
-    double Hinv[36];            // ... and turned into H^+ = P^T L^-T D^+ L^-1 P column by column (ldlt6_factor + ldlt6_apply on the
-                                // unit vectors, Eigen's pivoted LDLT with pseudo-inverse of D), formed once per
-                                // change of the visible set; every iteration then only needs x = H^+ b
+    double Hinv[36];            // H^+ = P^T L^-T D^+ L^-1 P by columns (ldlt6_factor + ldlt6_apply on the unit vectors:
+                                // Eigen's pivoted LDLT with pseudo-inverse of D), formed once per change of the
+                                // visible set; every iteration then only needs x = H^+ b
     double bsum[7];             // b totals + chi2 total of the current iteration
     UnitPose nx;                // staged pose block of pair nx_pair (prepare_next)
     int nx_pair;                // -1: nothing staged
@@ -539,7 +536,7 @@ typedef __attribute__((address_space(3))) BlockState LdsBlockState;   // ds_read
 // Solver wave, pair prologue: mT_c2r = cur.pose * ref.pose^-1 (:43); C_ref = (T_ref_w^-1).translation
 // (Frame::Set_Pose, src/Frame.cpp:167-174).
 // The pose block of a pair from its inputs, into `dst` (LDS). Its callers are out of line, data in
-// and out through memory only (like factor_to_lds): they run once per pair and their SE(3)
+// and out through memory only (like factor_hinv_to_lds): they run once per pair and their SE(3)
 // temporaries stay out of the register allocation of the per-iteration solver loop.
 typedef __attribute__((address_space(3))) UnitPose LdsUnitPose;
 __device__ __forceinline__ void unit_pose_compute(const double* T_ref_w_pair, const double* T_cur_w_pair,
@@ -621,11 +618,14 @@ __device__ __forceinline__ void commit_next(LdsBlockState& s, int lane) {
     unit_state_reset(s, lane);
 }
 
-// Factorise BlockState::Hsum and park the factors in BlockState (LDS). Deliberately NOT inlined:
-// it runs only when the visible set changed (about once per pyramid level), and keeping its ~60
-// live registers out of solver_step's allocation keeps the whole kernel inside the 168-VGPR budget
-// of a 12-wave workgroup without spills on the per-iteration path.
-__device__ __attribute__((noinline)) void factor_to_lds(LdsBlockState* sp, int lane) {
+// Factorise BlockState::Hsum and form H^+ in BlockState (LDS). x = H^+ b = sum_j b_j * column_j is the
+// substitution H.ldlt().solve(b) the reference runs every iteration (:318) up to rounding (the solve
+// is linear in b), including the zeroed components of a rank-deficient system. The six columns are
+// the solves of the six unit vectors — one per lane, so all of H^+ costs ONE substitution.
+// Deliberately NOT inlined: it runs only when the visible set changed (about once per pyramid level),
+// and keeping its ~70 live registers out of solver_step's allocation keeps the whole kernel inside
+// the 168-VGPR budget of a 12-wave workgroup without spills on the per-iteration path.
+__device__ __attribute__((noinline)) void factor_hinv_to_lds(LdsBlockState* sp, int lane) {
     LdsBlockState& s = *sp;
     double H[21], Fm[21], Fdinv[6];
     int tr0, tr1, tr2, tr3, tr4;
@@ -633,54 +633,25 @@ __device__ __attribute__((noinline)) void factor_to_lds(LdsBlockState* sp, int l
 #pragma unroll
     for (int i = 0; i < 21; ++i) H[i] = s.Hsum[i];
     ldlt6_factor(H, Fm, Fdinv, tr0, tr1, tr2, tr3, tr4, dmask);
-    if (lane == 0) {
+    const int j = lane < 6 ? lane : 5;                    // lane j < 6: column j = solve(e_j)
+    double e[6], col[6];
 #pragma unroll
-        for (int i = 0; i < 21; ++i) s.Fm[i] = Fm[i];
+    for (int i = 0; i < 6; ++i) e[i] = (i == j) ? 1.0 : 0.0;
+    ldlt6_apply(Fm, Fdinv, tr0, tr1, tr2, tr3, tr4, dmask, e, col);
+    if (lane < 6) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s.Fdinv[i] = Fdinv[i];
-        s.Ftr[0] = tr0; s.Ftr[1] = tr1; s.Ftr[2] = tr2; s.Ftr[3] = tr3; s.Ftr[4] = tr4;
-        s.Fmask = dmask;
+        for (int i = 0; i < 6; ++i) s.Hinv[j * 6 + i] = col[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// H^+ column j = solve(e_j): the same substitution the reference runs on b every iteration (:318),
-// done six times — after the first solve of the factorisation has been published, i.e. while the
-// patch waves run their next pass — so that the remaining iterations only need the matrix-vector
-// product. x = sum_j b_j * column_j is that substitution up to rounding (it is linear in b),
-// including the zeroed components of a rank-deficient system.
-__device__ __attribute__((noinline)) void hinv_to_lds(LdsBlockState* sp, int lane) {
-    LdsBlockState& s = *sp;
-    double Fm[21], Fdinv[6];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) Fm[i] = s.Fm[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Fdinv[i] = s.Fdinv[i];
-    const int tr0 = s.Ftr[0], tr1 = s.Ftr[1], tr2 = s.Ftr[2], tr3 = s.Ftr[3], tr4 = s.Ftr[4];
-    const unsigned dmask = s.Fmask;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double e[6], col[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) e[i] = (i == j) ? 1.0 : 0.0;
-        ldlt6_apply(Fm, Fdinv, tr0, tr1, tr2, tr3, tr4, dmask, e, col);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) s.Hinv[j * 6 + i] = col[i];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// Sum the per-row H partials (lane q < 21 sums entry q over the NP slots in fixed order) and
-// factorise the total. Called once per level on the all-visible H — speculatively, while the patch
+// Sum the per-row H partials (lane q < 21 sums entry q over the NP slots in fixed order), factorise
+// the total and form H^+. Called once per level on the all-visible H — speculatively, while the patch
 // waves run the level's first pass — and again only if a row later reports a different visible set.
 template <int NP>
-__device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, BlockState& s, int lane) {
+__device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, BlockState& s, int lane, double* hrow) {
     constexpr int WP = sizeof(WavePartial) / sizeof(double);
     const double* base = (const double*)s_part;
     if (lane < 21) {
@@ -692,15 +663,18 @@ __device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, Bloc
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    factor_to_lds((LdsBlockState*)&s, lane);              // out-of-line; parks the factors in LDS
+    factor_hinv_to_lds((LdsBlockState*)&s, lane);         // out-of-line; parks H^+ in LDS
+    const int li = lane < 6 ? lane : 5;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hrow[j] = s.Hinv[j * 6 + li];   // lane i < 6 keeps row i of H^+ (stored by columns)
 }
 
 // Solver wave, one Gauss-Newton iteration (reference :310-343). Executed uniformly by all 64
 // lanes of the solver wave (same cost as one lane); lane 0 publishes. Returns ctrl.
 template <int NP>   // NP = number of partial slots (rows or waves)
 __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int level, int it,
-                                           const WavePartial* s_part, BlockState& s, int lane, bool& hinv_valid,
-                                           const double* hrow /* lane i < 6: row i of H^+ while hinv_valid */,
+                                           const WavePartial* s_part, BlockState& s, int lane,
+                                           double* hrow /* lane i < 6: row i of H^+ */,
                                            unsigned long long* tacc = nullptr /* diagnostic build only */) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     if (tacc) ts0 = __builtin_amdgcn_s_memtime();
@@ -720,10 +694,7 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     const int cnt = packed & 0xffff;
     const int n_ref = (packed >> 16) & 0xffff;
     const int changed = __ballot(chg) != 0ull;
-    if (changed) {                                        // rare: a row's visible set differs from the cached one
-        solver_refresh_H<NP>(s_part, s, lane);
-        hinv_valid = false;
-    }
+    if (changed) solver_refresh_H<NP>(s_part, s, lane, hrow);   // rare: a row's visible set differs from the cached one
     double bs[6], chi2s;
     {
         constexpr int WP = sizeof(WavePartial) / sizeof(double);
@@ -762,14 +733,11 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     }
     if (tacc) { asm volatile("" : "+v"(bs[0])); ts1 = __builtin_amdgcn_s_memtime(); }
     const double chi2New = chi2s / (double)(16 * cnt);     // :298 (0/0 -> NaN)
-    // H.ldlt().solve(JRes) (:318): the substitution on the cached factors for the first solve after
-    // a (re)factorisation, x = H^+ b afterwards (H^+ is formed right after that first solve is
-    // published, see the caller)
+    // H.ldlt().solve(JRes) (:318) as x = H^+ b: lane i < 6 holds row i of H^+ and computes x_i;
+    // readlane broadcasts the six results
     __builtin_amdgcn_sched_barrier(0);   // keep the solver's sub-steps in order: short live ranges, no spills
     double x[6];
-    if (hinv_valid) {
-        // lane i < 6 holds row i of H^+ (hrow, loaded by the caller when H^+ was formed) and computes
-        // x_i; readlane broadcasts the six results
+    {
         double xr = 0.0;
 #pragma unroll
         for (int j = 0; j < 6; ++j) xr += hrow[j] * bs[j];
@@ -777,13 +745,6 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             x[i] = __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
-    } else {
-        double Fm[21], Fdinv[6];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) Fm[i] = s.Fm[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Fdinv[i] = s.Fdinv[i];
-        ldlt6_apply(Fm, Fdinv, s.Ftr[0], s.Ftr[1], s.Ftr[2], s.Ftr[3], s.Ftr[4], s.Fmask, bs, x);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (tacc) { asm volatile("" : "+v"(x[0])); ts2 = __builtin_amdgcn_s_memtime(); }
@@ -984,16 +945,15 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 // level's precompute; sum + factorise them here while they run the first pass
                 expected_h += NPW;
                 pair_wait_arrive(&s.arrive_h, expected_h);             // BH
-                solver_refresh_H<NP>(s_part, s, lane);
-                bool hinv_valid = false;
-                double hrow[6] = {0, 0, 0, 0, 0, 0};
+                double hrow[6];
+                solver_refresh_H<NP>(s_part, s, lane, hrow);
                 for (int it = 0; it < a.max_iters; ++it) {
                     unsigned long long t0 = 0, t1 = 0, t2 = 0;
                     if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
                     expected += NPW;
                     pair_wait_arrive(&s.arrive, expected);             // B1
                     if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
-                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hinv_valid, hrow, STAMPS ? t_sub : nullptr);
+                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hrow, STAMPS ? t_sub : nullptr);
                     if (STAMPS) {
                         t2 = __builtin_amdgcn_s_memtime();
                         if (it == 0) t_first += t1 - t0; else t_wait += t1 - t0;
@@ -1003,13 +963,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     pair_publish(s, ++published, lane);                // B2
                     if (ctrl) break;
                     // the rest of this iteration's window (the patch waves are running their next pass)
-                    if (!hinv_valid) {
-                        hinv_to_lds((LdsBlockState*)&s, lane);
-                        hinv_valid = true;
-                        const int li = lane < 6 ? lane : 5;
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) hrow[j] = s.Hinv[j * 6 + li];   // row li of H^+ (stored by columns)
-                    } else if (!prepared && level < a.max_level - 1) {
+                    if (!prepared && level < a.max_level - 1) {
                         // once per pair, not on its first level (the claim has long returned by now): the
                         // next pair's prologue
                         prepared = true;
@@ -1223,8 +1177,8 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
             }
             for (int it = 0; it < a.max_iters; ++it) {
                 __syncthreads();                                       // B1
-                bool hinv_valid = false;                               // this kernel refactorises every iteration
-                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hinv_valid, nullptr);
+                double hrow[6];                                        // (this kernel's partials always report "changed":
+                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow);   // H^+ is rebuilt every iteration)
                 __syncthreads();                                       // B2
                 if (ctrl) break;
             }
