@@ -43,11 +43,8 @@ struct SAKernelArgs {
 #ifndef SA_PPW
 #define SA_PPW 2
 #endif
-// current-image footprint windows in LDS (residual_patch): on/off and rows per window (5 = no vertical
-// slack, 7 = the floor position may move by one row before a lane refills)
-#ifndef SA_WINDOW
-#define SA_WINDOW 1
-#endif
+// rows per current-image footprint window in LDS (residual_patch): 5 = no vertical slack, 7 = the
+// floor position may move by one row before a lane refills
 #ifndef SA_WIN_ROWS
 #define SA_WIN_ROWS 5
 #endif

@@ -147,8 +147,7 @@ __device__ __forceinline__ SE3d load_se3(const double* q, const double* t) {
 struct __attribute__((packed, aligned(4))) U32x3 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a, b; };
 
-// Footprint gathers: plain loads (a timing-only experiment with sc1 / nt cache bits on these two
-// instructions made the residual pass longer, nt by ~85 %).
+// Footprint gathers: plain loads (measured: `nt` on them costs 8 %).
 __device__ __forceinline__ U32x3 gather_x3(const uint32_t* p) { return *(const U32x3*)p; }
 __device__ __forceinline__ U32x2 gather_x2(const uint32_t* p) { return *(const U32x2*)p; }
 
@@ -247,57 +246,72 @@ __device__ __forceinline__ FeatureRegs make_feature(const FeatureRaw& r, const d
 // Per-level part of GetJocabianMat for one feature (reference :89-100, :123-162), producing the
 // register-resident state. Branch-free: lanes without a valid patch run the same instructions on a
 // harmless address (the level's first bytes) and end up with P.valid == false and an unused grid, so
-// the seven row gathers, the hooks and the arithmetic sit in straight-line code.
-template <typename GT>
-__device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const LevelGeom& lg, int level,
-                                                 const uint8_t* __restrict__ ref_base,  // pair's ref pyramid
-                                                 const FeatureRegs& F, PatchRegs<GT>& P) {
-    P.X[0] = F.X[0]; P.X[1] = F.X[1]; P.X[2] = F.X[2];
+// the seven row gathers and the arithmetic sit in straight-line code. (Gathering the NEXT level's
+// rows while a level waits for its solver, parked in LDS, was measured: the level start gets 5 k
+// cycles shorter and the launch no faster — the cold lines cost the same L1 fill time wherever they
+// are issued. Non-temporal gathers: 8 % slower.)
+typedef __attribute__((address_space(3))) uint32_t LdsU32;
+struct RefGeom {
+    bool valid;       // mbInitial && P_w != 0 && inside the level's border (:86, :95-100)
+    int fu, fv;       // floor of the level position (3,3 for lanes without a patch)
+    double su, sv;    // subpixel offsets
+};
+__device__ __forceinline__ RefGeom ref_geom(const FeatureRegs& F, const LevelGeom& lg, int level) {
+    RefGeom g;
     const float scale_f = 1.0f / (float)(1 << level);                  // :65 tScale (float)
     const double scale = (double)scale_f;
     const double px = (double)F.px * scale;                            // :89-91
     const double py = (double)F.py * scale;
     const double boarder = 3.0;                                        // :67 int(0.5*4+1)
-    const bool valid = F.ok && !(px - boarder < 0 || py - boarder < 0 || px + boarder >= (double)lg.w ||
-                                 py + boarder >= (double)lg.h || !(px == px) || !(py == py));   // :86, :95-100
-    P.valid = valid;
-    // :123-132
-    const double fu_d = floor(px), fv_d = floor(py);
-    const int fu = valid ? (int)fu_d : 3, fv = valid ? (int)fv_d : 3;
-    const double su = px - fu_d, sv = py - fv_d;
-    const double omx = 1.0 - su, omy = 1.0 - sv;
-    const double w00 = omx * omy, w01 = su * omy, w10 = omx * sv, w11 = su * sv;
-
-    // 7x7 u8 footprint rows fv-3..fv+3, cols fu-3..fu+3, fetched as aligned dwords; the grid
-    // g[r][c] = bilinear value at pixel (fv-3+r, fu-3+c) + subpixel offset is built row by row.
-    // Patch pixel (i,k), i,k in 0..3, is g[i+1][k+1] (offsets -2..+1 from floor, quirk Q4); its
-    // gradient neighbours are g[i+1][k], g[i+1][k+2], g[i][k+1], g[i+2][k+1] (:150-158).
+    g.valid = F.ok && !(px - boarder < 0 || py - boarder < 0 || px + boarder >= (double)lg.w ||
+                        py + boarder >= (double)lg.h || !(px == px) || !(py == py));
+    const double fu_d = floor(px), fv_d = floor(py);                   // :123-132
+    g.fu = g.valid ? (int)fu_d : 3; g.fv = g.valid ? (int)fv_d : 3;
+    g.su = px - fu_d; g.sv = py - fv_d;
+    return g;
+}
+__device__ __forceinline__ uint32_t ref_row_offset(const LevelGeom& lg, const RefGeom& g, int r) {
+    return g.valid ? lg.off + (uint32_t)(g.fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(g.fu - 3) : lg.off;
+}
+// 7x7 u8 footprint rows fv-3..fv+3, cols fu-3..fu+3, fetched as aligned dwords. All seven row gathers
+// are issued before the first one is consumed: the rows are cold (each its own cache line), and seven
+// dependent round trips would be seven HBM latencies per level.
+__device__ __forceinline__ void ref_rows_issue(const SAKernelArgs& a, const LevelGeom& lg, const uint8_t* __restrict__ ref_base,
+                                               const RefGeom& g, U32x3* w) {
     const uint32_t* __restrict__ img32 = (const uint32_t*)ref_base;
     const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
-    // all seven row gathers are issued before the first one is consumed: the rows are cold (each
-    // its own cache line), and seven dependent round trips would be seven HBM latencies per level
-    uint32_t rlo[7], rhi[7];
-    {
-        U32x3 w[7];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            // (dw+2 may be the dword after the last pixel of the pyramid: shift the window back by one
-            // dword there; wave-uniformly false except at the very end of the allocation)
-            const uint32_t o = valid ? lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3) : lg.off;
-            w[r] = gather_x3(img32 + min(o >> 2, last_dw - 2u));
-        }
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const uint32_t o = valid ? lg.off + (uint32_t)(fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(fu - 3) : lg.off;
-            const uint32_t dw = o >> 2;
-            const uint32_t sh = (o & 3u) * 8u;
-            const uint32_t dwc = min(dw, last_dw - 2u);
-            const uint32_t w0 = (dwc == dw) ? w[r].a : w[r].b, w1 = (dwc == dw) ? w[r].b : w[r].c, w2 = (dwc == dw) ? w[r].c : 0u;
-            rlo[r] = __builtin_amdgcn_alignbit(w1, w0, sh);             // bytes 0..3
-            rhi[r] = __builtin_amdgcn_alignbit(w2, w1, sh);             // bytes 4..7
-        }
+    for (int r = 0; r < 7; ++r) {
+        // (dw+2 may be the dword after the last pixel of the pyramid: shift the window back by one
+        // dword there; wave-uniformly false except at the very end of the allocation)
+        w[r] = gather_x3(img32 + min(ref_row_offset(lg, g, r) >> 2, last_dw - 2u));
     }
-    __builtin_amdgcn_sched_barrier(0);
+}
+// row r -> its 7 bytes: rlo = bytes 0..3, rhi = bytes 4..6 (+ one unused)
+__device__ __forceinline__ void ref_rows_unpack(const SAKernelArgs& a, const LevelGeom& lg, const RefGeom& g, const U32x3* w,
+                                                uint32_t* rlo, uint32_t* rhi) {
+    const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t o = ref_row_offset(lg, g, r);
+        const uint32_t dw = o >> 2;
+        const uint32_t sh = (o & 3u) * 8u;
+        const uint32_t dwc = min(dw, last_dw - 2u);
+        const uint32_t w0 = (dwc == dw) ? w[r].a : w[r].b, w1 = (dwc == dw) ? w[r].b : w[r].c, w2 = (dwc == dw) ? w[r].c : 0u;
+        rlo[r] = __builtin_amdgcn_alignbit(w1, w0, sh);
+        rhi[r] = __builtin_amdgcn_alignbit(w2, w1, sh);
+    }
+}
+// The grid g[r][c] = bilinear value at pixel (fv-3+r, fu-3+c) + subpixel offset, built row by row.
+// Patch pixel (i,k), i,k in 0..3, is g[i+1][k+1] (offsets -2..+1 from floor, quirk Q4); its
+// gradient neighbours are g[i+1][k], g[i+1][k+2], g[i][k+1], g[i+2][k+1] (:150-158).
+template <typename GT>
+__device__ __forceinline__ void grid_from_rows(const FeatureRegs& F, const RefGeom& g, const uint32_t* rlo, const uint32_t* rhi,
+                                               PatchRegs<GT>& P) {
+    P.X[0] = F.X[0]; P.X[1] = F.X[1]; P.X[2] = F.X[2];
+    P.valid = g.valid;
+    const double omx = 1.0 - g.su, omy = 1.0 - g.sv;
+    const double w00 = omx * omy, w01 = g.su * omy, w10 = omx * g.sv, w11 = g.su * g.sv;
     double top[7], bot[7];
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
@@ -315,6 +329,21 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
         for (int c = 0; c < 7; ++c) top[c] = bot[c];
         __builtin_amdgcn_sched_barrier(0);   // one footprint row in flight
     }
+}
+
+template <typename GT>
+__device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const LevelGeom& lg, int level,
+                                                 const uint8_t* __restrict__ ref_base,  // pair's ref pyramid
+                                                 const FeatureRegs& F, PatchRegs<GT>& P) {
+    const RefGeom g = ref_geom(F, lg, level);
+    uint32_t rlo[7], rhi[7];
+    {
+        U32x3 w[7];
+        ref_rows_issue(a, lg, ref_base, g, w);
+        ref_rows_unpack(a, lg, g, w, rlo, rhi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    grid_from_rows<GT>(F, g, rlo, rhi, P);
 }
 
 // Per-patch Gauss-Newton matrix  Sxx A A^T + Sxy (A B^T + B A^T) + Syy B B^T  (upper triangle,
@@ -368,7 +397,6 @@ __device__ __forceinline__ void patch_hess_foreach(const PatchHess& h, F&& f) {
 // (`win` points at this lane's column, planes are WIN_NL dwords apart): conflict-free.
 constexpr int WIN_ROWS = SA_WIN_ROWS;
 constexpr uint32_t WIN_EMPTY = 0xffffffffu;
-typedef __attribute__((address_space(3))) uint32_t LdsU32;
 
 
 // tT_c2r * X -> pixel of the current level (reference :254-262). Returns the visibility test of :262.
@@ -849,20 +877,23 @@ __device__ __attribute__((noinline)) void solver_finish(double* T_cur_w_pair, in
 #else
 #define SA_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SA_WAVES_PER_EU, SA_WAVES_PER_EU)))
 #endif
+// LDS of the register kernel. One struct
+// so that the layout is ours: the small, hot structures sit at the lowest addresses (ds_read/ds_write
+// immediate offsets reach 64 KB; behind a large array every access would need extra address
+// arithmetic — measured: +75 % on the solver's partial sums), the per-patch arrays behind them.
+template <int NPW, int PPW>
+struct RegSmem {
+    BlockState st[PPW];
+    WavePartial part[PPW][NPW * 4];
+    uint32_t sink[PPW][64];                              // LDS-DMA target of prepare_next's cache warm-up (never read)
+    uint32_t win[PPW][WIN_ROWS * 3 * NPW * 64];          // current-image footprint windows (residual_patch), [plane][lane]
+};
+
 template <int NPW, typename GT, int PPW, bool STAMPS = false>
 __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_align_reg_kernel(const SAKernelArgs a) {
     constexpr int NP = NPW * 4;            // one partial slot per 16-lane DPP row
     constexpr int WPP = NPW + 1;           // waves per pair
-    // One struct so that the layout is ours: the small, hot structures sit at the lowest LDS addresses
-    // (ds_read/ds_write immediate offsets reach 64 KB; behind a large array every access would need
-    // extra address arithmetic — measured: +75 % on the solver's partial sums), the DMA buffer last.
-    struct Smem {
-        BlockState st[PPW];
-        WavePartial part[PPW][NP];
-        uint32_t win[PPW][SA_WINDOW ? WIN_ROWS * 3 * NPW * 64 : 1];  // current-image footprint windows (residual_patch)
-        uint32_t sink[PPW][64];                                      // LDS-DMA target of prepare_next's cache warm-up (never read)
-    };
-    __shared__ Smem sm;
+    __shared__ RegSmem<NPW, PPW> sm;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1023,7 +1054,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             uint32_t worg = WIN_EMPTY;                                 // the level's window is filled by its first pass
             unsigned long long tp0 = 0;
             if (STAMPS) tp0 = __builtin_amdgcn_s_memtime();
-            LdsU32* const win = (LdsU32*)&sm.win[slot][SA_WINDOW ? ltid : 0];
+            LdsU32* const win = (LdsU32*)&sm.win[slot][ltid];
             precompute_patch<GT>(a, lg, level, ref_base, F, P);
             if (STAMPS) {
                 pin_patch(P);   // make the stamp wait for the precompute results
@@ -1053,7 +1084,11 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 unsigned long long tq0 = 0, tq1 = 0;
                 if (STAMPS) tq0 = __builtin_amdgcn_s_memtime();
                 pin_patch(P);
-                const bool vis = residual_patch<GT, SA_WINDOW ? NPW * 64 : 0>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b,
+                // (The slot's waves 0 and 4 sit on the same SIMD and run their passes in phase; the arbiter
+                // favours the older wave 0: 4.0 k vs 5.2 k cycles per pass, and the solver waits for the
+                // slower one. Giving wave 4 issue priority for part of its pass moves cycles between the
+                // two but not the slower finish: measured, no gain.)
+                const bool vis = residual_patch<GT, NPW * 64>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b,
                                                                               win, &worg);
                 const unsigned long long vmask = __ballot(vis);
                 // reduce to the 16-lane DPP rows only (4 steps instead of 6); the solver's lane-parallel
@@ -1095,6 +1130,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             }
         }
         pair_signal_arrive(&s.ack, lane);                              // done with this pair's shared state
+        if (STAMPS && lane == 0 && a.workspace) {                      // every patch wave: pass and barrier cycles
+            unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 20 + (size_t)pair * 16;
+            o[wave] = st_pass; o[8 + wave] = st_bar;
+        }
         if (STAMPS && ltid == 0 && a.workspace) {
             unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 12;
             o[0] = st_pre; o[1] = st_pass; o[2] = st_h; o[3] = st_bar;
@@ -1300,35 +1339,29 @@ static unsigned persistent_grid(int n_pairs, int ppw, int num_cus) {
     return (unsigned)(need < num_cus ? need : num_cus);
 }
 
+template <int NPW, int PPW, bool STAMPS>
+static hipError_t launch_reg(const SAKernelArgs& args, int num_cus, hipStream_t stream) {
+    static_assert(sizeof(RegSmem<NPW, PPW>) <= 64 * 1024, "static LDS");
+    hipLaunchKernelGGL((sparse_align_reg_kernel<NPW, SA_GRID_T, PPW, STAMPS>), dim3(persistent_grid(args.n_pairs, PPW, num_cus)),
+                       dim3(PPW * (NPW + 1) * 64), 0, stream, args);
+    return hipGetLastError();
+}
+
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, true>), dim3(persistent_grid(args.n_pairs, SA_PPW, num_cus)),
-                       dim3(SA_PPW * 6 * 64), 0, stream, args);
-    return hipGetLastError();
+    return launch_reg<5, SA_PPW, true>(args, num_cus, stream);
 }
 
 hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
-    const dim3 grid((unsigned)args.n_pairs);
     switch (variant) {
-        case SA_REG128:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<2, SA_GRID_T, 4>), dim3(persistent_grid(args.n_pairs, 4, num_cus)), dim3(4 * 3 * 64), 0, stream, args);
-            break;
-        case SA_REG192:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<3, SA_GRID_T, 3>), dim3(persistent_grid(args.n_pairs, 3, num_cus)), dim3(3 * 4 * 64), 0, stream, args);
-            break;
-        case SA_REG256:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<4, SA_GRID_T, 2>), dim3(persistent_grid(args.n_pairs, 2, num_cus)), dim3(2 * 5 * 64), 0, stream, args);
-            break;
-        case SA_REG320:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW>), dim3(persistent_grid(args.n_pairs, SA_PPW, num_cus)),
-                               dim3(SA_PPW * 6 * 64), 0, stream, args);
-            break;
-        case SA_REG448:
-            hipLaunchKernelGGL((sparse_align_reg_kernel<7, SA_GRID_T, 1>), dim3(persistent_grid(args.n_pairs, 1, num_cus)), dim3(8 * 64), 0, stream, args);
-            break;
+        case SA_REG128: return launch_reg<2, 4, false>(args, num_cus, stream);
+        case SA_REG192: return launch_reg<3, 3, false>(args, num_cus, stream);
+        case SA_REG256: return launch_reg<4, 2, false>(args, num_cus, stream);
+        case SA_REG320: return launch_reg<5, SA_PPW, false>(args, num_cus, stream);
+        case SA_REG448: return launch_reg<7, 1, false>(args, num_cus, stream);
         case SA_WS:
-            hipLaunchKernelGGL((sparse_align_ws_kernel<7>), grid, dim3(8 * 64), 0, stream, args);
+            hipLaunchKernelGGL((sparse_align_ws_kernel<7>), dim3((unsigned)args.n_pairs), dim3(8 * 64), 0, stream, args);
             break;
     }
     return hipGetLastError();
