@@ -296,6 +296,82 @@ def test_device_api_with_padded_rows(gpu_ctx, oracle):
         assert ntg[i] == no
 
 
+@pytest.mark.parametrize("scale", [1.0, 2.5])
+def test_window_refills_under_multi_pixel_motion(gpu_ctx, oracle, scale):
+    """The kernel keeps each patch's current-image footprint in an LDS window and refills a lane's
+    window when its floor position leaves it. Fine levels only, started from the identity seed: the
+    patches move by several pixels between the first iterations, so most lanes refill repeatedly."""
+    xi = tuple(scale * v for v in (0.01, -0.006, 0.004, 0.004, -0.003, 0.005))
+    sc = cached_scene(width=640, height=480, levels=3, n_patches=300, seed=77, xi=xi, margin=40)
+    for (mx, mn, it) in [(1, 0, 30), (2, 0, 30), (2, 1, 12)]:
+        To, no, so = oracle.sparse_align(sc, mx, mn, it)
+        Tg, ng, sg = H.gpu_sparse_align(sc, mx, mn, it, ctx=gpu_ctx)
+        H.assert_pose_close(Tg, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"scale {scale} levels {(mx, mn)}")
+        assert ng == no and sg["iters"] == so["iters"] and sg["exit_code"] == so["exit_code"] and sg["n_vis"] == so["n_vis"]
+
+
+def test_footprints_at_the_end_of_the_pyramid_allocation(gpu_ctx, oracle):
+    """Tightly packed device pyramids (stride == width, pitch == end of the last level, no padding) with
+    features along the right and bottom borders of every level: the 12-byte row gathers of the last
+    rows would run past the allocation and take the shifted-window path; results must not change."""
+    import copy
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    L, N = 3, 120
+    ws, hs = [320, 160, 80], [240, 120, 60]
+    scenes = []
+    for i in range(2):
+        sc = copy.deepcopy(cached_scene(width=320, height=240, levels=L, n_patches=N, seed=950 + i, margin=12))
+        rng = np.random.default_rng(i)
+        k = N // 3
+        # bottom rows and right columns, just inside the coarsest level's 3-px border (x4 at level 0)
+        sc.px[:k, 0] = rng.uniform(20, 300, k); sc.px[:k, 1] = rng.uniform(224.0, 227.9, k)
+        sc.px[k:2 * k, 0] = rng.uniform(304.0, 307.9, k); sc.px[k:2 * k, 1] = rng.uniform(20, 220, k)
+        sc.px[2 * k, :] = (307.5, 227.5)
+        sc.px = sc.px.astype(np.float32)
+        sc.bearing = synth.bearing_from_px(sc.cam, sc.px)
+        X_r = sc.bearing * (sc.depth / sc.bearing[:, 2:3])
+        Rr, tr = sc.T_ref_w[:, :3], sc.T_ref_w[:, 3]
+        sc.p_world = (X_r - tr) @ Rr
+        scenes.append(sc)
+    offs, off = [], 0
+    for l in range(L):
+        offs.append(off)
+        off += ws[l] * hs[l]
+    pitch = off                                             # 100800: a multiple of 4, nothing behind the last pixel
+    P = len(scenes)
+    ref = np.zeros((P, pitch), np.uint8); cur = np.zeros((P, pitch), np.uint8)
+    for i, sc in enumerate(scenes):
+        for l in range(L):
+            ref[i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.ref_pyr[l].reshape(-1)
+            cur[i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.cur_pyr[l].reshape(-1)
+    arr = dict(ref=ref, cur=cur, px=np.stack([s.px for s in scenes]), bear=np.stack([s.bearing for s in scenes]),
+               pw=np.stack([s.p_world for s in scenes]), ini=np.stack([s.initial for s in scenes]),
+               Tr=np.stack([s.T_ref_w.reshape(12) for s in scenes]), Tc=np.stack([s.T_cur_w_seed.reshape(12) for s in scenes]))
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in arr.items()}
+    t["nt"] = torch.zeros(P, dtype=torch.int32, device=dev)
+    b = capi.BatchDesc()
+    b.n_pairs, b.max_features, b.levels = P, N, L
+    for l in range(L):
+        b.width[l], b.height[l], b.stride[l], b.level_offset[l] = ws[l], hs[l], ws[l], offs[l]
+    b.pyr_pitch = pitch
+    b.ref_pyr, b.cur_pyr, b.px_xy, b.bearing, b.p_world = (t[k].data_ptr() for k in ("ref", "cur", "px", "bear", "pw"))
+    b.initial, b.n_features, b.T_ref_w, b.T_cur_w = t["ini"].data_ptr(), None, t["Tr"].data_ptr(), t["Tc"].data_ptr()
+    b.n_tracked, b.stats = t["nt"].data_ptr(), None
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    stream = torch.cuda.Stream(device=dev)
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), stream.cuda_stream))
+    stream.synchronize()
+    Tg = t["Tc"].cpu().numpy(); ntg = t["nt"].cpu().numpy()
+    for i, sc in enumerate(scenes):
+        To, no, _ = oracle.sparse_align(sc, L, 0, 10)
+        H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"tight pair {i}")
+        assert ntg[i] == no and no > 0
+
+
 @pytest.mark.parametrize("n_patches", [16, 100, 128, 129, 192, 193, 256, 257, 320])
 def test_every_register_kernel_shape(gpu_ctx, oracle, n_patches):
     """Feature counts on both sides of every kernel-shape boundary (2+1x4, 3+1x3, 4+1x2, 5+1x2, 7+1x1 waves)."""
