@@ -4,8 +4,8 @@
 // separable [1 4 6 4 1], BORDER_REFLECT_101, (sum+128)>>8, output ((w+1)/2,(h+1)/2)).
 // Integer arithmetic, bit-exact. HBM-bound: each thread owns a strip of 4 output columns (one dword
 // store per output row) and walks down 8 output rows with a sliding window of horizontally
-// filtered input rows, each read once as one aligned 16-byte load; odd sizes take a byte-wise
-// reflected path.
+// filtered input rows (v_dot4_u32_u8), each read once as one 16-byte load, vertical pass on packed
+// u16; odd sizes take a byte-wise reflected path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,70 +30,98 @@ struct PyrDownArgs {
 };
 
 // Each thread owns a strip of 4 output columns and walks down PD_ROWS output rows with a sliding
-// window of horizontally filtered rows: every input row of the strip is loaded (one aligned 16-byte
-// load) and filtered ONCE and reused by the 2-3 output rows it contributes to.
+// window of horizontally filtered rows: every input row of the strip is loaded (one 16-byte load)
+// and filtered ONCE and reused by the 2-3 output rows it contributes to.
+//
+// The first version spent ~150 VALU instructions per output row on byte extraction and scalar
+// multiply-adds and was issue-bound (2.2 TB/s). Now: the horizontal [1 4 6 4 1] of one output is
+// ONE v_dot4_u32_u8 of the 4-byte window at its column with the constant (1,4,6,4), the fifth tap as
+// the accumulator operand (window assembled with v_alignbyte); the filtered rows are kept as packed
+// u16 pairs (<= 4080 each) and the vertical pass runs on v_pk_* (<= 65280 + 128 fits 16 bits);
+// ~50 instructions per output row. Threads are numbered linearly over (strip, row chunk), so waves
+// are full whatever the level width (640 px = 80 strips used to leave the second block column at 16
+// of 64 lanes).
 constexpr int PD_ROWS = 8;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// horizontal [1 4 6 4 1] of input row `row` for the 4 output columns x4..x4+3 (aligned fast path)
-__device__ __forceinline__ void pd_hrow(const uint8_t* __restrict__ src, int sstride, int row, int base, bool left,
-                                        bool right, int* h) {
-    const uint32_t* __restrict__ p32 = (const uint32_t*)(src + (size_t)row * sstride + base);
-    const uint32_t d0 = p32[0], d1 = p32[1], d2 = p32[2];
-    // the 4th dword is only needed by interior/left threads; for the right-border thread it would
-    // start past the row end, so it is not read there
-    const uint32_t d3 = right ? 0u : p32[3];
-    int px[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        px[j] = (d0 >> (8 * j)) & 0xff; px[4 + j] = (d1 >> (8 * j)) & 0xff;
-        px[8 + j] = (d2 >> (8 * j)) & 0xff; px[12 + j] = (d3 >> (8 * j)) & 0xff;
-    }
-    int w[11];                                // w[j] = pixel at column xs + j (reflected)
-#pragma unroll
-    for (int j = 0; j < 11; ++j) w[j] = left ? ((j < 2) ? px[2 - j] : px[j - 2]) : px[j + 2];
-    if (right) w[10] = w[8];                  // column sw -> sw-2 (BORDER_REFLECT_101)
-#pragma unroll
-    for (int o = 0; o < 4; ++o) h[o] = w[2 * o] + w[2 * o + 4] + 4 * (w[2 * o + 1] + w[2 * o + 3]) + 6 * w[2 * o + 2];
+__device__ __forceinline__ u16x2 pk(uint32_t lo, uint32_t hi) {
+    u16x2 v; v.x = (unsigned short)lo; v.y = (unsigned short)hi; return v;
 }
 
-__global__ __launch_bounds__(256) void pyrdown_kernel(const PyrDownArgs a) {
+// horizontal [1 4 6 4 1] of input row `row` for the 4 output columns x4..x4+3 (aligned fast path):
+// hA = (h0, h1), hB = (h2, h3)
+__device__ __forceinline__ void pd_hrow(const uint8_t* __restrict__ src, int sstride, int row, int base, bool left,
+                                        bool right, u16x2& hA, u16x2& hB) {
+    const uint32_t* __restrict__ p32 = (const uint32_t*)(src + (size_t)row * sstride + base);
+    // 16 bytes from `base` (a multiple of 4). The 4th dword of the right-border strip starts at the
+    // row end: it lies inside the pyramid (a source level is never the last level) and is not used.
+    const uint32_t d0 = p32[0], d1 = p32[1], d2 = p32[2], d3 = p32[3];
+    // e0..e3 = columns xs-2 .. xs+13 with xs = 2*x4 - 2; interior strips load exactly that
+    // (base = xs-2); the left-border strip (xs = -2) loads columns 0..15 and mirrors -4..-1 -> 4..1
+    const uint32_t e0 = left ? __builtin_amdgcn_perm(d1, d0, 0x01020304u) : d0;   // bytes [col4, col3, col2, col1]
+    const uint32_t e1 = left ? d0 : d1;
+    const uint32_t e2 = left ? d1 : d2;
+    const uint32_t e3 = left ? d2 : d3;
+    // output o: taps at bytes 2+2o .. 6+2o of (e0..e3)
+    const uint32_t k = 0x04060401u;                                   // weights of taps 0..3; tap 4 has weight 1
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(e1, e0, 2);        // bytes 2..5
+    const uint32_t w2 = __builtin_amdgcn_alignbyte(e2, e1, 2);        // bytes 6..9
+    const uint32_t t0 = (e1 >> 16) & 0xffu;                           // byte 6
+    const uint32_t t1 = e2 & 0xffu;                                   // byte 8
+    const uint32_t t2 = (e2 >> 16) & 0xffu;                           // byte 10
+    const uint32_t t3 = right ? t2 : (e3 & 0xffu);                    // byte 12; column sw -> sw-2 (BORDER_REFLECT_101)
+    const uint32_t h0 = __builtin_amdgcn_udot4(w0, k, t0, false);
+    const uint32_t h1 = __builtin_amdgcn_udot4(e1, k, t1, false);
+    const uint32_t h2 = __builtin_amdgcn_udot4(w2, k, t2, false);
+    const uint32_t h3 = __builtin_amdgcn_udot4(e2, k, t3, false);
+    hA = pk(h0, h1);
+    hB = pk(h2, h3);
+}
+
+// vertical [1 4 6 4 1] + rounding of one packed pair: ((r0 + r4) + 4 (r1 + r3) + 6 r2 + 128) >> 8
+__device__ __forceinline__ u16x2 pd_vert(u16x2 r0, u16x2 r1, u16x2 r2, u16x2 r3, u16x2 r4) {
+    const u16x2 four = {4, 4}, six = {6, 6}, half = {128, 128}, eight = {8, 8};
+    u16x2 v = (r1 + r3) * four + (r0 + r4);
+    v = r2 * six + v;
+    return (v + half) >> eight;
+}
+
+__global__ __launch_bounds__(256) void pyrdown_kernel(const PyrDownArgs a, int tx, int ty) {
     const int img = blockIdx.z;
-    const int y0 = (blockIdx.y * blockDim.y + threadIdx.y) * PD_ROWS;   // first output row of this thread
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;         // first of 4 output columns
-    if (y0 >= a.dh || x4 >= a.dw) return;
+    // linear numbering over (strip, row chunk): consecutive lanes = consecutive strips of a row chunk
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= tx * ty) return;
+    const int y0 = (gid / tx) * PD_ROWS;                                // first output row of this thread
+    const int x4 = (gid % tx) * 4;                                      // first of 4 output columns
     const uint8_t* __restrict__ src = a.pyr + (size_t)img * a.pyr_pitch + a.soff;
     uint8_t* __restrict__ dst = a.pyr + (size_t)img * a.pyr_pitch + a.doff;
     const int xs = 2 * x4 - 2;                       // first input column needed (x4 is a multiple of 4)
 
-    // Fast path: the 11 input columns xs..xs+10 of a row come from ONE aligned 16-byte load. Interior
-    // threads read columns (xs-2)..(xs+13) and use bytes 2..12; the left-border thread (xs = -2) reads
-    // columns 0..15 and mirrors columns -2,-1 -> 2,1; the right-border thread of an even-width image
-    // needs column sw -> sw-2. Keeping the border lanes on this path matters: one lane on the
-    // byte-wise path stalls its whole wave.
+    // Fast path: the 11 input columns xs..xs+10 of a row come from ONE 16-byte load. Interior threads
+    // read columns (xs-2)..(xs+13) and use bytes 2..12; the left-border thread (xs = -2) reads
+    // columns 0..15 and mirrors; the right-border thread of an even-width image needs column
+    // sw -> sw-2. Keeping the border lanes on this path matters: one lane on the byte-wise path
+    // stalls its whole wave.
     const bool left = (x4 == 0);
     const bool right = (xs + 10 >= a.sw);             // only column xs+10 == sw can be outside
     const bool fast = ((a.sstride & 3) == 0) && ((((size_t)src) & 3) == 0) && ((a.sw & 1) == 0) && a.sw >= 16 &&
                       (x4 + 3 < a.dw) && (!right || xs + 10 == a.sw) && (((size_t)(dst + x4)) & 3) == 0 && (a.dstride & 3) == 0;
     if (fast) {
         const int base = left ? 0 : (xs - 2);         // multiple of 4
-        int win[5][4];                                // horizontally filtered rows 2y-2 .. 2y+2
-        pd_hrow(src, a.sstride, reflect101(2 * y0 - 2, a.sh), base, left, right, win[0]);
-        pd_hrow(src, a.sstride, reflect101(2 * y0 - 1, a.sh), base, left, right, win[1]);
-        pd_hrow(src, a.sstride, reflect101(2 * y0, a.sh), base, left, right, win[2]);
+        u16x2 wA[5], wB[5];                           // horizontally filtered rows 2y-2 .. 2y+2
+        pd_hrow(src, a.sstride, reflect101(2 * y0 - 2, a.sh), base, left, right, wA[0], wB[0]);
+        pd_hrow(src, a.sstride, reflect101(2 * y0 - 1, a.sh), base, left, right, wA[1], wB[1]);
+        pd_hrow(src, a.sstride, reflect101(2 * y0, a.sh), base, left, right, wA[2], wB[2]);
 #pragma unroll
         for (int r = 0; r < PD_ROWS; ++r) {
             const int y = y0 + r;
             if (y >= a.dh) break;
             // window slot of input row 2y+k-2 is (2r + k) % 5
-            pd_hrow(src, a.sstride, reflect101(2 * y + 1, a.sh), base, left, right, win[(2 * r + 3) % 5]);
-            pd_hrow(src, a.sstride, reflect101(2 * y + 2, a.sh), base, left, right, win[(2 * r + 4) % 5]);
-            uint32_t packed = 0;
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const int v = win[(2 * r) % 5][o] + win[(2 * r + 4) % 5][o] + 4 * (win[(2 * r + 1) % 5][o] + win[(2 * r + 3) % 5][o]) +
-                              6 * win[(2 * r + 2) % 5][o];
-                packed |= (uint32_t)((v + 128) >> 8) << (8 * o);
-            }
+            pd_hrow(src, a.sstride, reflect101(2 * y + 1, a.sh), base, left, right, wA[(2 * r + 3) % 5], wB[(2 * r + 3) % 5]);
+            pd_hrow(src, a.sstride, reflect101(2 * y + 2, a.sh), base, left, right, wA[(2 * r + 4) % 5], wB[(2 * r + 4) % 5]);
+            const u16x2 oA = pd_vert(wA[(2 * r) % 5], wA[(2 * r + 1) % 5], wA[(2 * r + 2) % 5], wA[(2 * r + 3) % 5], wA[(2 * r + 4) % 5]);
+            const u16x2 oB = pd_vert(wB[(2 * r) % 5], wB[(2 * r + 1) % 5], wB[(2 * r + 2) % 5], wB[(2 * r + 3) % 5], wB[(2 * r + 4) % 5]);
+            const uint32_t packed = (uint32_t)oA.x | ((uint32_t)oA.y << 8) | ((uint32_t)oB.x << 16) | ((uint32_t)oB.y << 24);
             *(uint32_t*)(dst + (size_t)y * a.dstride + x4) = packed;
         }
         return;
@@ -128,16 +156,15 @@ hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, 
     a.pyr = pyr; a.pyr_pitch = pyr_pitch; a.n_images = n_images;
     a.sw = sw; a.sh = sh; a.sstride = sstride; a.soff = soff;
     a.dw = (sw + 1) / 2; a.dh = (sh + 1) / 2; a.dstride = dstride; a.doff = doff;
-    const dim3 block(64, 4);
-    const int tx = (a.dw + 3) / 4;
+    const int tx = (a.dw + 3) / 4;                          // strips of 4 output columns
+    const int ty = (a.dh + PD_ROWS - 1) / PD_ROWS;          // row chunks of PD_ROWS output rows per thread
     // gridDim.z is limited to 65535 images per launch
     for (int i0 = 0; i0 < n_images; i0 += 65535) {
         const int nz = (n_images - i0 < 65535) ? n_images - i0 : 65535;
         PyrDownArgs b = a;
         b.pyr = pyr + (size_t)i0 * pyr_pitch;
-        const int ty = (a.dh + PD_ROWS - 1) / PD_ROWS;      // row chunks of PD_ROWS output rows per thread
-        const dim3 grid((unsigned)((tx + 63) / 64), (unsigned)((ty + 3) / 4), (unsigned)nz);
-        hipLaunchKernelGGL(pyrdown_kernel, grid, block, 0, stream, b);
+        const dim3 grid((unsigned)((tx * ty + 255) / 256), 1u, (unsigned)nz);
+        hipLaunchKernelGGL(pyrdown_kernel, grid, dim3(256), 0, stream, b, tx, ty);
     }
     return hipGetLastError();
 }
