@@ -126,6 +126,7 @@ EXPORTED_SYMBOLS = [
     "dsdtm_sparse_align", "dsdtm_sparse_align_batch_device", "dsdtm_sparse_align_workspace_bytes",
     "dsdtm_reserve", "dsdtm_align2d_batch", "dsdtm_align2d_batch_device",
     "dsdtm_pyrdown_batch_device", "dsdtm_pyrdown", "dsdtm_warp_patches",
+    "dsdtm_frame_create", "dsdtm_frame_create_from_image", "dsdtm_frame_destroy", "dsdtm_sparse_align_frames",
 ]
 
 _LIB = None
@@ -181,8 +182,54 @@ def load():
     lib.dsdtm_pyrdown.restype = C.c_int
     lib.dsdtm_pyrdown.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+    lib.dsdtm_frame_create.restype = C.c_int
+    lib.dsdtm_frame_create.argtypes = [C.c_void_p, C.POINTER(Pyramid), C.POINTER(C.c_void_p)]
+    lib.dsdtm_frame_create_from_image.restype = C.c_int
+    lib.dsdtm_frame_create_from_image.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.dsdtm_frame_destroy.restype = None
+    lib.dsdtm_frame_destroy.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dsdtm_sparse_align_frames.restype = C.c_int
+    lib.dsdtm_sparse_align_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Camera), fp, dp, dp, u8p, C.c_int,
+                                              dp, dp, C.POINTER(AlignParams), C.POINTER(C.c_int), C.POINTER(AlignStats)]
     _LIB = lib
     return lib
+
+
+class DeviceFrame:
+    """A frame's image pyramid kept on the device (dsdtm_frame): uploaded once, used by every Run the
+    frame takes part in. `from_image` sends level 0 only and builds the pyramid with the library's
+    bit-exact pyrDown (Frame::ComputeImagePyramid, reference src/Frame.cpp:74-81)."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.handle = ctx, handle
+
+    @classmethod
+    def from_pyramid(cls, ctx: "Context", img_pyr):
+        pyr, keep = pyramid_struct(img_pyr)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.dsdtm_frame_create(ctx.handle, C.byref(pyr), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_image(cls, ctx: "Context", level0, levels: int):
+        import numpy as np
+        img = np.ascontiguousarray(level0, dtype=np.uint8)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.dsdtm_frame_create_from_image(ctx.handle, img.ctypes.data_as(u8p), img.shape[1], img.shape[0],
+                                                        img.strides[0], levels, C.byref(h)))
+        return cls(ctx, h)
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.dsdtm_frame_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

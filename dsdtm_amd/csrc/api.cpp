@@ -266,6 +266,75 @@ static void pack_pyramid(const dsdtm_pyramid* p, const PackedPyr& pl, uint8_t* d
     }
 }
 
+// One alignment on the context's stream. The pyramids are either packed into the staging buffer
+// together with the features (ref/cur given, dev_ref/dev_cur null) or already on the device.
+static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyramid* ref, const dsdtm_pyramid* cur,
+                            const uint8_t* dev_ref, const uint8_t* dev_cur, size_t dev_pitch,
+                            const dsdtm_camera* cam, const float* px_xy, const double* bearing,
+                            const double* p_world, const uint8_t* initial, int n_features,
+                            const double T_ref_w[12], double T_cur_w[12], const dsdtm_align_params* prm,
+                            int* n_tracked, dsdtm_align_stats* stats) {
+    if (int rc = validate_params(ctx, prm, pl.levels)) return rc;
+    // Run() (:34-38): too few features -> 0, pose untouched. Decided on the host: no launch needed.
+    if (stats) memset(stats, 0, sizeof *stats);
+    *n_tracked = 0;
+    if (n_features < prm->min_fts || prm->max_level - 1 < prm->min_level) return DSDTM_OK;
+
+    const bool staged_pyr = dev_ref == nullptr;
+    const size_t nf = (size_t)n_features;
+    const size_t pitch = staged_pyr ? align_up(pl.bytes, 256) : dev_pitch;
+    size_t o = 0;
+    const size_t o_ref = o; if (staged_pyr) o += pitch;
+    const size_t o_cur = o; if (staged_pyr) o += pitch;
+    const size_t o_bear = o; o += align_up(nf * 24, 256);
+    const size_t o_pw = o; o += align_up(nf * 24, 256);
+    const size_t o_tr = o; o += 256;
+    const size_t o_px = o; o += align_up(nf * 8, 256);
+    const size_t o_ini = o; o += align_up(nf, 256);
+    const size_t in_bytes = o;
+    const size_t o_tc = o; o += 256;          // in (seed) and out
+    const size_t o_nt = o; o += 256;
+    const size_t o_st = o; o += align_up(sizeof(dsdtm_align_stats), 256);
+    const size_t total = o;
+    if (int rc = ensure_stage(ctx, total)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    if (staged_pyr) {
+        pack_pyramid(ref, pl, h + o_ref);
+        pack_pyramid(cur, pl, h + o_cur);
+    }
+    memcpy(h + o_bear, bearing, nf * 24);
+    memcpy(h + o_pw, p_world, nf * 24);
+    memcpy(h + o_tr, T_ref_w, 96);
+    memcpy(h + o_px, px_xy, nf * 8);
+    memcpy(h + o_ini, initial, nf);
+    memcpy(h + o_tc, T_cur_w, 96);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes + 256, hipMemcpyHostToDevice, ctx->stream));
+
+    dsdtm_batch_desc b;
+    memset(&b, 0, sizeof b);
+    b.n_pairs = 1; b.max_features = n_features; b.levels = pl.levels;
+    for (int l = 0; l < pl.levels; ++l) { b.width[l] = pl.w[l]; b.height[l] = pl.h[l]; b.stride[l] = pl.w[l]; b.level_offset[l] = pl.off[l]; }
+    b.pyr_pitch = pitch;
+    b.ref_pyr = staged_pyr ? d + o_ref : dev_ref; b.cur_pyr = staged_pyr ? d + o_cur : dev_cur;
+    b.px_xy = (const float*)(d + o_px);
+    b.bearing = (const double*)(d + o_bear); b.p_world = (const double*)(d + o_pw); b.initial = d + o_ini;
+    b.n_features = nullptr; b.T_ref_w = (const double*)(d + o_tr); b.T_cur_w = (double*)(d + o_tc);
+    b.n_tracked = (int32_t*)(d + o_nt); b.stats = (dsdtm_align_stats*)(d + o_st);
+    if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, ctx->stream)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        unsigned timeout_flag = 0;
+        HIP_TRY(ctx, sparse_align_take_timeout_flag(&timeout_flag));
+        if (timeout_flag) { set_err(ctx, "sparse-align kernel: intra-workgroup hand-over timed out"); return DSDTM_ERR_HIP; }
+    }
+    memcpy(T_cur_w, h + o_tc, 96);
+    *n_tracked = *(const int32_t*)(h + o_nt);
+    if (stats) memcpy(stats, h + o_st, sizeof *stats);
+    return DSDTM_OK;
+}
+
 extern "C" int dsdtm_sparse_align(dsdtm_ctx* ctx, const dsdtm_pyramid* ref, const dsdtm_pyramid* cur,
                                   const dsdtm_camera* cam, const float* px_xy, const double* bearing,
                                   const double* p_world, const uint8_t* initial, int n_features,
@@ -282,61 +351,106 @@ extern "C" int dsdtm_sparse_align(dsdtm_ctx* ctx, const dsdtm_pyramid* ref, cons
     if (pr.levels != pc.levels) { set_err(ctx, "ref/cur pyramids differ in level count"); return DSDTM_ERR_INVALID; }
     for (int l = 0; l < pr.levels; ++l)
         if (pr.w[l] != pc.w[l] || pr.h[l] != pc.h[l]) { set_err(ctx, "ref/cur level %d differ in size", l); return DSDTM_ERR_INVALID; }
-    if (int rc = validate_params(ctx, prm, pr.levels)) return rc;
-    // Run() (:34-38): too few features -> 0, pose untouched. Decided on the host: no launch needed.
-    if (stats) memset(stats, 0, sizeof *stats);
-    *n_tracked = 0;
-    if (n_features < prm->min_fts || prm->max_level - 1 < prm->min_level) return DSDTM_OK;
+    return sparse_align_one(ctx, pr, ref, cur, nullptr, nullptr, 0, cam, px_xy, bearing, p_world, initial, n_features,
+                            T_ref_w, T_cur_w, prm, n_tracked, stats);
+}
 
-    const size_t nf = (size_t)n_features;
-    const size_t pitch = align_up(pr.bytes, 256);
-    size_t o = 0;
-    const size_t o_ref = o; o += pitch;
-    const size_t o_cur = o; o += pitch;
-    const size_t o_bear = o; o += align_up(nf * 24, 256);
-    const size_t o_pw = o; o += align_up(nf * 24, 256);
-    const size_t o_tr = o; o += 256;
-    const size_t o_px = o; o += align_up(nf * 8, 256);
-    const size_t o_ini = o; o += align_up(nf, 256);
-    const size_t in_bytes = o;
-    const size_t o_tc = o; o += 256;          // in (seed) and out
-    const size_t o_nt = o; o += 256;
-    const size_t o_st = o; o += align_up(sizeof(dsdtm_align_stats), 256);
-    const size_t total = o;
-    if (int rc = ensure_stage(ctx, total)) return rc;
-    uint8_t* h = (uint8_t*)ctx->h_pinned;
-    uint8_t* d = (uint8_t*)ctx->d_stage;
-    pack_pyramid(ref, pr, h + o_ref);
-    pack_pyramid(cur, pc, h + o_cur);
-    memcpy(h + o_bear, bearing, nf * 24);
-    memcpy(h + o_pw, p_world, nf * 24);
-    memcpy(h + o_tr, T_ref_w, 96);
-    memcpy(h + o_px, px_xy, nf * 8);
-    memcpy(h + o_ini, initial, nf);
-    memcpy(h + o_tc, T_cur_w, 96);
-    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes + 256, hipMemcpyHostToDevice, ctx->stream));
+// ---- frames that stay on the device --------------------------------------------------------------
+struct dsdtm_frame {
+    dsdtm_ctx* owner;
+    uint8_t* d;          // packed pyramid (the layout of plan_pyramid), its own allocation
+    size_t pitch;
+    PackedPyr pl;
+};
 
-    dsdtm_batch_desc b;
-    memset(&b, 0, sizeof b);
-    b.n_pairs = 1; b.max_features = n_features; b.levels = pr.levels;
-    for (int l = 0; l < pr.levels; ++l) { b.width[l] = pr.w[l]; b.height[l] = pr.h[l]; b.stride[l] = pr.w[l]; b.level_offset[l] = pr.off[l]; }
-    b.pyr_pitch = pitch;
-    b.ref_pyr = d + o_ref; b.cur_pyr = d + o_cur; b.px_xy = (const float*)(d + o_px);
-    b.bearing = (const double*)(d + o_bear); b.p_world = (const double*)(d + o_pw); b.initial = d + o_ini;
-    b.n_features = nullptr; b.T_ref_w = (const double*)(d + o_tr); b.T_cur_w = (double*)(d + o_tc);
-    b.n_tracked = (int32_t*)(d + o_nt); b.stats = (dsdtm_align_stats*)(d + o_st);
-    if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, ctx->stream)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    {
-        unsigned timeout_flag = 0;
-        HIP_TRY(ctx, sparse_align_take_timeout_flag(&timeout_flag));
-        if (timeout_flag) { set_err(ctx, "sparse-align kernel: intra-workgroup hand-over timed out"); return DSDTM_ERR_HIP; }
+static int frame_alloc(dsdtm_ctx* ctx, const PackedPyr& pl, dsdtm_frame** out) {
+    dsdtm_frame* f = new (std::nothrow) dsdtm_frame();
+    if (!f) return DSDTM_ERR_NOMEM;
+    f->owner = ctx; f->pl = pl; f->pitch = align_up(pl.bytes, 256); f->d = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&f->d, f->pitch) != hipSuccess) {
+        set_err(ctx, "hipMalloc of a %zu-byte frame failed", f->pitch);
+        delete f;
+        return DSDTM_ERR_NOMEM;
     }
-    memcpy(T_cur_w, h + o_tc, 96);
-    *n_tracked = *(const int32_t*)(h + o_nt);
-    if (stats) memcpy(stats, h + o_st, sizeof *stats);
+    *out = f;
     return DSDTM_OK;
+}
+
+extern "C" int dsdtm_frame_create(dsdtm_ctx* ctx, const dsdtm_pyramid* pyr, dsdtm_frame** out) {
+    if (!ctx || !out) return DSDTM_ERR_INVALID;
+    *out = nullptr;
+    PackedPyr pl;
+    if (int rc = plan_pyramid(ctx, pyr, &pl)) return rc;
+    if (int rc = ensure_stage(ctx, pl.bytes)) return rc;
+    dsdtm_frame* f = nullptr;
+    if (int rc = frame_alloc(ctx, pl, &f)) return rc;
+    pack_pyramid(pyr, pl, (uint8_t*)ctx->h_pinned);
+    hipError_t e = hipMemcpyAsync(f->d, ctx->h_pinned, pl.bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the pinned buffer is reused by the next call
+    if (e != hipSuccess) { set_err(ctx, "frame upload failed: %s", hipGetErrorString(e)); dsdtm_frame_destroy(ctx, f); return DSDTM_ERR_HIP; }
+    *out = f;
+    return DSDTM_OK;
+}
+
+extern "C" int dsdtm_frame_create_from_image(dsdtm_ctx* ctx, const uint8_t* level0, int width, int height, int stride,
+                                             int levels, dsdtm_frame** out) {
+    if (!ctx || !out) return DSDTM_ERR_INVALID;
+    *out = nullptr;
+    if (!level0 || width <= 0 || height <= 0 || stride < width || levels <= 0 || levels > DSDTM_MAX_LEVELS) {
+        set_err(ctx, "bad argument"); return DSDTM_ERR_INVALID;
+    }
+    PackedPyr pl;
+    int st[DSDTM_MAX_LEVELS];
+    pl.levels = levels;
+    size_t o = 0;
+    for (int l = 0; l < levels; ++l) {
+        pl.w[l] = l ? (pl.w[l - 1] + 1) / 2 : width; pl.h[l] = l ? (pl.h[l - 1] + 1) / 2 : height; st[l] = pl.w[l];
+        pl.off[l] = o; o += align_up((size_t)pl.w[l] * pl.h[l], 64);
+    }
+    pl.bytes = o;
+    if (int rc = ensure_stage(ctx, (size_t)width * height)) return rc;
+    dsdtm_frame* f = nullptr;
+    if (int rc = frame_alloc(ctx, pl, &f)) return rc;
+    uint8_t* hp = (uint8_t*)ctx->h_pinned;
+    if (stride == width) memcpy(hp, level0, (size_t)width * height);
+    else for (int y = 0; y < height; ++y) memcpy(hp + (size_t)y * width, level0 + (size_t)y * stride, width);
+    hipError_t e = hipMemcpyAsync(f->d, hp, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream);
+    int rc = DSDTM_OK;
+    if (e == hipSuccess) rc = dsdtm_pyrdown_batch_device(ctx, f->d, f->pitch, 1, levels, pl.w, pl.h, st, pl.off, ctx->stream);
+    if (e == hipSuccess && rc == DSDTM_OK) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || rc != DSDTM_OK) {
+        if (e != hipSuccess) { set_err(ctx, "frame upload failed: %s", hipGetErrorString(e)); rc = DSDTM_ERR_HIP; }
+        dsdtm_frame_destroy(ctx, f);
+        return rc;
+    }
+    *out = f;
+    return DSDTM_OK;
+}
+
+extern "C" void dsdtm_frame_destroy(dsdtm_ctx* ctx, dsdtm_frame* f) {
+    if (!f) return;
+    dsdtm_ctx* owner = ctx ? ctx : f->owner;
+    if (owner) { (void)hipSetDevice(owner->device); if (owner->stream) (void)hipStreamSynchronize(owner->stream); }
+    if (f->d) (void)hipFree(f->d);
+    delete f;
+}
+
+extern "C" int dsdtm_sparse_align_frames(dsdtm_ctx* ctx, const dsdtm_frame* ref, const dsdtm_frame* cur,
+                                         const dsdtm_camera* cam, const float* px_xy, const double* bearing,
+                                         const double* p_world, const uint8_t* initial, int n_features,
+                                         const double T_ref_w[12], double T_cur_w[12], const dsdtm_align_params* prm,
+                                         int* n_tracked, dsdtm_align_stats* stats) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!ref || !cur || !cam || !T_ref_w || !T_cur_w || !n_tracked || n_features < 0 ||
+        (n_features > 0 && (!px_xy || !bearing || !p_world || !initial))) {
+        set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID;
+    }
+    if (ref->owner != ctx || cur->owner != ctx) { set_err(ctx, "frame belongs to another context"); return DSDTM_ERR_INVALID; }
+    if (ref->pl.levels != cur->pl.levels) { set_err(ctx, "ref/cur pyramids differ in level count"); return DSDTM_ERR_INVALID; }
+    for (int l = 0; l < ref->pl.levels; ++l)
+        if (ref->pl.w[l] != cur->pl.w[l] || ref->pl.h[l] != cur->pl.h[l]) { set_err(ctx, "ref/cur level %d differ in size", l); return DSDTM_ERR_INVALID; }
+    return sparse_align_one(ctx, ref->pl, nullptr, nullptr, ref->d, cur->d, ref->pitch, cam, px_xy, bearing, p_world, initial,
+                            n_features, T_ref_w, T_cur_w, prm, n_tracked, stats);
 }
 
 // ---- Align2D ------------------------------------------------------------------------------

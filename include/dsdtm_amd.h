@@ -158,6 +158,29 @@ typedef struct dsdtm_batch_desc {
     dsdtm_align_stats* stats; /* n_pairs, or NULL                       */
 } dsdtm_batch_desc;
 
+/* ---- Frames that stay on the device ---------------------------------------------- */
+/*
+ * Replaces: the image part of DSDTM::Frame (include/Frame.h: mvImg_Pyr, built once per frame by
+ *           Frame::ComputeImagePyramid, src/Frame.cpp:74-81) for callers that keep frames between
+ *           Run calls. In tracking every frame is the current frame of one Run and the reference
+ *           frame of the next (src/Tracking.cpp:204,224): with a dsdtm_frame its pyramid crosses
+ *           PCIe once instead of twice, and dsdtm_frame_create_from_image sends level 0 only and
+ *           builds the other levels with the library's bit-exact pyrDown.
+ * A frame belongs to the context that created it and is immutable. dsdtm_frame_destroy waits for
+ * the context's pending work. dsdtm_sparse_align_frames is dsdtm_sparse_align with the two host
+ * pyramids replaced by frames (same results, bit for bit: it runs the same kernel).
+ */
+typedef struct dsdtm_frame dsdtm_frame;
+int dsdtm_frame_create(dsdtm_ctx* ctx, const dsdtm_pyramid* host_pyramid, dsdtm_frame** out);
+int dsdtm_frame_create_from_image(dsdtm_ctx* ctx, const uint8_t* level0, int width, int height, int stride,
+                                  int levels, dsdtm_frame** out);
+void dsdtm_frame_destroy(dsdtm_ctx* ctx, dsdtm_frame* frame);
+int dsdtm_sparse_align_frames(dsdtm_ctx* ctx, const dsdtm_frame* ref, const dsdtm_frame* cur,
+                              const dsdtm_camera* cam, const float* px_xy, const double* bearing,
+                              const double* p_world, const uint8_t* initial, int n_features,
+                              const double T_ref_w[12], double T_cur_w[12],
+                              const dsdtm_align_params* params, int* n_tracked, dsdtm_align_stats* stats);
+
 /* Enqueues the alignment of all pairs on `hip_stream` (a hipStream_t, NULL = default
  * stream). Asynchronous: results are valid after the stream is synchronised. */
 int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* batch,

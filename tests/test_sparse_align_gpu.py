@@ -407,6 +407,45 @@ def test_chained_sequence_like_tracking(gpu_ctx, oracle):
         assert ea < 5e-4 and et < 1e-3, (k, ea, et)
 
 
+def test_device_resident_frames_track_a_sequence(gpu_ctx, oracle):
+    """dsdtm_frame: a frame's pyramid is uploaded once and serves as `cur` of one Run and `ref` of the
+    next (src/Tracking.cpp:201-224). Same kernel as the host entry point: identical results bit for
+    bit; a frame built from level 0 alone (device pyrDown) gives the same pyramid, hence the same pose."""
+    from dsdtm_amd import capi
+    from dsdtm_amd.frame import Frame
+    from dsdtm_amd.sparse_align import Sprase_ImgAlign
+    rng = np.random.default_rng(77)
+    base = cached_scene(width=320, height=240, levels=3, n_patches=150, seed=41, margin=12)
+    tex = synth.make_texture(240, 320, 41)
+    frames_h, frames_d = [], []
+    xi = np.zeros(6)
+    for k in range(4):
+        pyr = synth.build_pyramid(synth.warp_plane(tex, base.cam, synth.se3_exp(xi), base.depth), 3) if k else base.ref_pyr
+        for lst in (frames_h, frames_d):
+            f = Frame(base.cam, pyr, base.T_ref_w)
+            f.set_features(base.px, base.bearing, base.p_world, base.initial)   # the plane's points, as seen from frame 0
+            lst.append(f)
+        xi = xi + np.concatenate([rng.uniform(-0.004, 0.004, 3), rng.uniform(-0.002, 0.002, 3)])
+    # every frame is aligned against frame 0 (whose features are valid), seeded with the previous pose
+    al_h = Sprase_ImgAlign(3, 0, 8, ctx=gpu_ctx)
+    al_d = Sprase_ImgAlign(3, 0, 8, ctx=gpu_ctx, resident_frames=True)
+    for k in range(1, 4):
+        for al, fr in ((al_h, frames_h), (al_d, frames_d)):
+            fr[k].Set_Pose(fr[k - 1].Get_Pose())
+            al.Run(fr[k], fr[0])
+        assert np.array_equal(frames_h[k].Get_Pose(), frames_d[k].Get_Pose()), k
+        assert al_h.last_stats == al_d.last_stats
+    assert frames_d[0]._device_frame.handle is not None                      # uploaded once, reused three times
+    # level 0 only + device pyrDown == the CPU-built pyramid (pyrDown is bit-exact)
+    cur_img = frames_h[3].mvImg_Pyr[0]
+    df = capi.DeviceFrame.from_image(gpu_ctx, cur_img, 3)
+    f = Frame(base.cam, frames_h[3].mvImg_Pyr, frames_h[2].Get_Pose())
+    f._device_frame = df
+    al_d.Run(f, frames_d[0])
+    assert np.array_equal(f.Get_Pose(), frames_h[3].Get_Pose())
+    df.close()
+
+
 def test_batch_launch_is_graph_capturable(gpu_ctx, oracle):
     """The device entry point only enqueues (a memset node + one kernel): it can be captured into a
     hipGraph and replayed — no allocation, no synchronisation in the launch path."""

@@ -20,9 +20,22 @@ for name, kw, prm in [("config2 640x480 N=300", dict(), (4, 0, 10)),
     for i in range(30):
         cur, ref = frames_from_scene(sc)
         t0 = time.perf_counter(); n = al.Run(cur, ref); ts.append(time.perf_counter() - t0)
+    # the same Run with both frames resident on the device (dsdtm_frame): features and poses only cross PCIe
+    alr = Sprase_ImgAlign(*prm, ctx=ctx, resident_frames=True)
+    cur_r, ref_r = frames_from_scene(sc)
+    tr, tu = [], []
+    for i in range(30):
+        seed = frames_from_scene(sc)[0].Get_Pose()
+        cur_r.Set_Pose(seed)
+        t0 = time.perf_counter(); nr = alr.Run(cur_r, ref_r); tr.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); df = capi.DeviceFrame.from_image(ctx, sc.cur_pyr[0], len(sc.cur_pyr)); tu.append(time.perf_counter() - t0)
+        df.close()
+    assert nr == n and np.array_equal(cur_r.Get_Pose(), cur.Get_Pose())
     t0 = time.perf_counter(); To, no, so = oracle_lib.sparse_align(sc, *prm); tc = time.perf_counter() - t0
     ang, dt = synth.pose_error(cur.Get_Pose(), To)
-    print(f"{name}: GPU host call median {np.median(ts[5:])*1e3:.3f} ms (min {min(ts)*1e3:.3f}) | CPU oracle {tc*1e3:.2f} ms | "
+    print(f"{name}: GPU host call median {np.median(ts[5:])*1e3:.3f} ms (min {min(ts)*1e3:.3f}) | resident frames "
+          f"{np.median(tr[5:])*1e3:.3f} ms per Run + {np.median(tu[5:])*1e3:.3f} ms per new frame (level 0 upload + device pyrDown) | "
+          f"CPU oracle {tc*1e3:.2f} ms | "
           f"n={n}/{no} iters={al.last_stats['iters'][:4]} delta={ang:.1e} rad {dt:.1e} m")
 # config 5 second half: 2000 Align2D problems on the 1280x960 current frame
 sc = synth.make_scene(width=1280, height=960, n_patches=2000, margin=60)
