@@ -357,7 +357,8 @@ extern "C" int dsdtm_sparse_align(dsdtm_ctx* ctx, const dsdtm_pyramid* ref, cons
 
 // ---- frames that stay on the device --------------------------------------------------------------
 struct dsdtm_frame {
-    dsdtm_ctx* owner;
+    dsdtm_ctx* owner;    // compared only, never dereferenced through the frame (a frame may outlive its context)
+    int device;
     uint8_t* d;          // packed pyramid (the layout of plan_pyramid), its own allocation
     size_t pitch;
     PackedPyr pl;
@@ -366,7 +367,7 @@ struct dsdtm_frame {
 static int frame_alloc(dsdtm_ctx* ctx, const PackedPyr& pl, dsdtm_frame** out) {
     dsdtm_frame* f = new (std::nothrow) dsdtm_frame();
     if (!f) return DSDTM_ERR_NOMEM;
-    f->owner = ctx; f->pl = pl; f->pitch = align_up(pl.bytes, 256); f->d = nullptr;
+    f->owner = ctx; f->device = ctx->device; f->pl = pl; f->pitch = align_up(pl.bytes, 256); f->d = nullptr;
     if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&f->d, f->pitch) != hipSuccess) {
         set_err(ctx, "hipMalloc of a %zu-byte frame failed", f->pitch);
         delete f;
@@ -429,9 +430,9 @@ extern "C" int dsdtm_frame_create_from_image(dsdtm_ctx* ctx, const uint8_t* leve
 
 extern "C" void dsdtm_frame_destroy(dsdtm_ctx* ctx, dsdtm_frame* f) {
     if (!f) return;
-    dsdtm_ctx* owner = ctx ? ctx : f->owner;
-    if (owner) { (void)hipSetDevice(owner->device); if (owner->stream) (void)hipStreamSynchronize(owner->stream); }
-    if (f->d) (void)hipFree(f->d);
+    (void)ctx;
+    (void)hipSetDevice(f->device);
+    if (f->d) (void)hipFree(f->d);       // hipFree waits for the device's pending work
     delete f;
 }
 

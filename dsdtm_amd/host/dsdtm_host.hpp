@@ -53,13 +53,28 @@ struct Feature {                                  // include/Feature.h:16-36 (+ 
     std::array<double, 3> mMptPose{{0, 0, 0}};    // Mpt->Get_Pose()
 };
 
+namespace detail { inline dsdtm_ctx* ctx(); }
+
 struct Frame {                                    // include/Frame.h (what the path touches)
     CameraPtr mCamera;
     std::vector<Image8> mvImg_Pyr;
     std::vector<Feature> mvFeatures;
     SE3 mT_c2w;
+    dsdtm_frame* mDev = nullptr;                  // the image pyramid, resident on the device (optional)
     const SE3& Get_Pose() const { return mT_c2w; }
     void Set_Pose(const SE3& T) { mT_c2w = T; }   // src/Frame.cpp:167-174
+    // Frame::ComputeImagePyramid (src/Frame.cpp:74-81) on the device: level 0 crosses PCIe once, the
+    // other levels are built by the library's bit-exact pyrDown and stay there for every Run.
+    void ComputeImagePyramidOnDevice(int levels) {
+        if (mDev || mvImg_Pyr.empty()) return;
+        const Image8& l0 = mvImg_Pyr[0];
+        if (dsdtm_frame_create_from_image(detail::ctx(), l0.data.data(), l0.cols, l0.rows, l0.step, levels, &mDev) != DSDTM_OK)
+            throw std::runtime_error(std::string("dsdtm_frame_create_from_image: ") + dsdtm_last_error(detail::ctx()));
+    }
+    Frame() = default;
+    Frame(const Frame&) = delete;
+    Frame& operator=(const Frame&) = delete;
+    ~Frame() { dsdtm_frame_destroy(nullptr, mDev); }
 };
 typedef std::shared_ptr<Frame> FramePtr;
 
@@ -109,9 +124,13 @@ public:
         SE3 Tc = tCurFrame->Get_Pose();
         const dsdtm_align_params prm{mnMaxLevel, mnMinLevel, mnMaxIterators, mnMinfts};
         int n_tracked = 0;
-        const int rc = dsdtm_sparse_align(detail::ctx(), &ref, &cur, &cam, px.data(), bearing.data(), pw.data(),
-                                          ini.data(), n, tRefFrame->Get_Pose().m.data(), Tc.m.data(), &prm,
-                                          &n_tracked, &last_stats);
+        const int rc = (tRefFrame->mDev && tCurFrame->mDev)
+            ? dsdtm_sparse_align_frames(detail::ctx(), tRefFrame->mDev, tCurFrame->mDev, &cam, px.data(), bearing.data(),
+                                        pw.data(), ini.data(), n, tRefFrame->Get_Pose().m.data(), Tc.m.data(), &prm,
+                                        &n_tracked, &last_stats)
+            : dsdtm_sparse_align(detail::ctx(), &ref, &cur, &cam, px.data(), bearing.data(), pw.data(),
+                                 ini.data(), n, tRefFrame->Get_Pose().m.data(), Tc.m.data(), &prm,
+                                 &n_tracked, &last_stats);
         if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_sparse_align: ") + dsdtm_last_error(detail::ctx()));
         if (n < mnMinfts) {                                  // src/Sprase_ImageAlign.cpp:34-38
             std::fprintf(stderr, "Too few features to track\n");

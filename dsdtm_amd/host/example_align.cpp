@@ -65,5 +65,13 @@ int main(int argc, char** argv) {
     for (int l = 0; l < levels; ++l) std::printf(" %d", align.last_stats.iters[l]);
     const bool ok = Feature_Alignment::Align2DGaussNewton(cur->mvImg_Pyr[0], border, patch, 10, px);   // Test/test_Feature_alignment.cpp:78
     std::printf("\nalign2d %d %.9g %.9g\n", ok ? 1 : 0, px[0], px[1]);
+    // the same Run with both frames resident on the device (pyramids built there from level 0)
+    ref->ComputeImagePyramidOnDevice(levels);
+    cur->ComputeImagePyramidOnDevice(levels);
+    cur->Set_Pose(Tc);
+    const int n_resident = align.Run(cur, ref);
+    std::printf("resident %d\npose_resident", n_resident);
+    for (double v : cur->Get_Pose().m) std::printf(" %.17g", v);
+    std::printf("\n");
     return 0;
 }

@@ -167,7 +167,7 @@ typedef struct dsdtm_batch_desc {
  *           PCIe once instead of twice, and dsdtm_frame_create_from_image sends level 0 only and
  *           builds the other levels with the library's bit-exact pyrDown.
  * A frame belongs to the context that created it and is immutable. dsdtm_frame_destroy waits for
- * the context's pending work. dsdtm_sparse_align_frames is dsdtm_sparse_align with the two host
+ * the device's pending work (ctx may be NULL; a frame may be destroyed after its context). dsdtm_sparse_align_frames is dsdtm_sparse_align with the two host
  * pyramids replaced by frames (same results, bit for bit: it runs the same kernel).
  */
 typedef struct dsdtm_frame dsdtm_frame;

@@ -66,3 +66,8 @@ def test_cpp_driver_matches_oracle(tmp_path, oracle):
     oko, pxo = oracle.align2d(img, pb[0], p[0], 10, px0)
     assert bool(int(a2d[1])) == oko
     assert np.allclose([float(a2d[2]), float(a2d[3])], pxo, atol=2e-3)
+    # the second Run of the driver used device-resident frames whose pyramids were built on the device
+    # from level 0: the scene's pyramids are pyrDown chains, pyrDown is bit-exact -> the same pose, bit for bit
+    assert int(out[4].split()[1]) == n
+    Tres = np.array([float(v) for v in out[5].split()[1:]]).reshape(3, 4)
+    assert np.array_equal(Tres, T)
