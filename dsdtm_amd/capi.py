@@ -127,7 +127,13 @@ EXPORTED_SYMBOLS = [
     "dsdtm_reserve", "dsdtm_align2d_batch", "dsdtm_align2d_batch_device",
     "dsdtm_pyrdown_batch_device", "dsdtm_pyrdown", "dsdtm_warp_patches",
     "dsdtm_frame_create", "dsdtm_frame_create_from_image", "dsdtm_frame_destroy", "dsdtm_sparse_align_frames",
+    "dsdtm_detect_cells", "dsdtm_detect_cells_frame",
 ]
+
+
+class DetectParams(C.Structure):
+    _fields_ = [("cell_size", C.c_int32), ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("levels", C.c_int32),
+                ("barrier", C.c_int32), ("detection_threshold", C.c_float)]
 
 _LIB = None
 LIB_NAME = "libdsdtm_amd.so"
@@ -192,6 +198,11 @@ def load():
     lib.dsdtm_sparse_align_frames.restype = C.c_int
     lib.dsdtm_sparse_align_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Camera), fp, dp, dp, u8p, C.c_int,
                                               dp, dp, C.POINTER(AlignParams), C.POINTER(C.c_int), C.POINTER(AlignStats)]
+    ip32 = C.POINTER(C.c_int32)
+    lib.dsdtm_detect_cells.restype = C.c_int
+    lib.dsdtm_detect_cells.argtypes = [C.c_void_p, C.POINTER(Pyramid), u8p, C.POINTER(DetectParams), fp, ip32, ip32, ip32]
+    lib.dsdtm_detect_cells_frame.restype = C.c_int
+    lib.dsdtm_detect_cells_frame.argtypes = [C.c_void_p, C.c_void_p, u8p, C.POINTER(DetectParams), fp, ip32, ip32, ip32]
     _LIB = lib
     return lib
 

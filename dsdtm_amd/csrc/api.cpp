@@ -454,6 +454,99 @@ extern "C" int dsdtm_sparse_align_frames(dsdtm_ctx* ctx, const dsdtm_frame* ref,
                             n_features, T_ref_w, T_cur_w, prm, n_tracked, stats);
 }
 
+// ---- feature detector (per-cell part) ----------------------------------------------------------
+static int detect_cells_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyramid* host_pyr, const uint8_t* dev_pyr,
+                            const uint8_t* grid_occupied, const dsdtm_detect_params* prm, float* cell_score,
+                            int32_t* cell_x, int32_t* cell_y, int32_t* cell_level) {
+    if (!prm || !cell_score || !cell_x || !cell_y || !cell_level) { set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID; }
+    if (prm->cell_size <= 0 || prm->grid_cols <= 0 || prm->grid_rows <= 0 || prm->levels <= 0 || prm->levels > pl.levels ||
+        prm->barrier < 0 || prm->barrier > 254 || !(prm->detection_threshold >= 0.0f) ||
+        (long long)prm->grid_cols * prm->grid_rows > (1 << 24)) {
+        set_err(ctx, "bad detector parameters"); return DSDTM_ERR_INVALID;
+    }
+    for (int l = 0; l < prm->levels; ++l)
+        if (pl.w[l] >= (1 << 14) || pl.h[l] >= (1 << 14)) { set_err(ctx, "level %d larger than 16383 pixels", l); return DSDTM_ERR_INVALID; }
+    const size_t G = (size_t)prm->grid_cols * prm->grid_rows;
+    const size_t pitch = align_up(pl.bytes, 256);
+    size_t o = 0;
+    const size_t o_pyr = o; if (!dev_pyr) o += pitch;
+    const size_t o_occ = o; o += align_up(G, 256);
+    const size_t in_bytes = o;
+    const size_t o_key = o; o += align_up(G * 8, 256);
+    const size_t o_score = o; o += pitch;
+    const size_t total = o;
+    if (int rc = ensure_stage(ctx, total)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    if (!dev_pyr) pack_pyramid(host_pyr, pl, h + o_pyr);
+    if (grid_occupied) memcpy(h + o_occ, grid_occupied, G); else memset(h + o_occ, 0, G);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d + o_key, 0, G * 8, ctx->stream));
+    DetectArgs a;
+    memset(&a, 0, sizeof a);
+    a.pyr = dev_pyr ? dev_pyr : d + o_pyr; a.score = d + o_score; a.cell_key = (unsigned long long*)(d + o_key);
+    a.occupied = d + o_occ;
+    a.cell_size = prm->cell_size; a.grid_cols = prm->grid_cols; a.grid_rows = prm->grid_rows; a.barrier = prm->barrier;
+    a.detection_threshold = prm->detection_threshold;
+    for (int l = 0; l < prm->levels; ++l) { a.lv[l].w = pl.w[l]; a.lv[l].h = pl.h[l]; a.lv[l].stride = pl.w[l]; a.lv[l].off = (uint32_t)pl.off[l]; }
+    HIP_TRY(ctx, detect_launch(a, prm->levels, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + o_key, d + o_key, G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long* keys = (const unsigned long long*)(h + o_key);
+    for (size_t k = 0; k < G; ++k) {
+        if (!keys[k]) { cell_score[k] = prm->detection_threshold; cell_x[k] = 0; cell_y[k] = 0; cell_level[k] = 0; continue; }   // :74
+        const uint32_t bits = (uint32_t)(keys[k] >> 32), order = 0xffffffffu - (uint32_t)keys[k];
+        const int L = (int)(order >> 28), y = (int)((order >> 14) & 0x3fffu), x = (int)(order & 0x3fffu);
+        memcpy(&cell_score[k], &bits, 4);
+        cell_x[k] = x << L; cell_y[k] = y << L; cell_level[k] = L;                                  // :106
+    }
+    return DSDTM_OK;
+}
+
+extern "C" int dsdtm_detect_cells(dsdtm_ctx* ctx, const dsdtm_pyramid* pyr, const uint8_t* grid_occupied,
+                                  const dsdtm_detect_params* prm, float* cell_score, int32_t* cell_x, int32_t* cell_y,
+                                  int32_t* cell_level) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    PackedPyr pl;
+    if (int rc = plan_pyramid(ctx, pyr, &pl)) return rc;
+    return detect_cells_one(ctx, pl, pyr, nullptr, grid_occupied, prm, cell_score, cell_x, cell_y, cell_level);
+}
+
+extern "C" int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame, const uint8_t* grid_occupied,
+                                        const dsdtm_detect_params* prm, float* cell_score, int32_t* cell_x, int32_t* cell_y,
+                                        int32_t* cell_level) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!frame) { set_err(ctx, "NULL frame"); return DSDTM_ERR_INVALID; }
+    if (frame->owner != ctx) { set_err(ctx, "frame belongs to another context"); return DSDTM_ERR_INVALID; }
+    return detect_cells_one(ctx, frame->pl, nullptr, frame->d, grid_occupied, prm, cell_score, cell_x, cell_y, cell_level);
+}
+
+// Diagnostic (tests): the FAST-10 score map and the non-max survivors of ONE 8-bit image, as the detector's
+// two passes produce them on the device. score/keep: width*height bytes each.
+extern "C" int dsdtm_debug_fast10(dsdtm_ctx* ctx, const uint8_t* img, int width, int height, int stride, int barrier,
+                                  uint8_t* score, uint8_t* keep) {
+    if (!ctx || !img || !score || !keep || width <= 0 || height <= 0 || stride < width || width >= (1 << 14) || height >= (1 << 14))
+        return DSDTM_ERR_INVALID;
+    const size_t n = (size_t)width * height, pitch = align_up(n, 256);
+    if (int rc = ensure_stage(ctx, 3 * pitch + 256)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    for (int y = 0; y < height; ++y) memcpy(h + (size_t)y * width, img + (size_t)y * stride, width);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d + pitch, 0, 2 * pitch + 256, ctx->stream));
+    DetectArgs a;
+    memset(&a, 0, sizeof a);
+    a.pyr = d; a.score = d + pitch; a.keep = d + 2 * pitch; a.cell_key = (unsigned long long*)(d + 3 * pitch);
+    a.cell_size = 1 << 20; a.grid_cols = 1; a.grid_rows = 1; a.barrier = barrier; a.detection_threshold = 3.0e38f;
+    a.lv[0].w = width; a.lv[0].h = height; a.lv[0].stride = width; a.lv[0].off = 0;
+    HIP_TRY(ctx, detect_launch(a, 1, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h, d + pitch, 2 * pitch, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(score, h, n);
+    memcpy(keep, h + pitch, n);
+    return DSDTM_OK;
+}
+
 // ---- Align2D ------------------------------------------------------------------------------
 extern "C" int dsdtm_align2d_batch_device(dsdtm_ctx* ctx, const dsdtm_image_desc* cur, const uint8_t* patch_border,
                                           const uint8_t* patch, const int32_t* level, double* px_xy,

@@ -59,6 +59,19 @@ hipError_t sparse_align_take_timeout_flag(unsigned* flag);   // device-side hand
 int sparse_align_occupancy(int variant);   // occupancy API answer (workgroups per CU)
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream);
 
+// Feature detector (per-cell part): FAST-10 score map, then non-max + Shi-Tomasi + best corner per cell.
+struct DetectArgs {
+    const uint8_t* pyr;            // packed pyramid (device)
+    uint8_t* score;                // score maps, same layout as the pyramid
+    unsigned long long* cell_key;  // grid_cols*grid_rows keys, zeroed before the launch
+    const uint8_t* occupied;       // grid_cols*grid_rows, may be null
+    uint8_t* keep;                 // diagnostic (dsdtm_debug_fast10): 1 where a corner survives the non-max step; else null
+    int cell_size, grid_cols, grid_rows, barrier;
+    float detection_threshold;
+    LevelGeom lv[DSDTM_MAX_LEVELS];
+};
+hipError_t detect_launch(const DetectArgs& args, int levels, hipStream_t stream);
+
 // Align2D: one wavefront per feature.
 struct A2DKernelArgs {
     const uint8_t* cur_pyr;       // packed pyramid (device)

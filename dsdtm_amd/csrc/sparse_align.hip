@@ -22,7 +22,8 @@
 //    MACs. H changes between iterations only when the set of visible patches does: every 16-lane
 //    row caches its H partial with the visibility ballot it was built for; the all-visible H of a
 //    level is published right after the precompute and factorised by the solver WHILE the first
-//    pass runs, later iterations only re-run the substitution on the cached LDLT factors.
+//    pass runs — into H^+ (one lane-parallel substitution of the six unit vectors), so that every
+//    iteration's solve is the matrix-vector product x = H^+ b.
 //  * the 7x7 (ref) u8 footprints are gathered with one dwordx3 load per row straight from the packed
 //    pyramid, all seven in flight together (a scattered wave-load costs ~64 L1 tag lookups whatever
 //    its width, and every row is its own cold cache line). The 5x5 (cur) footprint of a patch moves
@@ -31,8 +32,10 @@
 //    floor position leaves it (the CU's 32 KB L1 cannot hold the 1500 lines a pair-level touches).
 //  * reductions: DPP row rotations inside 16-lane rows (no LDS traffic), one LDS slot per row; the
 //    slot's SOLVER wave (owns no patches, so its registers and the patch registers never share live
-//    ranges) sums the partials lane-parallel, runs the pivoted-LDLT substitution, a series SE(3) exp
-//    and the accept/revert logic, and publishes R|t + a control word through LDS.
+//    ranges) sums the partials lane-parallel, computes x = H^+ b, a series SE(3) exp and the
+//    accept/revert logic, and publishes R|t + a control word through LDS. In an idle window of the
+//    current pair it also stages the next pair's prologue (pose block in LDS, feature lines warmed
+//    with LDS-DMA), so that a slot switches pairs without dependent HBM round trips.
 //  * hand-over between the waves of a slot uses monotonic LDS counters (B0/BH/B1/B2/ACK below), not
 //    s_barrier, so the slots of a workgroup run independently: one slot's solve overlaps the
 //    other's pass.

@@ -21,6 +21,8 @@ class Config:
         "Camera.MinPyraLevels": 0,
         "Camera.CellSize": 25,         # :28
         "Optimization.MaxIter": 8,     # src/Tracking.cpp:24
+        "Camera.Max_fts": 200,         # src/Feature_detection.cpp:14 (Config/EuRoc.yaml:27)
+        "Camera.Min_dist": 30,         # src/Frame.cpp:52 (Config/EuRoc.yaml:28)
     }
 
     @classmethod

@@ -158,6 +158,30 @@ typedef struct dsdtm_batch_desc {
     dsdtm_align_stats* stats; /* n_pairs, or NULL                       */
 } dsdtm_batch_desc;
 
+/* ---- Feature_detector::detect (per-cell part) ------------------------------------- */
+/*
+ * Replaces: the image part of void Feature_detector::detect(Frame*, const double detection_threshold,
+ *           const bool) (include/Feature_detection.h:57, src/Feature_detection.cpp:75-108) with the
+ *           vendored Thirdparty/fast calls it makes (fast_corner_detect_10_sse2, fast_corner_score_10,
+ *           fast_nonmax_3x3) and Feature_detector::shiTomasiScore (:157-198): for every cell of the
+ *           detector's grid, the FAST-10 corner (non-maximum suppressed, any pyramid level) with the
+ *           best Shi-Tomasi score above detection_threshold, skipping occupied cells.
+ * cell_score[k] = detection_threshold and cell_x/y/level[k] = 0 where no corner qualifies — exactly the
+ * `corners` vector the reference then sorts and walks (:110-150; that order-dependent rest — mask
+ * discs, Max_fts cap — is host bookkeeping over <= grid_cols*grid_rows entries, see
+ * dsdtm_amd/feature_detection.py and INTEGRATION.md). cell_x/cell_y are level-0 pixels (x * 2^level).
+ */
+typedef struct dsdtm_detect_params {
+    int32_t cell_size;            /* Camera.CellSize (src/Feature_detection.cpp:12) */
+    int32_t grid_cols, grid_rows; /* ceil(width / cell_size), ceil(height / cell_size) (:18-19) */
+    int32_t levels;               /* Camera.MaxPyraLevels (:13); <= the pyramid's level count */
+    int32_t barrier;              /* FAST barrier, 20 in the reference (:82,:91) */
+    float detection_threshold;    /* >= 0 */
+} dsdtm_detect_params;
+int dsdtm_detect_cells(dsdtm_ctx* ctx, const dsdtm_pyramid* host_pyramid, const uint8_t* grid_occupied,
+                       const dsdtm_detect_params* params, float* cell_score, int32_t* cell_x,
+                       int32_t* cell_y, int32_t* cell_level);
+
 /* ---- Frames that stay on the device ---------------------------------------------- */
 /*
  * Replaces: the image part of DSDTM::Frame (include/Frame.h: mvImg_Pyr, built once per frame by
@@ -180,6 +204,11 @@ int dsdtm_sparse_align_frames(dsdtm_ctx* ctx, const dsdtm_frame* ref, const dsdt
                               const double* p_world, const uint8_t* initial, int n_features,
                               const double T_ref_w[12], double T_cur_w[12],
                               const dsdtm_align_params* params, int* n_tracked, dsdtm_align_stats* stats);
+/* dsdtm_detect_cells on a device-resident frame (keyframe creation detects on the frame that was just tracked) */
+int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame, const uint8_t* grid_occupied,
+                             const dsdtm_detect_params* params, float* cell_score, int32_t* cell_x,
+                             int32_t* cell_y, int32_t* cell_level);
+
 
 /* Enqueues the alignment of all pairs on `hip_stream` (a hipStream_t, NULL = default
  * stream). Asynchronous: results are valid after the stream is synchronised. */

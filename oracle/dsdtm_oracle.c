@@ -793,3 +793,141 @@ int oracle_warp_patches(const dsdtm_pyramid* kf_pyr, int n_kf, const dsdtm_camer
     }
     return DSDTM_OK;
 }
+
+
+/* ===================================================================================
+ * Feature_detector::detect — reference src/Feature_detection.cpp:69-154 and the vendored
+ * Thirdparty/fast it calls (:79-92). SURVEY §8(f)4.
+ *
+ * The FAST part is a restatement of the *published definition* the vendored, mechanically
+ * generated sources implement (fast_10.cpp / faster_corner_10_sse.cpp: a pixel is a corner at
+ * barrier b iff 10 contiguous pixels of the 16-pixel Bresenham circle of radius 3 are all
+ * > p + b or all < p - b; fast_10_score.cpp: the largest such b; nonmax_3x3.cpp: suppressed iff
+ * one of the 8 neighbours is a corner with score >= its own). Unlike the rest of this file it IS
+ * pinned: Thirdparty/fast has no external dependency, `make -C oracle ref` compiles the reference's
+ * own sources into oracle/_ref/libfast_ref.so, and tests/test_detector_cpu.py holds this
+ * restatement to it corner by corner (and to committed fixtures where the reference is absent).
+ * =================================================================================== */
+static const int FAST_RING[16][2] = {   /* (dx, dy) in the order of fast_10_score.cpp:3146-3163 */
+    {0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+    {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+/* max over the 16 arcs of 10 contiguous ring pixels of the smallest difference on the arc, for the
+ * brighter (+) and the darker (-) polarity: the pixel is a corner at barrier b iff that value > b */
+static int fast10_margin(const uint8_t* p, int stride) {
+    int d[16];
+    const int c = *p;
+    for (int i = 0; i < 16; ++i) d[i] = (int)p[FAST_RING[i][1] * stride + FAST_RING[i][0]] - c;
+    int best = -256;
+    for (int s = 0; s < 16; ++s) {
+        int mb = 256, md = 256;
+        for (int k = 0; k < 10; ++k) {
+            const int v = d[(s + k) & 15];
+            if (v < mb) mb = v;
+            if (-v < md) md = -v;
+        }
+        if (mb > best) best = mb;
+        if (md > best) best = md;
+    }
+    return best;
+}
+
+void oracle_fast10(const uint8_t* img, int w, int h, int stride, int barrier, uint8_t* score, uint8_t* keep) {
+    memset(score, 0, (size_t)w * h);
+    memset(keep, 0, (size_t)w * h);
+    /* faster_corner_10_sse.cpp:187-203: plain detector below 22 columns, nothing below 7 rows; both
+     * scan rows 3..h-4 and columns 3..w-4 */
+    if (h < 7 || w < 7) return;
+    for (int y = 3; y < h - 3; ++y)
+        for (int x = 3; x < w - 3; ++x) {
+            const int m = fast10_margin(img + (size_t)y * stride + x, stride);
+            if (m > barrier) score[(size_t)y * w + x] = (uint8_t)(m - 1);     /* fast_10_score.cpp:22-3140 */
+        }
+    /* nonmax_3x3.cpp:47-106: every comparison is `neighbour score >= own score` */
+    for (int y = 3; y < h - 3; ++y)
+        for (int x = 3; x < w - 3; ++x) {
+            const int s = score[(size_t)y * w + x];
+            if (!s) continue;
+            int sup = 0;
+            for (int dy = -1; dy <= 1 && !sup; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (!dx && !dy) continue;
+                    const int n = score[(size_t)(y + dy) * w + (x + dx)];
+                    if (n && n >= s) { sup = 1; break; }
+                }
+            keep[(size_t)y * w + x] = (uint8_t)!sup;
+        }
+}
+
+int oracle_fast10_list(const uint8_t* img, int w, int h, int stride, int barrier, int32_t* out, int cap) {
+    uint8_t* score = (uint8_t*)malloc((size_t)w * h);
+    uint8_t* keep = (uint8_t*)malloc((size_t)w * h);
+    oracle_fast10(img, w, h, stride, barrier, score, keep);
+    int n = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            if (!score[(size_t)y * w + x]) continue;
+            if (n < cap) {
+                out[4 * n] = x; out[4 * n + 1] = y; out[4 * n + 2] = score[(size_t)y * w + x];
+                out[4 * n + 3] = keep[(size_t)y * w + x];
+            }
+            ++n;
+        }
+    free(score); free(keep);
+    return n;
+}
+
+/* Feature_detector::shiTomasiScore, src/Feature_detection.cpp:157-198. The gradient sums are exact
+ * in float (integers < 2^24); the divisions by 2.0*box_area are double divisions by 128 (exact);
+ * the last line mixes float operands with the double constant 0.5 and calls the float overload of
+ * sqrt that <cmath> puts in scope for a float argument (assumption: the reference translation unit
+ * cannot be built here — OpenCV). */
+float oracle_shi_tomasi(const uint8_t* img, int w, int h, int stride, int u, int v) {
+    float dXX = 0.0f, dYY = 0.0f, dXY = 0.0f;
+    const int halfbox_size = 4, box_size = 8, box_area = 64;
+    const int x_min = u - halfbox_size, x_max = u + halfbox_size, y_min = v - halfbox_size, y_max = v + halfbox_size;
+    if (x_min < 1 || x_max >= w - 1 || y_min < 1 || y_max >= h - 1) return 0.0f;      /* :173 */
+    for (int y = y_min; y < y_max; ++y) {
+        const uint8_t* l = img + (size_t)stride * y + x_min - 1;
+        const uint8_t* r = img + (size_t)stride * y + x_min + 1;
+        const uint8_t* t = img + (size_t)stride * (y - 1) + x_min;
+        const uint8_t* b = img + (size_t)stride * (y + 1) + x_min;
+        for (int x = 0; x < box_size; ++x, ++l, ++r, ++t, ++b) {
+            const float dx = (float)(*r - *l);
+            const float dy = (float)(*b - *t);
+            dXX += dx * dx; dYY += dy * dy; dXY += dx * dy;
+        }
+    }
+    dXX = (float)(dXX / (2.0 * box_area));
+    dYY = (float)(dYY / (2.0 * box_area));
+    dXY = (float)(dXY / (2.0 * box_area));
+    const float tr = dXX + dYY;
+    const float disc = tr * tr - 4 * (dXX * dYY - dXY * dXY);
+    return (float)(0.5 * (tr - sqrtf(disc)));
+}
+
+void oracle_detect_cells(const dsdtm_pyramid* pyr, int levels, int cell_size, int grid_cols, int grid_rows,
+                         const uint8_t* grid_occupied, double detection_threshold, int barrier,
+                         float* cell_score, int32_t* cell_x, int32_t* cell_y, int32_t* cell_level) {
+    const int G = grid_cols * grid_rows;
+    for (int k = 0; k < G; ++k) { cell_score[k] = (float)detection_threshold; cell_x[k] = 0; cell_y[k] = 0; cell_level[k] = 0; }   /* :74 */
+    for (int L = 0; L < levels; ++L) {                                              /* :76 */
+        const int scale = 1 << L, w = pyr->width[L], h = pyr->height[L], st = pyr->stride[L];
+        const uint8_t* img = pyr->data[L];
+        uint8_t* score = (uint8_t*)malloc((size_t)w * h);
+        uint8_t* keep = (uint8_t*)malloc((size_t)w * h);
+        oracle_fast10(img, w, h, st, barrier, score, keep);                         /* :79-92 */
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                if (!keep[(size_t)y * w + x]) continue;
+                const int k = ((y * scale) / cell_size) * grid_cols + (x * scale) / cell_size;      /* :97-98 */
+                if (k < 0 || k >= G) continue;
+                if (grid_occupied && grid_occupied[k]) continue;                    /* :100 */
+                const float sc = oracle_shi_tomasi(img, w, h, st, x, y);            /* :103 */
+                if (sc > cell_score[k]) {                                           /* :104-107 */
+                    cell_score[k] = sc; cell_x[k] = x * scale; cell_y[k] = y * scale; cell_level[k] = L;
+                }
+            }
+        free(score); free(keep);
+    }
+}

@@ -61,6 +61,22 @@ int oracle_warp_patches(const dsdtm_pyramid* kf_pyr, int n_kf, const dsdtm_camer
                         double* affine, int32_t* search_level,
                         uint8_t* patch_border, uint8_t* patch);
 
+/* --- Feature_detector::detect (src/Feature_detection.cpp:69-154), SURVEY §8(f)4 ---------------- */
+/* FAST-10 corners of one 8-bit image as the reference obtains them (fast_corner_detect_10_sse2 +
+ * fast_corner_score_10 + fast_nonmax_3x3, Thirdparty/fast): score[y*w+x] = 0 where (x,y) is not a
+ * corner at `barrier`, else the corner score (largest barrier at which it still is one, >= barrier);
+ * keep[y*w+x] = 1 where the corner survives the 3x3 non-maximum suppression. */
+void oracle_fast10(const uint8_t* img, int w, int h, int stride, int barrier, uint8_t* score, uint8_t* keep);
+/* the same as a list in the reference's raster order: (x, y, score, is_nonmax) quadruples; returns the count */
+int oracle_fast10_list(const uint8_t* img, int w, int h, int stride, int barrier, int32_t* out, int cap);
+/* Feature_detector::shiTomasiScore (:157-198) */
+float oracle_shi_tomasi(const uint8_t* img, int w, int h, int stride, int u, int v);
+/* The per-cell part of detect() (:75-104): best Shi-Tomasi corner of every grid cell over all pyramid
+ * levels; cell_score[k] stays `detection_threshold` (x = y = level = 0) where no corner beats it. */
+void oracle_detect_cells(const dsdtm_pyramid* pyr, int levels, int cell_size, int grid_cols, int grid_rows,
+                         const uint8_t* grid_occupied, double detection_threshold, int barrier,
+                         float* cell_score, int32_t* cell_x, int32_t* cell_y, int32_t* cell_level);
+
 /* --- building blocks exported for unit tests ------------------------------------ */
 /* SE3 as Sophus stores it: unit quaternion (w,x,y,z) + translation. */
 typedef struct oracle_se3 { double q[4]; double t[3]; } oracle_se3;

@@ -53,8 +53,69 @@ def load(native: bool = False):
     lib.oracle_sparse_align_batch_timed.restype = C.c_double
     lib.oracle_sparse_align_batch_timed.argtypes = [C.POINTER(capi.BatchDesc), C.POINTER(capi.Camera),
                                                     C.POINTER(capi.AlignParams), C.c_int]
+    ip32 = C.POINTER(C.c_int32)
+    lib.oracle_fast10_list.restype = C.c_int
+    lib.oracle_fast10_list.argtypes = [capi.u8p, C.c_int, C.c_int, C.c_int, C.c_int, ip32, C.c_int]
+    lib.oracle_shi_tomasi.restype = C.c_float
+    lib.oracle_shi_tomasi.argtypes = [capi.u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.oracle_detect_cells.restype = None
+    lib.oracle_detect_cells.argtypes = [C.POINTER(capi.Pyramid), C.c_int, C.c_int, C.c_int, C.c_int, capi.u8p, C.c_double,
+                                        C.c_int, C.POINTER(C.c_float), ip32, ip32, ip32]
     _LIBS[key] = lib
     return lib
+
+
+# ---- the reference's own FAST build (oracle/_ref/libfast_ref.so, `make -C oracle ref`) ------------
+def fast_ref_lib():
+    """The vendored Thirdparty/fast of the reference compiled from its own sources (only where
+    /root/reference exists, or where the prebuilt file travelled); None otherwise."""
+    path = os.path.join(_ORACLE_DIR, "_ref", "libfast_ref.so")
+    if not os.path.exists(path):
+        if not os.path.isdir("/root/reference/Thirdparty/fast/src"):
+            return None
+        subprocess.run(["make", "-s", "-C", _ORACLE_DIR, "ref"], check=True)
+    if "fast_ref" not in _LIBS:
+        lib = C.CDLL(path)
+        lib.fast_ref_detect.restype = C.c_int
+        lib.fast_ref_detect.argtypes = [capi.u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]
+        _LIBS["fast_ref"] = lib
+    return _LIBS["fast_ref"]
+
+
+def _fast_list(fn, img, barrier):
+    img = np.asarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((w * h, 4), np.int32)
+    n = fn(img.ctypes.data_as(capi.u8p), w, h, img.strides[0], barrier, out.ctypes.data_as(C.POINTER(C.c_int32)), w * h)
+    return out[:n].copy()
+
+
+def fast10_list(img, barrier=20):
+    """(x, y, score, is_nonmax) rows in raster order — oracle restatement."""
+    return _fast_list(load().oracle_fast10_list, img, barrier)
+
+
+def fast10_list_reference(img, barrier=20):
+    lib = fast_ref_lib()
+    return None if lib is None else _fast_list(lib.fast_ref_detect, img, barrier)
+
+
+def shi_tomasi(img, u, v):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    return float(load().oracle_shi_tomasi(img.ctypes.data_as(capi.u8p), img.shape[1], img.shape[0], img.strides[0], u, v))
+
+
+def detect_cells(img_pyr, levels, cell_size, grid_cols, grid_rows, occupied, detection_threshold, barrier=20):
+    pyr, keep = capi.pyramid_struct(img_pyr)
+    G = grid_cols * grid_rows
+    score = np.zeros(G, np.float32)
+    cx, cy, cl = np.zeros(G, np.int32), np.zeros(G, np.int32), np.zeros(G, np.int32)
+    occ = np.ascontiguousarray(occupied, np.uint8) if occupied is not None else np.zeros(G, np.uint8)
+    ip = C.POINTER(C.c_int32)
+    load().oracle_detect_cells(C.byref(pyr), levels, cell_size, grid_cols, grid_rows, occ.ctypes.data_as(capi.u8p),
+                               float(detection_threshold), barrier, score.ctypes.data_as(C.POINTER(C.c_float)),
+                               cx.ctypes.data_as(ip), cy.ctypes.data_as(ip), cl.ctypes.data_as(ip))
+    return score, cx, cy, cl
 
 
 def _dp(a):

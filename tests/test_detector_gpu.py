@@ -1,0 +1,109 @@
+"""GPU side of the feature detector: the HIP passes against the (reference-pinned) oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dsdtm_amd import capi, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx():
+    return capi.default_context(0)
+
+
+def gpu_fast10(ctx, img, barrier):
+    img = np.asarray(img, np.uint8)
+    h, w = img.shape
+    score, keep = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)
+    f = ctx.lib.dsdtm_debug_fast10
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, capi.u8p, C.c_int, C.c_int, C.c_int, C.c_int, capi.u8p, capi.u8p]
+    ctx.check(f(ctx.handle, img.ctypes.data_as(capi.u8p), w, h, img.strides[0], barrier, score.ctypes.data_as(capi.u8p),
+                keep.ctypes.data_as(capi.u8p)))
+    ys, xs = np.nonzero(score)
+    return np.stack([xs, ys, score[ys, xs], keep[ys, xs]], 1).astype(np.int32)
+
+
+def test_fast_maps_equal_the_reference_vectors(gpu_ctx):
+    """Score map + non-max survivors of the device passes, corner by corner, against the vectors the
+    reference's own FAST sources produced (tests/golden/fast_reference.npz)."""
+    fx = np.load(H.golden_path("fast_reference.npz"))
+    assert np.array_equal(gpu_fast10(gpu_ctx, fx["test1"], 75), fx["test1_b75"]) and len(fx["test1_b75"]) == 167
+    for name in ("test1", "noise", "lowc", "tex", "narrow"):
+        assert np.array_equal(gpu_fast10(gpu_ctx, fx[name], 20), fx[name + "_b20"]), name
+
+
+def test_fast_maps_equal_the_oracle_on_odd_shapes(gpu_ctx, oracle):
+    rng = np.random.default_rng(8)
+    for shape in [(7, 22), (6, 40), (33, 257), (61, 300), (480, 640)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        img[img < 25] = 0; img[img > 230] = 255
+        for barrier in (20, 3):
+            assert np.array_equal(gpu_fast10(gpu_ctx, img, barrier), oracle.fast10_list(img, barrier)), (shape, barrier)
+    big = rng.integers(0, 256, (50, 120), dtype=np.uint8)
+    assert np.array_equal(gpu_fast10(gpu_ctx, big[:, 7:99], 20), oracle.fast10_list(big[:, 7:99], 20))     # strided input
+
+
+def _cells(ctx, det, frame, thr):
+    return det.detect_cells(frame, thr)
+
+
+@pytest.mark.parametrize("size,levels", [((640, 480), 5), ((320, 240), 3), ((752, 480), 4)])
+def test_detect_cells_equal_the_oracle(gpu_ctx, oracle, size, levels):
+    from dsdtm_amd.feature_detection import Feature_detector
+    from dsdtm_amd.frame import Config, Frame
+    w, h = size
+    if size == (752, 480):
+        img = np.load(H.golden_path("fast_reference.npz"))["test1"]          # the reference's own test image
+    else:
+        img = np.clip(np.rint(synth.make_texture(h, w, w + levels)), 0, 255).astype(np.uint8)
+    pyr = synth.build_pyramid(img, levels)
+    old = Config.Get("Camera.MaxPyraLevels")
+    Config.Set("Camera.MaxPyraLevels", levels)
+    try:
+        det = Feature_detector(w, h, ctx=gpu_ctx)
+        fr = Frame(synth.Camera.tum(w, h), pyr)
+        rng = np.random.default_rng(w)
+        det.Set_ExistingFeatures(np.stack([rng.uniform(0, w - 1, 30), rng.uniform(0, h - 1, 30)], 1))
+        occ = det.mvGrid_occupy.copy()
+        for thr in (5.0, 40.0):
+            got = _cells(gpu_ctx, det, fr, thr)
+            want = oracle.detect_cells(pyr, levels, det.mCell_size, det.mGrid_cols, det.mGrid_rows, occ, thr)
+            for g, wv, name in zip(got, want, ("score", "x", "y", "level")):
+                assert np.array_equal(g, wv), (name, thr, np.nonzero(g != wv)[0][:5])
+            assert (got[0][occ == 1] == np.float32(thr)).all() and (got[0] > thr).sum() > 20
+        # a device-resident frame (pyramid built on the device from level 0) gives the same cells
+        fr._device_frame = capi.DeviceFrame.from_image(gpu_ctx, img, levels)
+        got_f = _cells(gpu_ctx, det, fr, 5.0)
+        want = oracle.detect_cells(pyr, levels, det.mCell_size, det.mGrid_cols, det.mGrid_rows, occ, 5.0)
+        assert all(np.array_equal(g, wv) for g, wv in zip(got_f, want))
+        fr._device_frame.close()
+    finally:
+        Config.Set("Camera.MaxPyraLevels", old)
+
+
+def test_detect_like_keyframe_creation(gpu_ctx, oracle):
+    """Feature_detector::detect end to end (src/Tracking.cpp:416: detect(frame, 5.0) on a frame that
+    already has tracked features) against the sequential restatement on oracle cells."""
+    from dsdtm_amd.feature_detection import Feature_detector
+    from dsdtm_amd.frame import Config, Frame
+    from tests import detector_restatement as R
+    img = np.clip(np.rint(synth.make_texture(480, 640, 99)), 0, 255).astype(np.uint8)
+    pyr = synth.build_pyramid(img, 5)
+    det = Feature_detector(640, 480, ctx=gpu_ctx)
+    fr = Frame(synth.Camera.tum(640, 480), pyr)
+    rng = np.random.default_rng(1)
+    ex = np.stack([rng.uniform(20, 620, 60), rng.uniform(20, 460, 60)], 1).astype(np.float32)
+    has = (rng.random(60) < 0.8).astype(np.uint8)
+    fr.set_features(ex, np.zeros((60, 3)), np.zeros((60, 3)), has)
+    det.Set_ExistingFeatures(ex)
+    cells = oracle.detect_cells(pyr, 5, det.mCell_size, det.mGrid_cols, det.mGrid_rows, det.mvGrid_occupy.copy(), 5.0)
+    want = R.detect(cells, 640, 480, det.mCell_size, det.mMax_fts, ex, has, int(Config.Get("Camera.Min_dist")))
+    n_new = det.detect(fr, 5.0)
+    got = [(int(fr.px[60 + i, 0]), int(fr.px[60 + i, 1]), int(fr.level[60 + i])) for i in range(n_new)]
+    assert got == want and 20 < n_new <= det.mMax_fts - 60
+    assert fr.n_features == 60 + n_new
