@@ -51,3 +51,21 @@ t0 = time.perf_counter(); co, pxo = oracle_lib.align2d_batch(sc.cur_pyr, pb, p, 
 same = cg == co
 print(f"config5 Align2D x2000: GPU host call median {np.median(ts[3:])*1e3:.3f} ms | CPU oracle {tc*1e3:.2f} ms | flags equal {same.mean():.4f} "
       f"max|dpx| {np.abs(pxg-pxo)[same & co].max():.2e} converged {co.mean():.3f}")
+# keyframe creation: Feature_detector::detect on a 640x480, 5-level frame (src/Tracking.cpp:416)
+from dsdtm_amd.feature_detection import Feature_detector
+from dsdtm_amd.frame import Frame
+img = np.clip(np.rint(synth.make_texture(480, 640, 99)), 0, 255).astype(np.uint8)
+pyr5 = synth.build_pyramid(img, 5)
+det = Feature_detector(640, 480, ctx=ctx)
+fr = Frame(synth.Camera.tum(640, 480), pyr5)
+th, tf = [], []
+for i in range(20):
+    t0 = time.perf_counter(); cells = det.detect_cells(fr, 5.0); th.append(time.perf_counter() - t0)
+fr._device_frame = capi.DeviceFrame.from_pyramid(ctx, pyr5)
+for i in range(20):
+    t0 = time.perf_counter(); cells_f = det.detect_cells(fr, 5.0); tf.append(time.perf_counter() - t0)
+t0 = time.perf_counter(); want = oracle_lib.detect_cells(pyr5, 5, det.mCell_size, det.mGrid_cols, det.mGrid_rows, None, 5.0); tc = time.perf_counter() - t0
+t0 = time.perf_counter(); n_new = det.detect(fr, 5.0); td = time.perf_counter() - t0
+same = all(np.array_equal(a, b) for a, b in zip(cells, want)) and all(np.array_equal(a, b) for a, b in zip(cells_f, want))
+print(f"detector 640x480 x5 levels: per-cell corners GPU host call median {np.median(th[3:])*1e3:.3f} ms | resident frame "
+      f"{np.median(tf[3:])*1e3:.3f} ms | CPU oracle {tc*1e3:.1f} ms | equal {same} | full detect() incl. host bookkeeping {td*1e3:.2f} ms, {n_new} features")
