@@ -3,8 +3,9 @@
  * uses them) of DSDTM's sparse photometric alignment path.
  *
  * TEST INFRASTRUCTURE ONLY — see dsdtm_oracle.h. PARITY UNPINNED by the reference (it
- * holds no golden vectors for this path); every function cites the reference lines it
- * follows so the restatement can be audited by reading.
+ * holds no golden vectors for this path), except the FAST-10 detector part at the end of this
+ * file, which is pinned to a build of the reference's own vendored sources; every function
+ * cites the reference lines it follows so the restatement can be audited by reading.
  *
  * Build: see oracle/Makefile (-O2, no -ffast-math, -ffp-contract=off: the reference is
  * built with -msse..-mssse3 only (CMakeLists.txt:5-8), i.e. without FMA contraction).

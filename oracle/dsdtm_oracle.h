@@ -12,6 +12,10 @@
  * none present; see oracle/Makefile `_ref` note). This restatement follows the reference
  * source line by line (citations at each function) and is cross-checked by an
  * independent numpy restatement and analytic ground truth in tests/.
+ * EXCEPTION (pinned): the FAST-10 part of the feature detector (oracle_fast10*) — the reference
+ * vendors Thirdparty/fast, which builds from its own sources (`make -C oracle ref` ->
+ * oracle/_ref/libfast_ref.so); the restatement is held to that build and to vectors it produced
+ * (tests/golden/fast_reference.npz, incl. the reference test's known answer of 167 corners).
  *
  * Third-party arithmetic restated from its published algorithm (not under /root/reference):
  *   Sophus (non-templated SE3/SO3; README.md:6 says "Sophus 1.0.0", version unpinned)
