@@ -4,12 +4,15 @@
 //   DSDTM::Sprase_ImgAlign      (reference include/Sprase_ImageAlign.h:20-69)
 //   DSDTM::Feature_Alignment    (reference include/Feature_alignment.h:23-99, the static
 //                                Align2DGaussNewton and its batch form)
+//   DSDTM::Feature_detector     (reference include/Feature_detection.h:35-75)
 // over dependency-free stand-ins for the data the path reads (Frame / Feature / Camera / SE3): the
 // reference's own types need OpenCV, Eigen and Sophus, which this build image does not have
 // (INTEGRATION.md shows the adapter against the real types). All compute happens in
 // libdsdtm_amd.so (HIP, gfx950); there is no CPU path here.
 #pragma once
+#include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <memory>
@@ -26,6 +29,10 @@ static const int mHalf_PatchSize = 4;   // include/Feature_alignment.h:21
 // Config::Get<int>("Camera.Min_fts") etc. — only the keys the path reads
 struct Config {
     static int& Min_fts() { static int v = 15; return v; }            // src/Sprase_ImageAlign.cpp:14
+    static int& CellSize() { static int v = 25; return v; }           // src/Feature_detection.cpp:12
+    static int& MaxPyraLevels() { static int v = 5; return v; }       // :13
+    static int& Max_fts() { static int v = 200; return v; }           // :14
+    static int& Min_dist() { static int v = 30; return v; }           // src/Frame.cpp:52
 };
 
 struct Image8 {                                   // cv::Mat CV_8UC1
@@ -175,6 +182,93 @@ public:
 
 private:
     CameraPtr mCam;
+};
+
+// cv::circle(img, center, radius, 0, -1) for an 8-bit mask: OpenCV 2.4 drawing.cpp Circle() (midpoint
+// algorithm, filled by horizontal spans, clipped to the image) — the detector's and the tracker's
+// mask painting (src/Feature_detection.cpp:143, src/Frame.cpp:291)
+inline void FillCircle(Image8& mask, int cx, int cy, int radius, uint8_t value) {
+    auto hline = [&](int y, int x1, int x2) {
+        if (y < 0 || y >= mask.rows) return;
+        x1 = std::max(x1, 0); x2 = std::min(x2, mask.cols - 1);
+        for (int x = x1; x <= x2; ++x) mask.data[(size_t)y * mask.step + x] = value;
+    };
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        hline(cy - dy, cx - dx, cx + dx); hline(cy + dy, cx - dx, cx + dx);
+        hline(cy - dx, cx - dy, cx + dy); hline(cy + dx, cx - dy, cx + dy);
+        dy++; err += plus; plus += 2;
+        const int m = (err <= 0) - 1;
+        err -= minus & m; dx += m; minus -= m & 2;
+    }
+}
+
+struct Corner {                                   // include/Feature_detection.h:19-33
+    int x, y, level;
+    float score, angle;
+    Corner(int _x, int _y, float _score, int _level, float _angle) : x(_x), y(_y), level(_level), score(_score), angle(_angle) {}
+    bool operator<(const Corner& c) const { return c.score < score; }
+};
+typedef std::vector<Corner> Corners;
+
+class Feature_detector {
+public:
+    Feature_detector(int width, int height)           // src/Feature_detection.cpp:10-21 (Camera.width / Camera.height)
+        : mImg_height(height), mImg_width(width), mCell_size(Config::CellSize()), mPyr_levels(Config::MaxPyraLevels()),
+          mMax_fts(Config::Max_fts()) {
+        mGrid_rows = (int)std::ceil(1.0 * mImg_height / mCell_size);
+        mGrid_cols = (int)std::ceil(1.0 * mImg_width / mCell_size);
+        mvGrid_occupy.assign((size_t)mGrid_rows * mGrid_cols, 0);
+    }
+
+    void Set_ExistingFeatures(const std::vector<Feature>& features) {          // :40-47
+        std::fill(mvGrid_occupy.begin(), mvGrid_occupy.end(), 0);
+        for (const Feature& f : features)
+            mvGrid_occupy[(size_t)((int)(f.mpx_y / mCell_size) * mGrid_cols + (int)(f.mpx_x / mCell_size))] = 1;
+    }
+    void ResetGrid() { std::fill(mvGrid_occupy.begin(), mvGrid_occupy.end(), 0); }   // :64-67
+
+    // void detect(Frame* frame, const double detection_threshold, const bool tFirst = true) — :69-154.
+    // The image work (:76-108) is one library call; the order-dependent rest follows the reference.
+    void detect(Frame* frame, const double detection_threshold, const bool /*tFirst*/ = true) {
+        if ((int)frame->mvFeatures.size() >= mMax_fts) return;                                   // :71-72
+        const size_t G = mvGrid_occupy.size();
+        std::vector<float> score(G);
+        std::vector<int32_t> cx(G), cy(G), cl(G);
+        const int levels = std::min<int>(mPyr_levels, (int)frame->mvImg_Pyr.size());
+        const dsdtm_detect_params prm{mCell_size, mGrid_cols, mGrid_rows, levels, 20, (float)detection_threshold};
+        int rc;
+        if (frame->mDev) {
+            rc = dsdtm_detect_cells_frame(detail::ctx(), frame->mDev, mvGrid_occupy.data(), &prm, score.data(), cx.data(), cy.data(), cl.data());
+        } else {
+            const dsdtm_pyramid pyr = detail::to_pyr(frame->mvImg_Pyr);
+            rc = dsdtm_detect_cells(detail::ctx(), &pyr, mvGrid_occupy.data(), &prm, score.data(), cx.data(), cy.data(), cl.data());
+        }
+        if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_detect_cells: ") + dsdtm_last_error(detail::ctx()));
+        Corners corners;
+        corners.reserve(G);
+        for (size_t k = 0; k < G; ++k) corners.push_back(Corner(cx[k], cy[k], score[k], cl[k], 0.0f));
+        std::stable_sort(corners.begin(), corners.end());                                        // :110
+        Image8 mask(mImg_width, mImg_height);                                                    // src/Frame.cpp:64
+        std::fill(mask.data.begin(), mask.data.end(), 255);
+        if (!frame->mvFeatures.empty())                                                          // :119-122, Frame::Set_Mask
+            for (const Feature& f : frame->mvFeatures)
+                if (f.mbInitial) FillCircle(mask, (int)std::lround(f.mpx_x), (int)std::lround(f.mpx_y), Config::Min_dist(), 0);
+        for (const Corner& c : corners) {                                                        // :124-150
+            if (c.score > 20) {
+                if (mask.data[(size_t)c.y * mask.step + c.x] != 255) continue;                   // :139
+                Feature f;
+                f.mpx_x = (float)c.x; f.mpx_y = (float)c.y; f.mlevel = c.level;                   // :142 (Add_Feature(.., 0): no bearing)
+                frame->mvFeatures.push_back(f);
+                FillCircle(mask, c.x, c.y, mCell_size, 0);                                       // :143
+            }
+            if ((int)frame->mvFeatures.size() >= mMax_fts) break;                                // :148-149
+        }
+        ResetGrid();                                                                             // :152
+    }
+
+    int mImg_height, mImg_width, mCell_size, mPyr_levels, mGrid_rows, mGrid_cols, mMax_fts;
+    std::vector<uint8_t> mvGrid_occupy;
 };
 
 }  // namespace DSDTM

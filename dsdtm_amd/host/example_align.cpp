@@ -73,5 +73,12 @@ int main(int argc, char** argv) {
     std::printf("resident %d\npose_resident", n_resident);
     for (double v : cur->Get_Pose().m) std::printf(" %.17g", v);
     std::printf("\n");
+    // keyframe creation (src/Tracking.cpp:416): detect new features on the current frame, which holds none yet
+    Config::MaxPyraLevels() = levels;
+    Feature_detector detector(hdr[6], hdr[7]);
+    detector.detect(cur.get(), 5.0);
+    std::printf("detected %zu", cur->mvFeatures.size());
+    for (const Feature& ft : cur->mvFeatures) std::printf(" %d %d %d", (int)ft.mpx_x, (int)ft.mpx_y, ft.mlevel);
+    std::printf("\n");
     return 0;
 }
