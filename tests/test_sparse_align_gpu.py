@@ -296,6 +296,31 @@ def test_device_api_with_padded_rows(gpu_ctx, oracle):
         assert ntg[i] == no
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_configurations(gpu_ctx, oracle, seed):
+    """Random image sizes (odd and even), level ranges, feature counts across the kernel shapes,
+    iteration caps, reference poses, motions and shares of uninitialised features."""
+    rng = np.random.default_rng(1000 + seed)
+    width, height = int(rng.integers(150, 420)), int(rng.integers(120, 330))
+    levels = int(rng.integers(2, 6))
+    while min(width, height) >> (levels - 1) < 24:
+        levels -= 1
+    n = int(rng.choice([18, 64, 127, 130, 190, 200, 256, 300, 321, 450, 520]))
+    max_level = int(rng.integers(1, levels + 1)); min_level = int(rng.integers(0, max_level))
+    iters = int(rng.integers(1, 13))
+    xi = tuple(rng.uniform(-1, 1, 6) * np.array([0.012, 0.012, 0.012, 0.006, 0.006, 0.006]) * rng.uniform(0.2, 2.0))
+    sc = synth.make_scene(width=width, height=height, levels=levels, n_patches=n, seed=2000 + seed, xi=xi, margin=8,
+                          T_ref_w=synth.random_pose(rng), frac_uninitial=float(rng.choice([0.0, 0.1, 0.4])),
+                          depth=float(rng.uniform(1.0, 5.0)))
+    To, no, so = oracle.sparse_align(sc, max_level, min_level, iters)
+    Tg, ng, sg = H.gpu_sparse_align(sc, max_level, min_level, iters, ctx=gpu_ctx)
+    what = f"seed {seed}: {width}x{height} L{levels} [{min_level},{max_level}) n={n} it={iters}"
+    H.assert_pose_close(Tg, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=what)
+    assert ng == no, what
+    for k in ("iters", "exit_code", "n_ref", "n_vis"):
+        assert sg[k] == so[k], (what, k)
+
+
 @pytest.mark.parametrize("scale", [1.0, 2.5])
 def test_window_refills_under_multi_pixel_motion(gpu_ctx, oracle, scale):
     """The kernel keeps each patch's current-image footprint in an LDS window and refills a lane's
