@@ -1044,6 +1044,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + ltid, ltid < nf);
         unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
         unsigned long long st_lvl[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pass cycles / pass count of levels 0..3
+        unsigned long long st_plv[4] = {0, 0, 0, 0}, st_first[4] = {0, 0, 0, 0};   // precompute / first-pass cycles of levels 0..3
         FeatureRegs F;
         {
             const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
@@ -1061,7 +1062,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             precompute_patch<GT>(a, lg, level, ref_base, F, P);
             if (STAMPS) {
                 pin_patch(P);   // make the stamp wait for the precompute results
-                st_pre += __builtin_amdgcn_s_memtime() - tp0;
+                const unsigned long long dtp = __builtin_amdgcn_s_memtime() - tp0;
+                st_pre += dtp;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) if (l == level) st_plv[l] += dtp;
             }
             const unsigned long long valid_mask = __ballot(P.valid);
             const int n_ref_row = __popc((unsigned)(valid_mask >> (16 * row)) & 0xffffu);
@@ -1109,7 +1113,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 if (STAMPS) {
                     tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0;
 #pragma unroll
-                    for (int l = 0; l < 4; ++l) if (l == level) { st_lvl[l] += tq1 - tq0; st_lvl[4 + l] += 1; }
+                    for (int l = 0; l < 4; ++l) if (l == level) { st_lvl[l] += tq1 - tq0; st_lvl[4 + l] += 1; if (it == 0) st_first[l] += tq1 - tq0; }
                 }
                 const bool h_changed = (vmask != cached_mask);        // wave-uniform, rare
                 if (h_changed) {
@@ -1136,6 +1140,11 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         if (STAMPS && lane == 0 && a.workspace) {                      // every patch wave: pass and barrier cycles
             unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 20 + (size_t)pair * 16;
             o[wave] = st_pass; o[8 + wave] = st_bar;
+        }
+        if (STAMPS && ltid == 0 && a.workspace) {                      // wave 0: per-level precompute and first-pass cycles
+            unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 36 + (size_t)pair * 8;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) { o[l] = st_plv[l]; o[4 + l] = st_first[l]; }
         }
         if (STAMPS && ltid == 0 && a.workspace) {
             unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 12;
