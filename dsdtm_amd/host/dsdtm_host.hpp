@@ -15,6 +15,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <list>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -70,6 +72,17 @@ struct Frame {                                    // include/Frame.h (what the p
     dsdtm_frame* mDev = nullptr;                  // the image pyramid, resident on the device (optional)
     const SE3& Get_Pose() const { return mT_c2w; }
     void Set_Pose(const SE3& T) { mT_c2w = T; }   // src/Frame.cpp:167-174
+    std::array<double, 3> Get_CameraCnt() const { // mOw = -R^T t (src/Frame.cpp:170-173)
+        const auto& m = mT_c2w.m;
+        return {{-(m[0] * m[3] + m[4] * m[7] + m[8] * m[11]), -(m[1] * m[3] + m[5] * m[7] + m[9] * m[11]),
+                 -(m[2] * m[3] + m[6] * m[7] + m[10] * m[11])}};
+    }
+    std::array<double, 2> World2Pixel(const std::array<double, 3>& P) const {   // src/Frame.cpp:318-323
+        const auto& m = mT_c2w.m;
+        const double x = m[0] * P[0] + m[1] * P[1] + m[2] * P[2] + m[3], y = m[4] * P[0] + m[5] * P[1] + m[6] * P[2] + m[7],
+                     z = m[8] * P[0] + m[9] * P[1] + m[10] * P[2] + m[11];
+        return {{(double)mCamera->mfx * x / z + (double)mCamera->mcx, (double)mCamera->mfy * y / z + (double)mCamera->mcy}};
+    }
     // Frame::ComputeImagePyramid (src/Frame.cpp:74-81) on the device: level 0 crosses PCIe once, the
     // other levels are built by the library's bit-exact pyrDown and stay there for every Run.
     void ComputeImagePyramidOnDevice(int levels) {
@@ -153,9 +166,147 @@ protected:
     int mnMaxLevel, mnMinLevel, mnMaxIterators, mnMinfts;
 };
 
+struct MapPoint {                                 // include/MapPoint.h (what the search reads)
+    std::array<double, 3> mPose{{0, 0, 0}};
+    std::map<int, int> mObservations;             // keyframe index -> feature index (iterated in keyframe order)
+    int mnFound = 1;
+    bool mbBad = false;
+    const std::array<double, 3>& Get_Pose() const { return mPose; }
+    bool IsBad() const { return mbBad; }
+    int Get_FoundNums() const { return mnFound; }
+    void IncreaseFound(int n = 1) { mnFound += n; }
+};
+
+inline int cvRound(double v) { return (int)std::nearbyint(v); }      // OpenCV 2.4 cvRound: round half to even
+inline bool IsInImage(const Camera& c, double x, double y, int boundary, int level = 0) {   // src/Camera.cpp:187-193
+    return cvRound(x) >= boundary && cvRound(x) < c.mwidth / (1 << level) - boundary &&
+           cvRound(y) >= boundary && cvRound(y) < c.mheight / (1 << level) - boundary;
+}
+inline void FillCircle(Image8& mask, int cx, int cy, int radius, uint8_t value);
+
 class Feature_Alignment {
 public:
-    explicit Feature_Alignment(CameraPtr camera) : mCam(camera) {}
+    explicit Feature_Alignment(CameraPtr camera) : mCam(camera) {
+        mGrid_Rows = (int)std::ceil(1.0 * mCam->mheight / Config::CellSize());      // src/Feature_alignment.cpp:29-30
+        mGrid_Cols = (int)std::ceil(1.0 * mCam->mwidth / Config::CellSize());
+        mCells.resize((size_t)mGrid_Rows * mGrid_Cols);
+    }
+
+    struct Candidate { MapPoint* mp; std::array<double, 2> px; };
+    struct Match { int cell; MapPoint* mp; float px[2]; int level; };
+
+    void ResetGrid() { for (auto& c : mCells) c.clear(); }                            // :46-52
+    bool ReprojectPoint(const Frame& tFrame, MapPoint* tMPoint) {                     // :54-69
+        const std::array<double, 2> px = tFrame.World2Pixel(tMPoint->Get_Pose());
+        if (!(std::isfinite(px[0]) && std::isfinite(px[1]) && IsInImage(*mCam, px[0], px[1], 8))) return false;
+        const int index = (int)(px[1] / Config::CellSize()) * mGrid_Cols + (int)(px[0] / Config::CellSize());
+        mCells[(size_t)index].push_back(Candidate{tMPoint, px});
+        return true;
+    }
+
+    // MapPoint::Get_ClosetObs (src/MapPoint.cpp:133-174): the observation whose viewing direction is
+    // closest to the frame's; none when cos < 0.5
+    static bool Get_ClosetObs(const MapPoint& mp, const Frame& frame, const std::vector<Frame*>& keyframes, int& kf, int& feat) {
+        if (mp.mObservations.empty()) return false;
+        auto unit = [](std::array<double, 3> v) { const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                                                  return std::array<double, 3>{{v[0] / n, v[1] / n, v[2] / n}}; };
+        const std::array<double, 3> c = frame.Get_CameraCnt();
+        const std::array<double, 3> v = unit({{c[0] - mp.mPose[0], c[1] - mp.mPose[1], c[2] - mp.mPose[2]}});
+        int best = -1, first = -1;
+        double best_cos = 0.0;
+        for (const auto& o : mp.mObservations) {
+            if (first < 0) first = o.first;
+            const std::array<double, 3> k = keyframes[(size_t)o.first]->Get_CameraCnt();
+            const std::array<double, 3> r = unit({{k[0] - mp.mPose[0], k[1] - mp.mPose[1], k[2] - mp.mPose[2]}});
+            const double cs = r[0] * v[0] + r[1] * v[1] + r[2] * v[2];
+            if (cs > best_cos) { best_cos = cs; best = o.first; }
+        }
+        if (best < 0) best = first;
+        if (best_cos < 0.5) return false;
+        kf = best; feat = mp.mObservations.at(best);
+        return true;
+    }
+
+    // void SearchLocalPoints(FramePtr tFrame) (:71-83) with ReprojectCell (:85-121) and FindMatchDirect
+    // (:128-158): every live candidate is warped and aligned speculatively in two library calls, then
+    // the reference's order-dependent rules are replayed (cells in index order, candidates by found
+    // count, mask, first success per cell, 200-match cap).
+    std::vector<Match> SearchLocalPoints(Frame& tFrame, const std::vector<Frame*>& keyframes, Image8& img_mask) {
+        struct Spec { int cell, pos, kf, feat; };
+        std::vector<Spec> cand;
+        std::vector<std::vector<Candidate>> cells(mCells.size());
+        for (size_t ci = 0; ci < mCells.size(); ++ci) {
+            cells[ci].assign(mCells[ci].begin(), mCells[ci].end());
+            std::stable_sort(cells[ci].begin(), cells[ci].end(),                      // :88 (std::list::sort is stable)
+                             [](const Candidate& a, const Candidate& b) { return a.mp->Get_FoundNums() > b.mp->Get_FoundNums(); });
+            for (size_t pos = 0; pos < cells[ci].size(); ++pos) {
+                const MapPoint& mp = *cells[ci][pos].mp;
+                if (mp.IsBad()) continue;
+                int kf, feat;
+                if (!Get_ClosetObs(mp, tFrame, keyframes, kf, feat)) continue;         // :135
+                const Feature& rf = keyframes[(size_t)kf]->mvFeatures[(size_t)feat];
+                const int s = 1 << rf.mlevel;
+                if (!IsInImage(*mCam, rf.mpx_x / s, rf.mpx_y / s, mHalf_PatchSize + 1, rf.mlevel)) continue;   // :138-140
+                cand.push_back(Spec{(int)ci, (int)pos, kf, feat});
+            }
+        }
+        const int m = (int)cand.size();
+        std::vector<uint8_t> conv((size_t)m);
+        std::vector<double> pxr(2 * (size_t)m);
+        std::vector<int32_t> sl((size_t)m);
+        if (m > 0) {
+            std::vector<dsdtm_pyramid> pyrs;
+            std::vector<double> Tk;
+            for (Frame* k : keyframes) { pyrs.push_back(detail_to_pyr(k->mvImg_Pyr)); Tk.insert(Tk.end(), k->Get_Pose().m.begin(), k->Get_Pose().m.end()); }
+            std::vector<int32_t> ck((size_t)m), rl((size_t)m);
+            std::vector<float> rp(2 * (size_t)m);
+            std::vector<double> rb(3 * (size_t)m), pw(3 * (size_t)m), aff(4 * (size_t)m);
+            std::vector<uint8_t> pb(100 * (size_t)m), pp(64 * (size_t)m);
+            for (int i = 0; i < m; ++i) {
+                const Feature& rf = keyframes[(size_t)cand[i].kf]->mvFeatures[(size_t)cand[i].feat];
+                const MapPoint& mp = *cells[(size_t)cand[i].cell][(size_t)cand[i].pos].mp;
+                ck[i] = cand[i].kf; rl[i] = rf.mlevel; rp[2 * i] = rf.mpx_x; rp[2 * i + 1] = rf.mpx_y;
+                for (int k = 0; k < 3; ++k) { rb[3 * i + k] = rf.mNormal[k]; pw[3 * i + k] = mp.mPose[k]; }   // :167 the same map point
+            }
+            const Camera& c = *mCam;
+            const dsdtm_camera cam{c.mfx, c.mfy, c.mcx, c.mcy, c.mf, c.mwidth, c.mheight};
+            int rc = dsdtm_warp_patches(ctx_(), pyrs.data(), (int)pyrs.size(), &cam, Tk.data(), tFrame.Get_Pose().m.data(), ck.data(),
+                                        rp.data(), rl.data(), rb.data(), pw.data(), Config::MaxPyraLevels() - 3, m, aff.data(),
+                                        sl.data(), pb.data(), pp.data());
+            if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_warp_patches: ") + dsdtm_last_error(ctx_()));
+            for (int i = 0; i < m; ++i) {                                             // :150 px in the search level
+                const std::array<double, 2>& p0 = cells[(size_t)cand[i].cell][(size_t)cand[i].pos].px;
+                pxr[2 * i] = p0[0] / (1 << sl[i]); pxr[2 * i + 1] = p0[1] / (1 << sl[i]);
+            }
+            const dsdtm_pyramid cur = detail_to_pyr(tFrame.mvImg_Pyr);
+            rc = dsdtm_align2d_batch(ctx_(), &cur, pb.data(), pp.data(), sl.data(), pxr.data(), conv.data(), 10, m);   // :152
+            if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_align2d_batch: ") + dsdtm_last_error(ctx_()));
+        }
+        std::map<std::pair<int, int>, int> index;
+        for (int i = 0; i < m; ++i) index[{cand[i].cell, cand[i].pos}] = i;
+        std::vector<Match> matches;
+        for (size_t ci = 0; ci < cells.size(); ++ci) {                                // :75 index order
+            for (size_t pos = 0; pos < cells[ci].size(); ++pos) {
+                MapPoint* mp = cells[ci][pos].mp;
+                if (mp->IsBad()) continue;                                            // :93
+                const std::array<double, 2>& px = cells[ci][pos].px;
+                if (img_mask.data[(size_t)cvRound(px[1]) * img_mask.step + cvRound(px[0])] != 255) continue;   // :96
+                const auto it = index.find({(int)ci, (int)pos});
+                if (it == index.end() || !conv[(size_t)it->second]) continue;         // :101-104
+                const int i = it->second;
+                const double x = pxr[2 * i] * (1 << sl[i]), y = pxr[2 * i + 1] * (1 << sl[i]);   // :154-156
+                mp->IncreaseFound();                                                  // :106
+                FillCircle(img_mask, cvRound(x), cvRound(y), Config::CellSize(), 0);  // :111
+                Match mt; mt.cell = (int)ci; mt.mp = mp; mt.px[0] = (float)x; mt.px[1] = (float)y; mt.level = sl[i];
+                matches.push_back(mt);
+                Feature f; f.mpx_x = mt.px[0]; f.mpx_y = mt.px[1]; f.mlevel = mt.level;   // :113-114 Add_Feature / Add_MapPoint
+                tFrame.mvFeatures.push_back(f);
+                break;                                                                // :117 first success wins
+            }
+            if (matches.size() >= 200) break;                                         // :80
+        }
+        return matches;
+    }
 
     // static bool Align2DGaussNewton(const cv::Mat&, uchar*, uchar*, int, Eigen::Vector2d&)
     // — include/Feature_alignment.h:85. tCurPx is written back also on failure (:414).
@@ -180,9 +331,17 @@ public:
         if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_align2d_batch: ") + dsdtm_last_error(detail::ctx()));
     }
 
+    int mGrid_Rows = 0, mGrid_Cols = 0;
+    std::vector<std::list<Candidate>> mCells;
+
 private:
+    static dsdtm_ctx* ctx_();
+    static dsdtm_pyramid detail_to_pyr(const std::vector<Image8>& v);
     CameraPtr mCam;
 };
+
+inline dsdtm_ctx* Feature_Alignment::ctx_() { return detail::ctx(); }
+inline dsdtm_pyramid Feature_Alignment::detail_to_pyr(const std::vector<Image8>& v) { return detail::to_pyr(v); }
 
 // cv::circle(img, center, radius, 0, -1) for an 8-bit mask: OpenCV 2.4 drawing.cpp Circle() (midpoint
 // algorithm, filled by horizontal spans, clipped to the image) — the detector's and the tracker's

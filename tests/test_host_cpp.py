@@ -16,15 +16,16 @@ HOST = os.path.join(ROOT, "dsdtm_amd", "host")
 EXE = os.path.join(HOST, "example_align")
 
 
-def build_example():
-    src = os.path.join(HOST, "example_align.cpp")
+def build_example(name="example_align"):
+    exe = os.path.join(HOST, name)
+    src = os.path.join(HOST, name + ".cpp")
     hdr = os.path.join(HOST, "dsdtm_host.hpp")
     lib = capi.lib_path()
-    if (not os.path.exists(EXE)) or any(os.path.getmtime(p) > os.path.getmtime(EXE) for p in (src, hdr, lib)):
-        subprocess.run(["g++", "-O2", "-std=c++14", "-Wall", "-o", EXE, src, lib,
+    if (not os.path.exists(exe)) or any(os.path.getmtime(p) > os.path.getmtime(exe) for p in (src, hdr, lib)):
+        subprocess.run(["g++", "-O2", "-std=c++14", "-Wall", "-o", exe, src, lib,
                         "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"],
                        check=True)
-    return EXE
+    return exe
 
 
 def dump_scene(path, sc, params, min_fts, border, patch, px0):
@@ -43,7 +44,7 @@ def dump_scene(path, sc, params, min_fts, border, patch, px0):
 
 
 def test_cpp_host_layer_builds_against_the_c_abi():
-    assert os.path.exists(build_example())
+    assert os.path.exists(build_example()) and os.path.exists(build_example("example_search"))
 
 
 @pytest.mark.gpu
@@ -81,3 +82,48 @@ def test_cpp_driver_matches_oracle(tmp_path, oracle):
     det = [int(v) for v in out[6].split()[1:]]
     assert det[0] == len(want_det) and det[0] > 10
     assert [tuple(det[1 + 3 * i:4 + 3 * i]) for i in range(det[0])] == want_det
+
+
+def dump_world(path, cam, kfs, cur, mps, levels, cell, max_levels):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8i", levels, len(kfs), len(mps), cam.width, cam.height, cell, max_levels, 0))
+        f.write(struct.pack("<5f", cam.fx, cam.fy, cam.cx, cam.cy, cam.f))
+        for fr in list(kfs) + [cur]:
+            f.write(np.ascontiguousarray(fr.Get_Pose(), "<f8").tobytes())
+            for l in fr.mvImg_Pyr[:levels]:
+                f.write(np.ascontiguousarray(l).tobytes())
+            f.write(struct.pack("<i", fr.n_features))
+            for i in range(fr.n_features):
+                f.write(fr.px[i].astype("<f4").tobytes() + struct.pack("<i", int(fr.level[i])) + fr.bearing[i].astype("<f8").tobytes())
+        for mp in mps:
+            f.write(np.asarray(mp.mPose, "<f8").tobytes() + struct.pack("<3i", mp.mnFound, int(mp.mbBad), len(mp.mObservations)))
+            for k in sorted(mp.mObservations):
+                f.write(struct.pack("<2i", k, mp.mObservations[k]))
+
+
+@pytest.mark.gpu
+def test_cpp_search_local_points_matches_the_python_mirror(tmp_path, gpu_ctx):
+    """Feature_Alignment::ResetGrid / ReprojectPoint / SearchLocalPoints of the C++ layer against
+    dsdtm_amd.search.LocalPointSearch (itself held to the sequential restatement in test_search_gpu.py):
+    same library calls underneath, so cells, map points, levels, pixels and the mask agree exactly."""
+    from dsdtm_amd import search
+    from dsdtm_amd.frame import Config
+    from tests.test_search_gpu import make_world
+    exe = build_example("example_search")
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5)
+    cam, kfs, cur, mps = make_world(5, n_points=700)
+    world = tmp_path / "world.bin"
+    dump_world(world, cam, kfs, cur, mps, 5, 25, 5)
+    out = subprocess.run([exe, str(world)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    s = search.LocalPointSearch(cam, ctx=gpu_ctx)
+    s.ResetGrid()
+    n_in = sum(s.ReprojectPoint(cur, mp) for mp in mps)
+    mask = np.full((cam.height, cam.width), 255, np.uint8)
+    got = s.SearchLocalPoints(cur, kfs, mask)
+    assert int(out[0].split()[1]) == n_in and int(out[1].split()[1]) == len(got) and len(got) > 100
+    idx = {id(mp): i for i, mp in enumerate(mps)}
+    for line, g in zip(out[2:2 + len(got)], got):
+        c, mi, x, y, lv = line.split()
+        assert (int(c), int(mi), int(lv)) == (g[0], idx[id(g[1])], g[3])
+        assert np.float32(x) == g[2][0] and np.float32(y) == g[2][1]
+    assert int(out[2 + len(got)].split()[1]) == int(mask.astype(np.uint64).sum())
