@@ -127,7 +127,7 @@ EXPORTED_SYMBOLS = [
     "dsdtm_reserve", "dsdtm_align2d_batch", "dsdtm_align2d_batch_device",
     "dsdtm_pyrdown_batch_device", "dsdtm_pyrdown", "dsdtm_warp_patches",
     "dsdtm_frame_create", "dsdtm_frame_create_from_image", "dsdtm_frame_destroy", "dsdtm_sparse_align_frames",
-    "dsdtm_detect_cells", "dsdtm_detect_cells_frame",
+    "dsdtm_detect_cells", "dsdtm_detect_cells_frame", "dsdtm_match_candidates_frames",
 ]
 
 
@@ -203,8 +203,19 @@ def load():
     lib.dsdtm_detect_cells.argtypes = [C.c_void_p, C.POINTER(Pyramid), u8p, C.POINTER(DetectParams), fp, ip32, ip32, ip32]
     lib.dsdtm_detect_cells_frame.restype = C.c_int
     lib.dsdtm_detect_cells_frame.argtypes = [C.c_void_p, C.c_void_p, u8p, C.POINTER(DetectParams), fp, ip32, ip32, ip32]
+    lib.dsdtm_match_candidates_frames.restype = C.c_int
+    lib.dsdtm_match_candidates_frames.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(Camera), dp, dp,
+                                                  ip32, fp, ip32, dp, dp, C.c_int, C.c_int, C.c_int, dp, ip32, u8p]
     _LIB = lib
     return lib
+
+
+def device_frame_of(ctx, frame):
+    """The frame's pyramid on the device (uploaded on first use, cached on the Frame object)."""
+    df = getattr(frame, "_device_frame", None)
+    if df is None or df.ctx is not ctx or df.handle is None:
+        df = frame._device_frame = DeviceFrame.from_pyramid(ctx, frame.mvImg_Pyr)
+    return df
 
 
 class DeviceFrame:

@@ -75,8 +75,10 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
     const float i21 = (m20 * m01 - m21 * m00) * invdet;   // cofactor<1,2>
     const float i22 = (m00 * m11 - m01 * m10) * invdet;   // cofactor<2,2>
 
-    float u = (float)a.px_xy[2 * (size_t)f];
-    float v = (float)a.px_xy[2 * (size_t)f + 1];
+    // (px_level0: the caller's pixel is in level-0 units; the division by 2^level is exact in double, :150)
+    const double lscale = a.px_level0 ? (double)(1 << lvl) : 1.0;
+    float u = (float)(a.px_xy[2 * (size_t)f] / lscale);
+    float v = (float)(a.px_xy[2 * (size_t)f + 1] / lscale);
     float mean_diff = 0.0f;
     const float min_update_squared = (float)(0.03 * 0.03);
     bool converged = false;
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
         if (up0 * up0 + up1 * up1 < min_update_squared) { converged = true; break; }   // :400
     }
     if (lane == 0) {
-        a.px_xy[2 * (size_t)f] = (double)u;                                  // :414 always written back
-        a.px_xy[2 * (size_t)f + 1] = (double)v;
+        a.px_xy[2 * (size_t)f] = (double)u * lscale;                         // :414 always written back (:154-156 back to level 0)
+        a.px_xy[2 * (size_t)f + 1] = (double)v * lscale;
         a.converged[f] = converged ? 1 : 0;
     }
 }

@@ -737,6 +737,90 @@ extern "C" int dsdtm_warp_patches(dsdtm_ctx* ctx, const dsdtm_pyramid* kf_pyr, i
     return DSDTM_OK;
 }
 
+// ---- FindMatchDirect for M candidates on device-resident frames: warp prelude + Align2D, one call ----
+extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* cur, const dsdtm_frame* const* kf, int n_kf,
+                                             const dsdtm_camera* cam, const double* T_kf_w, const double T_cur_w[12],
+                                             const int32_t* cand_kf, const float* ref_px, const int32_t* ref_level,
+                                             const double* ref_bearing, const double* p_world, int max_search_level,
+                                             int max_iters, int m, double* px_xy, int32_t* search_level, uint8_t* converged) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!cur || !kf || n_kf <= 0 || n_kf > 4096 || !cam || !T_kf_w || !T_cur_w || m < 0 ||
+        (m > 0 && (!cand_kf || !ref_px || !ref_level || !ref_bearing || !p_world || !px_xy || !search_level || !converged))) {
+        set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID;
+    }
+    if (m == 0) return DSDTM_OK;
+    if (cur->owner != ctx) { set_err(ctx, "frame belongs to another context"); return DSDTM_ERR_INVALID; }
+    const PackedPyr& p0 = cur->pl;
+    for (int k = 0; k < n_kf; ++k) {
+        if (!kf[k] || kf[k]->owner != ctx) { set_err(ctx, "keyframe %d: NULL or foreign frame", k); return DSDTM_ERR_INVALID; }
+        const PackedPyr& pk = kf[k]->pl;
+        if (pk.levels != p0.levels || memcmp(pk.w, p0.w, sizeof(int) * p0.levels) || memcmp(pk.h, p0.h, sizeof(int) * p0.levels)) {
+            set_err(ctx, "keyframe %d pyramid geometry differs from the current frame", k); return DSDTM_ERR_INVALID;
+        }
+    }
+    if (max_search_level < 0 || max_search_level >= p0.levels) { set_err(ctx, "max_search_level outside the pyramid"); return DSDTM_ERR_INVALID; }
+    for (int i = 0; i < m; ++i) {
+        if (cand_kf[i] < 0 || cand_kf[i] >= n_kf || ref_level[i] < 0 || ref_level[i] >= p0.levels) {
+            set_err(ctx, "candidate %d: keyframe %d / level %d out of range", i, cand_kf[i], ref_level[i]); return DSDTM_ERR_INVALID;
+        }
+    }
+    const size_t M = (size_t)m;
+    size_t o = 0;
+    const size_t o_ptr = o; o += align_up((size_t)n_kf * sizeof(void*), 256);
+    const size_t o_tk = o; o += align_up((size_t)n_kf * 96, 256);
+    const size_t o_rb = o; o += align_up(M * 24, 256);
+    const size_t o_pw = o; o += align_up(M * 24, 256);
+    const size_t o_ck = o; o += align_up(M * 4, 256);
+    const size_t o_rl = o; o += align_up(M * 4, 256);
+    const size_t o_rp = o; o += align_up(M * 8, 256);
+    const size_t o_px = o; o += align_up(M * 16, 256);          // in and out
+    const size_t in_bytes = o;
+    const size_t o_sl = o; o += align_up(M * 4, 256);
+    const size_t o_cv = o; o += align_up(M, 256);
+    const size_t out_end = o;
+    const size_t o_af = o; o += align_up(M * 32, 256);          // device only
+    const size_t o_pb = o; o += align_up(M * 100, 256);
+    const size_t o_pp = o; o += align_up(M * 64, 256);
+    const size_t total = o;
+    if (int rc = ensure_stage(ctx, total)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    for (int k = 0; k < n_kf; ++k) ((const uint8_t**)(h + o_ptr))[k] = kf[k]->d;
+    memcpy(h + o_tk, T_kf_w, (size_t)n_kf * 96);
+    memcpy(h + o_rb, ref_bearing, M * 24);
+    memcpy(h + o_pw, p_world, M * 24);
+    memcpy(h + o_ck, cand_kf, M * 4);
+    memcpy(h + o_rl, ref_level, M * 4);
+    memcpy(h + o_rp, ref_px, M * 8);
+    memcpy(h + o_px, px_xy, M * 16);
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    WarpKernelArgs a;
+    memset(&a, 0, sizeof a);
+    a.kf_ptrs = (const uint8_t* const*)(d + o_ptr); a.T_kf_w = (const double*)(d + o_tk);
+    a.cand_kf = (const int32_t*)(d + o_ck); a.ref_px = (const float*)(d + o_rp);
+    a.ref_level = (const int32_t*)(d + o_rl); a.ref_bearing = (const double*)(d + o_rb);
+    a.p_world = (const double*)(d + o_pw); a.affine = (double*)(d + o_af);
+    a.search_level = (int32_t*)(d + o_sl); a.patch_border = d + o_pb; a.patch = d + o_pp;
+    memcpy(a.T_cur_w, T_cur_w, 96);
+    a.m = m; a.n_kf = n_kf; a.max_search_level = max_search_level; a.levels = p0.levels;
+    a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy;
+    for (int l = 0; l < p0.levels; ++l) { a.lv[l].w = p0.w[l]; a.lv[l].h = p0.h[l]; a.lv[l].stride = p0.w[l]; a.lv[l].off = (uint32_t)p0.off[l]; }
+    HIP_TRY(ctx, warp_launch(a, ctx->stream));
+    A2DKernelArgs b;
+    memset(&b, 0, sizeof b);
+    b.cur_pyr = cur->d; b.patch_border = d + o_pb; b.patch = d + o_pp; b.level = (const int32_t*)(d + o_sl);
+    b.px_xy = (double*)(d + o_px); b.converged = d + o_cv; b.m = m; b.max_iters = max_iters; b.levels = p0.levels;
+    b.px_level0 = 1;
+    for (int l = 0; l < p0.levels; ++l) b.lv[l] = a.lv[l];
+    HIP_TRY(ctx, align2d_launch(b, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h + o_px, d + o_px, out_end - o_px, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(px_xy, h + o_px, M * 16);
+    memcpy(search_level, h + o_sl, M * 4);
+    memcpy(converged, h + o_cv, M);
+    return DSDTM_OK;
+}
+
 // ---- debug: device self-test of the FP64 building blocks (not in the public header) ------------
 extern "C" int dsdtm_debug_selftest(dsdtm_ctx* ctx, const double* in, double* out, int n_cases) {
     if (!ctx || !in || !out || n_cases < 0) return DSDTM_ERR_INVALID;

@@ -81,6 +81,7 @@ struct A2DKernelArgs {
     double* px_xy;                // M x 2 (in/out)
     uint8_t* converged;           // M
     int m, max_iters, levels;
+    int px_level0;                // 1: px_xy is in level-0 pixels (divided by 2^level on load, multiplied back on store)
     LevelGeom lv[DSDTM_MAX_LEVELS];
 };
 hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream);
@@ -91,7 +92,8 @@ hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, 
 
 // Warp prelude: one 128-thread group per candidate (100 sample lanes).
 struct WarpKernelArgs {
-    const uint8_t* kf_pyr;        // n_kf packed pyramids, pitch kf_pitch
+    const uint8_t* kf_pyr;        // n_kf packed pyramids, pitch kf_pitch ...
+    const uint8_t* const* kf_ptrs; // ... or (non-null) n_kf base pointers of separately allocated pyramids (device array)
     size_t kf_pitch;
     const double* T_kf_w;         // n_kf x 12
     const int32_t* cand_kf;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
     const float Ai0 = (float)(A11 * invdet), Ai1 = (float)(-A01 * invdet);
     const float Ai2 = (float)(-A10 * invdet), Ai3 = (float)(A00 * invdet);
     const LevelGeom lg = a.lv[tLevel];
-    const uint8_t* __restrict__ img = a.kf_pyr + (size_t)k * a.kf_pitch + lg.off;
+    const uint8_t* __restrict__ img = (a.kf_ptrs ? a.kf_ptrs[k] : a.kf_pyr + (size_t)k * a.kf_pitch) + lg.off;
     const float refx = rx / (float)(1 << tLevel), refy = ry / (float)(1 << tLevel);     // :215-216
     const int int_scale = 1 / (1 << sl);                                                // :231 quirk W1
     const int ix = (j % 10) - 5, iy = (j / 10) - 5;

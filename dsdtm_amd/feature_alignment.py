@@ -70,6 +70,35 @@ def warp_patches(kf_pyrs, cam, T_kf_w, T_cur_w, cand_kf, ref_px, ref_level, ref_
     return aff, sl, pb, pp
 
 
+def match_candidates_frames(cur_frame, keyframes, cam, T_kf_w, T_cur_w, cand_kf, ref_px, ref_level, ref_bearing, p_world,
+                            cand_px, max_search_level, max_iters, ctx=None):
+    """FindMatchDirect (src/Feature_alignment.cpp:142-156) for M candidates on device-resident frames in
+    ONE library call: warp prelude + Align2D, the warped patches never leave the device.
+    Returns (converged bool[M], px float64[M,2] in level-0 pixels, search_level int32[M])."""
+    ctx = ctx or capi.default_context()
+    dcur = capi.device_frame_of(ctx, cur_frame)
+    dk = [capi.device_frame_of(ctx, k) for k in keyframes]
+    n_kf, m = len(dk), len(cand_kf)
+    handles = (C.c_void_p * n_kf)(*[d.handle for d in dk])
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    Tk = np.ascontiguousarray(T_kf_w, np.float64).reshape(n_kf, 12)
+    Tc = np.ascontiguousarray(T_cur_w, np.float64).reshape(12)
+    ck = np.ascontiguousarray(cand_kf, np.int32)
+    rp = np.ascontiguousarray(ref_px, np.float32).reshape(m, 2)
+    rl = np.ascontiguousarray(ref_level, np.int32)
+    rb = np.ascontiguousarray(ref_bearing, np.float64).reshape(m, 3)
+    pw = np.ascontiguousarray(p_world, np.float64).reshape(m, 3)
+    px = np.array(cand_px, dtype=np.float64).reshape(m, 2).copy()
+    sl = np.zeros(m, np.int32)
+    conv = np.zeros(m, np.uint8)
+    ctx.check(ctx.lib.dsdtm_match_candidates_frames(
+        ctx.handle, dcur.handle, handles, n_kf, C.byref(capi.camera_struct(cam)), Tk.ctypes.data_as(dp), Tc.ctypes.data_as(dp),
+        ck.ctypes.data_as(ip), rp.ctypes.data_as(C.POINTER(C.c_float)), rl.ctypes.data_as(ip), rb.ctypes.data_as(dp),
+        pw.ctypes.data_as(dp), int(max_search_level), int(max_iters), m, px.ctypes.data_as(dp), sl.ctypes.data_as(ip),
+        conv.ctypes.data_as(capi.u8p)))
+    return conv.astype(bool), px, sl
+
+
 class Feature_Alignment:
     """Only the parts of the class that are on the hot path are mirrored here; the
     reprojection grid (ResetGrid / ReprojectPoint / SearchLocalPoints, :22-126) lives in

@@ -116,8 +116,11 @@ def get_closest_obs(mp: MapPoint, frame: Frame, keyframes):
 class LocalPointSearch(FA.Feature_Alignment):
     """Feature_Alignment(CameraPtr) with ResetGrid / ReprojectPoint / SearchLocalPoints."""
 
-    def __init__(self, camera, ctx=None):
+    def __init__(self, camera, ctx=None, resident_frames: bool = False):
         super().__init__(camera, ctx)
+        # resident_frames: keyframe and current pyramids stay on the device (dsdtm_frame) and every
+        # candidate is matched by ONE library call (dsdtm_match_candidates_frames)
+        self.resident_frames = bool(resident_frames)
         self.mMax_pts = Config.Get("Camera.Max_tkfts")
         self.mPyr_levels = Config.Get("Camera.MaxPyraLevels")
         self.mCell_size = Config.Get("Camera.CellSize")
@@ -171,13 +174,21 @@ class LocalPointSearch(FA.Feature_Alignment):
             ref_b = np.array([keyframes[k].bearing[f] for k, f in zip(ck, fi)], np.float64)
             # SolveAffineMatrix uses tReferFeature->Mpt->Get_Pose() (:167), i.e. the same map point
             pw = np.array([self.mCells[c[0]][c[1]][0].Get_Pose() for c in cand], np.float64)
-            aff, sl, pb, pp = FA.warp_patches([k.mvImg_Pyr for k in keyframes], cam,
-                                              np.array([k.Get_Pose() for k in keyframes]), tFrame.Get_Pose(),
-                                              ck, ref_px, ref_lv, ref_b, pw, self.mPyr_levels - 3, ctx=self._ctx)
-            px0 = np.array([self.mCells[c[0]][c[1]][1] / (1 << int(s)) for c, s in zip(cand, sl)])   # :150
-            conv, pxr = FA.align2d_batch(tFrame.mvImg_Pyr, pb, pp, sl, px0, 10, ctx=self._ctx)       # :152
-            for c, ok, p, s in zip(cand, conv, pxr, sl):
-                results[(c[0], c[1])] = (bool(ok), p * (1 << int(s)), int(s))                        # :154-156
+            if self.resident_frames:
+                cpx = np.array([self.mCells[c[0]][c[1]][1] for c in cand], np.float64)
+                conv, pxl0, sl = FA.match_candidates_frames(tFrame, keyframes, cam, np.array([k.Get_Pose() for k in keyframes]),
+                                                            tFrame.Get_Pose(), ck, ref_px, ref_lv, ref_b, pw, cpx,
+                                                            self.mPyr_levels - 3, 10, ctx=self._ctx)
+                for c, ok, p, s in zip(cand, conv, pxl0, sl):
+                    results[(c[0], c[1])] = (bool(ok), p, int(s))
+            else:
+                aff, sl, pb, pp = FA.warp_patches([k.mvImg_Pyr for k in keyframes], cam,
+                                                  np.array([k.Get_Pose() for k in keyframes]), tFrame.Get_Pose(),
+                                                  ck, ref_px, ref_lv, ref_b, pw, self.mPyr_levels - 3, ctx=self._ctx)
+                px0 = np.array([self.mCells[c[0]][c[1]][1] / (1 << int(s)) for c, s in zip(cand, sl)])   # :150
+                conv, pxr = FA.align2d_batch(tFrame.mvImg_Pyr, pb, pp, sl, px0, 10, ctx=self._ctx)       # :152
+                for c, ok, p, s in zip(cand, conv, pxr, sl):
+                    results[(c[0], c[1])] = (bool(ok), p * (1 << int(s)), int(s))                        # :154-156
         # ---- replay of the sequential rules --------------------------------------------------------
         matches = []
         n_matches = 0

@@ -35,10 +35,7 @@ class Sprase_ImgAlign:
 
     @staticmethod
     def _device_frame(ctx, frame: Frame):
-        df = getattr(frame, "_device_frame", None)
-        if df is None or df.ctx is not ctx or df.handle is None:
-            df = frame._device_frame = capi.DeviceFrame.from_pyramid(ctx, frame.mvImg_Pyr)
-        return df
+        return capi.device_frame_of(ctx, frame)
 
     def Run(self, tCurFrame: Frame, tRefFrame: Frame) -> int:
         ctx = self._context()

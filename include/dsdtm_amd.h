@@ -204,6 +204,24 @@ int dsdtm_sparse_align_frames(dsdtm_ctx* ctx, const dsdtm_frame* ref, const dsdt
                               const double* p_world, const uint8_t* initial, int n_features,
                               const double T_ref_w[12], double T_cur_w[12],
                               const dsdtm_align_params* params, int* n_tracked, dsdtm_align_stats* stats);
+/*
+ * Replaces: bool Feature_Alignment::FindMatchDirect(const MapPoint*, const FramePtr, Eigen::Vector2d&, int&)
+ *           (src/Feature_alignment.cpp:128-158, after Get_ClosetObs and the IsInImage test :135-140) for
+ *           M candidates at once on device-resident frames: SolveAffineMatrix / GetBestSearchLevel /
+ *           WarpAffine / GetPatchNoBoarder (:142-148), px / 2^level (:150), Align2DGaussNewton(.., 10, ..)
+ *           (:152), px * 2^level (:154-156). One call; the warped patches never leave the device.
+ * kf          : the keyframes' frames (same pyramid geometry as cur)
+ * cand_kf ... p_world, max_search_level : as dsdtm_warp_patches
+ * px_xy       : M x 2 double, in: the candidate's reprojected pixel (level 0), out: the refined pixel
+ *               (level 0), written back also when not converged (:414)
+ * search_level, converged : M outputs
+ */
+int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* cur, const dsdtm_frame* const* kf, int n_kf,
+                                  const dsdtm_camera* cam, const double* T_kf_w, const double T_cur_w[12],
+                                  const int32_t* cand_kf, const float* ref_px, const int32_t* ref_level,
+                                  const double* ref_bearing, const double* p_world, int max_search_level,
+                                  int max_iters, int m, double* px_xy, int32_t* search_level, uint8_t* converged);
+
 /* dsdtm_detect_cells on a device-resident frame (keyframe creation detects on the frame that was just tracked) */
 int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame, const uint8_t* grid_occupied,
                              const dsdtm_detect_params* params, float* cell_score, int32_t* cell_x,

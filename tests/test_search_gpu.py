@@ -73,6 +73,27 @@ def test_search_local_points_matches_sequential_reference_flow(gpu_ctx, seed):
     assert len(got) <= 200
 
 
+@pytest.mark.gpu
+def test_search_on_resident_frames_is_identical(gpu_ctx):
+    """dsdtm_match_candidates_frames (warp prelude + Align2D in one call on device-resident frames) gives
+    the two-call host path's matches bit for bit."""
+    Config.Set("Camera.CellSize", 25)
+    Config.Set("Camera.MaxPyraLevels", 5)
+    outs = []
+    for resident in (False, True):
+        cam, kfs, cur, mps = make_world(7, n_points=600)
+        s = search.LocalPointSearch(cam, ctx=gpu_ctx, resident_frames=resident)
+        s.ResetGrid()
+        for mp in mps:
+            s.ReprojectPoint(cur, mp)
+        mask = np.full((cam.height, cam.width), 255, np.uint8)
+        got = s.SearchLocalPoints(cur, kfs, mask)
+        idx = {id(mp): i for i, mp in enumerate(mps)}
+        outs.append(([(g[0], idx[id(g[1])], float(g[2][0]), float(g[2][1]), g[3]) for g in got], mask))
+    assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 100
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_fill_circle_matches_independent_version():
     rng = np.random.default_rng(0)
     for _ in range(50):
