@@ -270,6 +270,23 @@ public:
             }
             const Camera& c = *mCam;
             const dsdtm_camera cam{c.mfx, c.mfy, c.mcx, c.mcy, c.mf, c.mwidth, c.mheight};
+            bool resident = tFrame.mDev != nullptr;
+            for (Frame* k : keyframes) resident = resident && k->mDev != nullptr;
+            if (resident) {
+                // device-resident frames: warp prelude + Align2D in ONE call, px in and out in level-0 pixels
+                std::vector<const dsdtm_frame*> kd;
+                for (Frame* k : keyframes) kd.push_back(k->mDev);
+                for (int i = 0; i < m; ++i) {
+                    const std::array<double, 2>& p0 = cells[(size_t)cand[i].cell][(size_t)cand[i].pos].px;
+                    pxr[2 * i] = p0[0]; pxr[2 * i + 1] = p0[1];
+                }
+                const int rc = dsdtm_match_candidates_frames(ctx_(), tFrame.mDev, kd.data(), (int)kd.size(), &cam, Tk.data(),
+                                                             tFrame.Get_Pose().m.data(), ck.data(), rp.data(), rl.data(), rb.data(),
+                                                             pw.data(), Config::MaxPyraLevels() - 3, 10, m, pxr.data(), sl.data(),
+                                                             conv.data());
+                if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_match_candidates_frames: ") + dsdtm_last_error(ctx_()));
+                for (int i = 0; i < m; ++i) { pxr[2 * i] /= (1 << sl[i]); pxr[2 * i + 1] /= (1 << sl[i]); }   // (level units below)
+            } else {
             int rc = dsdtm_warp_patches(ctx_(), pyrs.data(), (int)pyrs.size(), &cam, Tk.data(), tFrame.Get_Pose().m.data(), ck.data(),
                                         rp.data(), rl.data(), rb.data(), pw.data(), Config::MaxPyraLevels() - 3, m, aff.data(),
                                         sl.data(), pb.data(), pp.data());
@@ -281,6 +298,7 @@ public:
             const dsdtm_pyramid cur = detail_to_pyr(tFrame.mvImg_Pyr);
             rc = dsdtm_align2d_batch(ctx_(), &cur, pb.data(), pp.data(), sl.data(), pxr.data(), conv.data(), 10, m);   // :152
             if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_align2d_batch: ") + dsdtm_last_error(ctx_()));
+            }
         }
         std::map<std::pair<int, int>, int> index;
         for (int i = 0; i < m; ++i) index[{cand[i].cell, cand[i].pos}] = i;

@@ -79,5 +79,17 @@ int main(int argc, char** argv) {
     unsigned long long sum = 0;
     for (uint8_t v : mask.data) sum += v;
     std::printf("mask_sum %llu\n", sum);
+    // the same search with every pyramid resident on the device (one library call for all candidates)
+    for (auto& k : kfs) k->ComputeImagePyramidOnDevice(levels);
+    cur->ComputeImagePyramidOnDevice(levels);
+    cur->mvFeatures.clear();
+    for (const auto& m : ms) m.mp->mnFound -= 1;                              // undo IncreaseFound of the first search
+    Image8 mask2(cam->mwidth, cam->mheight);
+    std::fill(mask2.data.begin(), mask2.data.end(), 255);
+    const std::vector<Feature_Alignment::Match> mr = fa.SearchLocalPoints(*cur, kfp, mask2);
+    bool same = mr.size() == ms.size() && mask2.data == mask.data;
+    for (size_t i = 0; same && i < ms.size(); ++i)
+        same = mr[i].cell == ms[i].cell && mr[i].mp == ms[i].mp && mr[i].px[0] == ms[i].px[0] && mr[i].px[1] == ms[i].px[1] && mr[i].level == ms[i].level;
+    std::printf("resident_same %d\n", same ? 1 : 0);
     return 0;
 }

@@ -127,3 +127,4 @@ def test_cpp_search_local_points_matches_the_python_mirror(tmp_path, gpu_ctx):
         assert (int(c), int(mi), int(lv)) == (g[0], idx[id(g[1])], g[3])
         assert np.float32(x) == g[2][0] and np.float32(y) == g[2][1]
     assert int(out[2 + len(got)].split()[1]) == int(mask.astype(np.uint64).sum())
+    assert out[3 + len(got)].split() == ["resident_same", "1"]         # device-resident frames: one library call, same matches
