@@ -41,6 +41,7 @@ def test_struct_layouts_match_the_header():
     # 3 ints + 3*8 ints (=108, padded to 112) + 8 size_t + pitch + 11 pointers
     assert C.sizeof(capi.BatchDesc) == 112 + 64 + 8 + 88
     assert C.sizeof(capi.ImageDesc) == 4 + 3 * 32 + 4 + 64 + 8 + 8
+    assert C.sizeof(capi.DetectParams) == 5 * 4 + 4
 
 
 def test_no_cpu_fallback_without_device():
