@@ -231,6 +231,64 @@ def test_batch_device_api_with_ragged_feature_counts(gpu_ctx, oracle):
             assert list(stg["iters"][i]) == so["iters"] and list(stg["n_ref"][i]) == so["n_ref"]
 
 
+def _device_batch(torch, dev, scenes, L, W, Hh):
+    """Packs scenes into device tensors + a BatchDesc (rows contiguous, all features used)."""
+    from dsdtm_amd import capi
+    ws, hs, st, offs, nbytes = capi.pyramid_layout(W, Hh, L)
+    pitch = (nbytes + 255) // 256 * 256
+    P, N = len(scenes), len(scenes[0].px)
+    ref = np.zeros((P, pitch), np.uint8); cur = np.zeros((P, pitch), np.uint8)
+    for i, sc in enumerate(scenes):
+        for l in range(L):
+            ref[i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.ref_pyr[l].reshape(-1)
+            cur[i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.cur_pyr[l].reshape(-1)
+    arr = dict(ref=ref, cur=cur, px=np.stack([s.px for s in scenes]), bear=np.stack([s.bearing for s in scenes]),
+               pw=np.stack([s.p_world for s in scenes]), ini=np.stack([s.initial for s in scenes]),
+               Tr=np.stack([s.T_ref_w.reshape(12) for s in scenes]), Tc=np.stack([s.T_cur_w_seed.reshape(12) for s in scenes]))
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in arr.items()}
+    t["nt"] = torch.zeros(P, dtype=torch.int32, device=dev)
+    b = capi.BatchDesc()
+    b.n_pairs, b.max_features, b.levels = P, N, L
+    for l in range(L):
+        b.width[l], b.height[l], b.stride[l], b.level_offset[l] = ws[l], hs[l], st[l], offs[l]
+    b.pyr_pitch = pitch
+    b.ref_pyr, b.cur_pyr, b.px_xy, b.bearing, b.p_world = (t[k].data_ptr() for k in ("ref", "cur", "px", "bear", "pw"))
+    b.initial, b.n_features, b.T_ref_w, b.T_cur_w = t["ini"].data_ptr(), None, t["Tr"].data_ptr(), t["Tc"].data_ptr()
+    b.n_tracked, b.stats = t["nt"].data_ptr(), None
+    return t, b
+
+
+def test_launches_in_flight_on_two_streams(gpu_ctx, oracle):
+    """Two batches launched back to back on two streams of one context (each launch has its own pair
+    counter; the persistent workgroups of both are resident together): both give the oracle's results."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L = 320, 240, 3
+    groups = [[cached_scene(width=W, height=Hh, levels=L, n_patches=n, seed=800 + 10 * g + i, margin=12) for i in range(p)]
+              for g, (n, p) in enumerate([(150, 9), (300, 7)])]
+    streams = [torch.cuda.Stream(device=dev) for _ in groups]
+    packed = [_device_batch(torch, dev, scenes, L, W, Hh) for scenes in groups]
+    cam = capi.camera_struct(groups[0][0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    torch.cuda.synchronize()
+    for rep in range(3):                                   # several rounds: counters are recycled from a ring
+        for (t, b), scenes in zip(packed, groups):
+            t["Tc"].copy_(torch.from_numpy(np.stack([s.T_cur_w_seed.reshape(12) for s in scenes])).to(dev))
+        torch.cuda.synchronize()
+        for (t, b), st in zip(packed, streams):
+            gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+        for st in streams:
+            st.synchronize()
+        for (t, b), scenes in zip(packed, groups):
+            Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+            for i, sc in enumerate(scenes):
+                To, no, _ = oracle.sparse_align(sc, L, 0, 10)
+                H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"round {rep} pair {i}")
+                assert ntg[i] == no
+
+
 def test_repeated_launches_are_bitwise_deterministic(gpu_ctx):
     """The pair-local LDS hand-over protocol (two pairs per workgroup, speculative factorisation)
     must not depend on timing: identical inputs -> bit-identical poses, launch after launch, for
