@@ -106,6 +106,12 @@ struct BlockState {
 // counters instead. All waves of a workgroup are co-resident, every wait has its producer in
 // flight, and every spin is bounded (a broken protocol ends the kernel instead of hanging the GPU).
 constexpr unsigned SPIN_LIMIT = 1u << 24;
+#ifndef SA_SLEEP_ARRIVE
+#define SA_SLEEP_ARRIVE 1   // solver waiting for the patch waves (and for acknowledgements)
+#endif
+#ifndef SA_SLEEP_SEQ
+#define SA_SLEEP_SEQ 4      // patch waves waiting for the solver (polling less often leaves issue slots and LDS to the others: +1 %)
+#endif
 // A spin that runs out means the protocol is broken: the wave leaves the wait (so the kernel always
 // terminates) and raises this device-global flag, which the host entry points turn into an error.
 __device__ unsigned g_handover_timeout = 0;
@@ -118,7 +124,7 @@ __device__ __forceinline__ void pair_signal_arrive(unsigned* counter, int lane) 
 __device__ __forceinline__ void pair_wait_arrive(unsigned* counter, unsigned target) {
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < SPIN_LIMIT)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SA_SLEEP_ARRIVE);
     if (spins >= SPIN_LIMIT) spin_timeout();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -129,7 +135,7 @@ __device__ __forceinline__ void pair_publish(BlockState& s, unsigned seq, int la
 __device__ __forceinline__ void pair_wait_seq(BlockState& s, unsigned seq) {
     unsigned spins = 0;
     while (__hip_atomic_load(&s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq && ++spins < SPIN_LIMIT)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SA_SLEEP_SEQ);
     if (spins >= SPIN_LIMIT) spin_timeout();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
