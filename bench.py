@@ -216,6 +216,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if not os.path.exists(capi.lib_path()):   # tooling convenience only: the product itself never builds or falls back
+        from dsdtm_amd.csrc import build as hip_build
+        if rank == 0:
+            hip_build.build(verbose=False)
+        if world > 1:
+            dist.barrier()
     ctx = capi.Context(local_rank)          # fails loudly without the HIP library / a gfx950 device
     cam = synth.Camera.tum(args.width, args.height)
     cam_struct = capi.camera_struct(cam)
