@@ -9,7 +9,7 @@ for so in "$@"; do
   touch dsdtm_amd/csrc/libdsdtm_amd.so
   for rep in 1 2; do
     echo "== $so run $rep" | tee -a gpurun_out/ab.log
-    python bench.py --steps 20 --warmup 3 --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline']['kernel_ms_avg'])" | tee -a gpurun_out/ab.log
+    python bench.py --steps 200 --warmup 20 --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline']['kernel_ms_avg'])" | tee -a gpurun_out/ab.log
   done
   if [ -n "$AB_CHECK" ]; then python -m pytest tests/test_sparse_align_gpu.py -x -q -m gpu -k "golden or config2 or random" 2>&1 | tail -2 | tee -a gpurun_out/ab.log; fi
   if [ -n "$AB_STAMPS" ]; then python tools/stamps.py 2>/dev/null | tail -6 | tee -a gpurun_out/ab.log; fi

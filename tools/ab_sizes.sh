@@ -7,6 +7,6 @@ for so in "$@"; do
   cp "$so" dsdtm_amd/csrc/libdsdtm_amd.so; touch dsdtm_amd/csrc/libdsdtm_amd.so
   for n in 512 1024 2048 4096; do
     echo -n "$so pairs=$n: " | tee -a gpurun_out/ab_sizes.log
-    python bench.py --steps 10 --warmup 2 --no-cpu --pairs $n | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']), round(d['roofline']['kernel_ms_avg'],4))" | tee -a gpurun_out/ab_sizes.log
+    python bench.py --steps 100 --warmup 10 --no-cpu --pairs $n | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']), round(d['roofline']['kernel_ms_avg'],4))" | tee -a gpurun_out/ab_sizes.log
   done
 done

@@ -6,7 +6,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/${1:-prof}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="$REPO/bench.py --steps 10 --warmup 2 --no-cpu"
+B="$REPO/bench.py --steps 200 --warmup 20 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $B > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $B > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $B > "$OUT/pmc_write.log" 2>&1
