@@ -133,6 +133,10 @@ def build_batch(torch, dev, ctx, cam, n_pairs, width, height, levels, n_patches,
         cw, ch = (int(v) for v in os.environ["DSDTM_BENCH_CLUSTER"].split("x"))
         px = np.stack([rng.uniform(width / 2 - cw / 2, width / 2 + cw / 2, (n_pairs, n_patches)),
                        rng.uniform(height / 2 - ch / 2, height / 2 + ch / 2, (n_pairs, n_patches))], axis=2).astype(np.float32)
+    if os.environ.get("DSDTM_BENCH_SORT"):      # diagnostic: spatially coherent feature order (128-px strips, then rows)
+        key = (px[:, :, 0] // 128).astype(np.int64) * 100000 + px[:, :, 1].astype(np.int64)
+        order = np.argsort(key, axis=1, kind="stable")
+        px = np.take_along_axis(px, order[:, :, None], axis=1)
     bearing = synth.bearing_from_px(cam, px.reshape(-1, 2)).reshape(n_pairs, n_patches, 3)
     X_r = bearing * (depth[:, None, None] / bearing[:, :, 2:3])
     Rr, tr = T_ref[:, :3, :3], T_ref[:, :3, 3]

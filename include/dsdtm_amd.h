@@ -106,7 +106,8 @@ int dsdtm_device_count(void);
  *           :240-299, GaussNewtonSolver :301-344.
  *
  * ref/cur     : pyramids of tRefFrame / tCurFrame (host memory)
- * px_xy       : n_features x 2 float  — Feature::mpx        (include/Feature.h:19)
+ * px_xy       : n_features x 2 float  — Feature::mpx        (include/Feature.h:19); any order (results do not
+ *               depend on it beyond summation rounding; a spatially coherent order gathers ~1.5 % faster)
  * bearing     : n_features x 3 double — Feature::mNormal    (include/Feature.h:24)
  * p_world     : n_features x 3 double — Feature::Mpt->Get_Pose() (src/MapPoint.cpp:38-43);
  *               ignored (may be anything) where initial[i]==0
