@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "device_math.h"
 #include "kernels.h"
 
 namespace dsdtm {
@@ -25,11 +26,14 @@ namespace dsdtm {
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-__global__ __launch_bounds__(256) void fast_score_kernel(const DetectArgs a, int level) {
+// (one launch covers all levels: blockIdx.z = level, the grid has level 0's extent and the blocks
+// outside a smaller level leave at once)
+__global__ __launch_bounds__(256) void fast_score_kernel(const DetectArgs a) {
+    const int level = blockIdx.z;
     const LevelGeom lg = a.lv[level];
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    if (x >= lg.w) return;
+    if (x >= lg.w || y >= lg.h) return;
     uint8_t* __restrict__ out = a.score + lg.off + (size_t)y * lg.stride + x;
     // faster_corner_10_sse.cpp:23-186: rows 3..h-4, columns 3..w-4
     if (x < 3 || x >= lg.w - 3 || y < 3 || y >= lg.h - 3) { *out = 0; return; }
@@ -59,63 +63,69 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const DetectArgs a, int
     *out = margin > a.barrier ? (uint8_t)(margin - 1) : (uint8_t)0;      // fast_10_score.cpp: largest such b
 }
 
-// Feature_detector::shiTomasiScore (:157-198). The three gradient sums are integers < 2^24 (exact in
-// float in any order); the rest follows the reference's float expression without contraction.
+// Feature_detector::shiTomasiScore (:157-198) for the corner (u, v), computed by the WHOLE wave: lane =
+// one pixel of the 8x8 box (the reference's 64-iteration loop), three integer wave sums. The gradient
+// sums are integers < 2^24 (exact in float in any order); the rest follows the reference's float
+// expression without contraction. u, v are wave-uniform.
 #pragma clang fp contract(off)
-__device__ __forceinline__ float shi_tomasi(const uint8_t* __restrict__ img, int w, int h, int stride, int u, int v) {
+__device__ __forceinline__ float shi_tomasi_wave(const uint8_t* __restrict__ img, int w, int h, int stride, int u, int v, int lane) {
     const int x_min = u - 4, x_max = u + 4, y_min = v - 4, y_max = v + 4;
-    if (x_min < 1 || x_max >= w - 1 || y_min < 1 || y_max >= h - 1) return 0.0f;
-    int sxx = 0, syy = 0, sxy = 0;
-    for (int y = y_min; y < y_max; ++y) {
-        const uint8_t* __restrict__ row = img + (size_t)stride * y + x_min;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const int dx = (int)row[x + 1] - (int)row[x - 1];
-            const int dy = (int)row[x + stride] - (int)row[x - stride];
-            sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
-        }
-    }
+    if (x_min < 1 || x_max >= w - 1 || y_min < 1 || y_max >= h - 1) return 0.0f;   // :173
+    const uint8_t* __restrict__ p = img + (size_t)stride * (y_min + (lane >> 3)) + x_min + (lane & 7);
+    const int dx = (int)p[1] - (int)p[-1];
+    const int dy = (int)p[stride] - (int)p[-stride];
+    const int sxx = wave_sum_i32(dx * dx), syy = wave_sum_i32(dy * dy), sxy = wave_sum_i32(dx * dy);
     const float dXX = (float)sxx / 128.0f, dYY = (float)syy / 128.0f, dXY = (float)sxy / 128.0f;   // / (2.0 * box_area), exact
     const float tr = dXX + dYY;
     const float disc = tr * tr - 4 * (dXX * dYY - dXY * dXY);
     return 0.5f * (tr - sqrtf(disc));
 }
 
-__global__ __launch_bounds__(256) void fast_select_kernel(const DetectArgs a, int level) {
+__global__ __launch_bounds__(256) void fast_select_kernel(const DetectArgs a) {
+    const int level = blockIdx.z;
     const LevelGeom lg = a.lv[level];
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    if (x < 3 || x >= lg.w - 3 || y < 3 || y >= lg.h - 3) return;
-    const uint8_t* __restrict__ sm = a.score + lg.off + (size_t)y * lg.stride + x;
-    const int s = *sm;
-    if (!s) return;
-    // nonmax_3x3.cpp:47-106: suppressed iff a neighbouring corner scores >= (ties suppress both)
-    const int st = lg.stride;
-    const int n0 = sm[-st - 1], n1 = sm[-st], n2 = sm[-st + 1], n3 = sm[-1], n4 = sm[1], n5 = sm[st - 1], n6 = sm[st], n7 = sm[st + 1];
-    if (imax(imax(imax(n0, n1), imax(n2, n3)), imax(imax(n4, n5), imax(n6, n7))) >= s) return;
-    if (a.keep) a.keep[lg.off + (size_t)y * lg.stride + x] = 1;
-    const int scale = 1 << level;
-    const int k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;     // :97-98
-    if (k < 0 || k >= a.grid_cols * a.grid_rows) return;
-    if (a.occupied && a.occupied[k]) return;                                                 // :100
-    const float sc = shi_tomasi(a.pyr + lg.off, lg.w, lg.h, lg.stride, x, y);                // :103
-    if (!(sc > a.detection_threshold)) return;                                               // :104 vs the initial score (:74)
-    // max score wins; among equal scores the first in (level, row, column) order, as the sequential
-    // loop's strict '>' leaves it
-    const unsigned order = ((unsigned)level << 28) | ((unsigned)y << 14) | (unsigned)x;
-    const unsigned long long key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xffffffffu - order);
-    atomicMax(a.cell_key + k, key);
+    const int lane = threadIdx.x & 63;
+    if (y >= lg.h || (int)(blockIdx.x * blockDim.x) >= lg.w) return;       // whole block outside the level (block-uniform)
+    bool cand = false;
+    int k = 0;
+    if (x >= 3 && x < lg.w - 3 && y >= 3 && y < lg.h - 3) {
+        const uint8_t* __restrict__ sm = a.score + lg.off + (size_t)y * lg.stride + x;
+        const int s = *sm;
+        if (s) {
+            // nonmax_3x3.cpp:47-106: suppressed iff a neighbouring corner scores >= (ties suppress both)
+            const int st = lg.stride;
+            const int n0 = sm[-st - 1], n1 = sm[-st], n2 = sm[-st + 1], n3 = sm[-1], n4 = sm[1], n5 = sm[st - 1], n6 = sm[st], n7 = sm[st + 1];
+            if (imax(imax(imax(n0, n1), imax(n2, n3)), imax(imax(n4, n5), imax(n6, n7))) < s) {
+                if (a.keep) a.keep[lg.off + (size_t)y * lg.stride + x] = 1;
+                const int scale = 1 << level;
+                k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;      // :97-98
+                cand = k >= 0 && k < a.grid_cols * a.grid_rows && !(a.occupied && a.occupied[k]);   // :100
+            }
+        }
+    }
+    // the survivors of this wave's 64 pixels, one after the other, each scored by all 64 lanes
+    unsigned long long todo = __ballot(cand);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int cx = __builtin_amdgcn_readlane(x, src);
+        const float sc = shi_tomasi_wave(a.pyr + lg.off, lg.w, lg.h, lg.stride, cx, y, lane);   // :103
+        if (lane == src && sc > a.detection_threshold) {                                        // :104 vs the initial score (:74)
+            // max score wins; among equal scores the first in (level, row, column) order, as the sequential
+            // loop's strict '>' leaves it
+            const unsigned order = ((unsigned)level << 28) | ((unsigned)y << 14) | (unsigned)x;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xffffffffu - order);
+            atomicMax(a.cell_key + k, key);
+        }
+    }
 }
 
 hipError_t detect_launch(const DetectArgs& a, int levels, hipStream_t stream) {
-    for (int l = 0; l < levels; ++l) {
-        const dim3 grid((unsigned)((a.lv[l].w + 255) / 256), (unsigned)a.lv[l].h);
-        hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, stream, a, l);
-    }
-    for (int l = 0; l < levels; ++l) {
-        const dim3 grid((unsigned)((a.lv[l].w + 255) / 256), (unsigned)a.lv[l].h);
-        hipLaunchKernelGGL(fast_select_kernel, grid, dim3(256), 0, stream, a, l);
-    }
+    const dim3 grid((unsigned)((a.lv[0].w + 255) / 256), (unsigned)a.lv[0].h, (unsigned)levels);
+    hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(fast_select_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
