@@ -33,6 +33,7 @@ struct dsdtm_ctx {
     // (each zeroed by a memset node on the launch stream right before its kernel)
     unsigned* d_counter = nullptr;
     unsigned launch_seq = 0;
+    unsigned* d_timeout_flag = nullptr;   // device address of the kernel's hand-over timeout flag
     int num_cus = 256;
 };
 
@@ -296,7 +297,7 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     const size_t o_nt = o; o += 256;
     const size_t o_st = o; o += align_up(sizeof(dsdtm_align_stats), 256);
     const size_t total = o;
-    if (int rc = ensure_stage(ctx, total)) return rc;
+    if (int rc = ensure_stage(ctx, total + 256)) return rc;
     uint8_t* h = (uint8_t*)ctx->h_pinned;
     uint8_t* d = (uint8_t*)ctx->d_stage;
     if (staged_pyr) {
@@ -323,11 +324,16 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     b.n_tracked = (int32_t*)(d + o_nt); b.stats = (dsdtm_align_stats*)(d + o_st);
     if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, ctx->stream)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
+    // the kernel's hand-over timeout flag travels back with the results (no extra round trip)
+    if (!ctx->d_timeout_flag) HIP_TRY(ctx, sparse_align_timeout_flag_address(&ctx->d_timeout_flag));
+    unsigned* h_flag = (unsigned*)(h + total);
+    *h_flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(h_flag, ctx->d_timeout_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    {
-        unsigned timeout_flag = 0;
-        HIP_TRY(ctx, sparse_align_take_timeout_flag(&timeout_flag));
-        if (timeout_flag) { set_err(ctx, "sparse-align kernel: intra-workgroup hand-over timed out"); return DSDTM_ERR_HIP; }
+    if (*h_flag) {
+        (void)sparse_align_clear_timeout_flag();
+        set_err(ctx, "sparse-align kernel: intra-workgroup hand-over timed out");
+        return DSDTM_ERR_HIP;
     }
     memcpy(T_cur_w, h + o_tc, 96);
     *n_tracked = *(const int32_t*)(h + o_nt);

@@ -55,7 +55,8 @@ SAVariant sparse_align_pick_variant(int max_features);
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features);
 hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream);
 // diagnostic (in-kernel stamps) instantiation of the 5+1-wave register kernel; workspace = n_pairs*8 u64
-hipError_t sparse_align_take_timeout_flag(unsigned* flag);   // device-side hand-over timeout (should never fire)
+hipError_t sparse_align_timeout_flag_address(unsigned** addr);   // device-side hand-over timeout flag (should never be set)
+hipError_t sparse_align_clear_timeout_flag();
 int sparse_align_occupancy(int variant);   // occupancy API answer (workgroups per CU)
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream);
 

@@ -1332,15 +1332,15 @@ size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
     return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
 }
 
-// reads (and clears) the hand-over timeout flag; synchronous, host entry points only
-hipError_t sparse_align_take_timeout_flag(unsigned* flag) {
-    hipError_t e = hipMemcpyFromSymbol(flag, HIP_SYMBOL(g_handover_timeout), sizeof(unsigned));
-    if (e != hipSuccess) return e;
-    if (*flag) {
-        const unsigned zero = 0;
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_handover_timeout), &zero, sizeof(unsigned));
-    }
-    return e;
+// Device address of the hand-over timeout flag of the current device: the host entry points copy it
+// back together with their results (one D2H on the stream, no extra synchronisation) and clear it with
+// sparse_align_clear_timeout_flag in the rare case it is set.
+hipError_t sparse_align_timeout_flag_address(unsigned** addr) {
+    return hipGetSymbolAddress((void**)addr, HIP_SYMBOL(g_handover_timeout));
+}
+hipError_t sparse_align_clear_timeout_flag() {
+    const unsigned zero = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_handover_timeout), &zero, sizeof(unsigned));
 }
 
 int sparse_align_occupancy(int variant) {
