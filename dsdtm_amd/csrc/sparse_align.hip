@@ -965,7 +965,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 continue;
             }
             const int next_raw = claim_issue();                        // latency hidden under this pair
-            unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0;
+            unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0, t_refresh = 0;
             unsigned long long t_sub[3] = {0, 0, 0};
             if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
             if (staged) commit_next(*(LdsBlockState*)&s, lane);        // prepared while the previous pair was running
@@ -986,7 +986,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 expected_h += NPW;
                 pair_wait_arrive(&s.arrive_h, expected_h);             // BH
                 double hrow[6];
+                unsigned long long tr0 = 0;
+                if (STAMPS) tr0 = __builtin_amdgcn_s_memtime();
                 solver_refresh_H<NP>(s_part, s, lane, hrow);
+                if (STAMPS) { asm volatile("" : "+v"(hrow[0])); t_refresh += __builtin_amdgcn_s_memtime() - tr0; }
                 for (int it = 0; it < a.max_iters; ++it) {
                     unsigned long long t0 = 0, t1 = 0, t2 = 0;
                     if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
@@ -1025,6 +1028,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 o[5] = t_sub[0];
                 o[6] = t_sub[1];
                 o[7] = t_sub[2];
+                ((unsigned long long*)a.workspace)[(size_t)a.n_pairs * 48 + pair] = t_refresh;
             }
             pair = claim_value(next_raw);
         }
@@ -1051,6 +1055,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
         unsigned long long st_pre = 0, st_pass = 0, st_h = 0, st_bar = 0;
         unsigned long long st_lvl[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // pass cycles / pass count of levels 0..3
         unsigned long long st_plv[4] = {0, 0, 0, 0}, st_first[4] = {0, 0, 0, 0};   // precompute / first-pass cycles of levels 0..3
+        unsigned long long st_bfirst[4] = {0, 0, 0, 0};                            // wait for the solver after the first pass
         FeatureRegs F;
         {
             const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
@@ -1138,7 +1143,14 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 ++seen;
                 pair_signal_arrive(&s.arrive, lane);                   // B1
                 pair_wait_seq(s, seen);                                // B2
-                if (STAMPS) st_bar += __builtin_amdgcn_s_memtime() - tq2;
+                if (STAMPS) {
+                    const unsigned long long dtb = __builtin_amdgcn_s_memtime() - tq2;
+                    st_bar += dtb;
+                    if (it == 0) {
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) if (l == level) st_bfirst[l] += dtb;
+                    }
+                }
                 if (s.ctrl) break;
             }
         }
@@ -1151,6 +1163,9 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 36 + (size_t)pair * 8;
 #pragma unroll
             for (int l = 0; l < 4; ++l) { o[l] = st_plv[l]; o[4 + l] = st_first[l]; }
+            unsigned long long* o2 = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 44 + (size_t)pair * 4;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) o2[l] = st_bfirst[l];
         }
         if (STAMPS && ltid == 0 && a.workspace) {
             unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 8 + (size_t)pair * 12;

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0); ctx = capi.Context(0)
 cam = synth.Camera.tum(640, 480); cs = capi.camera_struct(cam); prm = capi.AlignParams(4, 0, 10, 15)
 st = torch.cuda.Stream(device=dev)
 d = bench.build_batch(torch, dev, ctx, cam, a.pairs, 640, 480, 4, 300, seed=0xD5D7, stream=st)
-stamps = torch.zeros((a.pairs * 44,), dtype=torch.int64, device=dev)
+stamps = torch.zeros((a.pairs * 49,), dtype=torch.int64, device=dev)
 f = ctx.lib.dsdtm_debug_sparse_align_stamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.POINTER(capi.BatchDesc), C.POINTER(capi.Camera), C.POINTER(capi.AlignParams), C.c_void_p, C.c_void_p]
 for rep in range(3):
@@ -22,7 +22,9 @@ allst = stamps.cpu().numpy().astype(np.float64)
 s = allst[:a.pairs*8].reshape(a.pairs, 8)
 w = allst[a.pairs*8:a.pairs*20].reshape(a.pairs, 12)
 pw = allst[a.pairs*20:a.pairs*36].reshape(a.pairs, 16)
-lv = allst[a.pairs*36:].reshape(a.pairs, 8)
+lv = allst[a.pairs*36:a.pairs*44].reshape(a.pairs, 8)
+bf = allst[a.pairs*44:a.pairs*48].reshape(a.pairs, 4)
+rf = allst[a.pairs*48:]
 n_it = s[:, 3]
 print("pairs", a.pairs, "iterations/pair mean", n_it.mean())
 print("cycles per block: total %.0f | first-pass waits (4 levels) %.0f | later-pass waits %.0f | solve %.0f" % (s[:,4].mean(), s[:,0].mean(), s[:,1].mean(), s[:,2].mean()))
@@ -32,6 +34,8 @@ print("wave0: precompute %.0f (per level %.0f) | passes %.0f (per pass %.0f) | H
 print("wave0 pass cycles by level 0..3: " + " | ".join("%.0f (%.1f passes)" % ((w[:,4+l]/np.maximum(w[:,8+l],1)).mean(), w[:,8+l].mean()) for l in range(4)))
 print("per patch wave, cycles per iteration: pass " + " ".join("%.0f" % (pw[:,k]/n_it).mean() for k in range(5)) + " | wait for solver " + " ".join("%.0f" % (pw[:,8+k]/n_it).mean() for k in range(5)))
 print("wave0 per level 0..3: precompute " + " ".join("%.0f" % lv[:,l].mean() for l in range(4)) + " | first pass " + " ".join("%.0f" % lv[:,4+l].mean() for l in range(4)))
+print("wave0 wait for the solver after the FIRST pass of levels 0..3: " + " ".join("%.0f" % bf[:,l].mean() for l in range(4)) + " (later passes: %.0f)" % ((w[:,3] - bf.sum(1)) / np.maximum(n_it - 4, 1)).mean())
+print("solver: H sum + factorisation + H^+ per level %.0f cycles" % (rf / 4).mean())
 # pair-duration spread and what it costs a 2-pairs-per-slot launch (list scheduling on 512 slots)
 dur = s[:, 4]
 print("pair cycles: mean %.0f | p5 %.0f | p50 %.0f | p95 %.0f | max %.0f" % (dur.mean(), *np.percentile(dur, [5, 50, 95]), dur.max()))
