@@ -9,5 +9,7 @@ from .frame import Camera, Config, Frame  # noqa: F401
 from .sparse_align import Sprase_ImgAlign  # noqa: F401
 from .feature_alignment import Feature_Alignment  # noqa: F401
 from .feature_detection import Feature_detector  # noqa: F401
+from .optimizer import Optimizer  # noqa: F401
 
-__all__ = ["Camera", "Config", "Frame", "Sprase_ImgAlign", "Feature_Alignment", "Feature_detector"]
+__all__ = ["Camera", "Config", "Frame", "Sprase_ImgAlign", "Feature_Alignment", "Feature_detector",
+           "Optimizer"]

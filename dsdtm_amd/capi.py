@@ -128,12 +128,33 @@ EXPORTED_SYMBOLS = [
     "dsdtm_pyrdown_batch_device", "dsdtm_pyrdown", "dsdtm_warp_patches",
     "dsdtm_frame_create", "dsdtm_frame_create_from_image", "dsdtm_frame_destroy", "dsdtm_sparse_align_frames",
     "dsdtm_detect_cells", "dsdtm_detect_cells_frame", "dsdtm_match_candidates_frames",
+    "dsdtm_pose_optimization", "dsdtm_pose_optimization_batch_device",
 ]
 
 
 class DetectParams(C.Structure):
     _fields_ = [("cell_size", C.c_int32), ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("levels", C.c_int32),
                 ("barrier", C.c_int32), ("detection_threshold", C.c_float)]
+
+
+class PoseOptParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PoseOptSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("successful_steps", C.c_int32), ("termination", C.c_int32),
+                ("n_residual_blocks", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("x", C.c_double * 6)]
+
+    def as_dict(self):
+        return dict(iterations=self.iterations, successful_steps=self.successful_steps, termination=self.termination,
+                    n_residual_blocks=self.n_residual_blocks, initial_cost=self.initial_cost,
+                    final_cost=self.final_cost, x=np.array(list(self.x)))
+
+
+# dsdtm_pose_opt_termination
+PO_FUNCTION_TOLERANCE, PO_PARAMETER_TOLERANCE, PO_GRADIENT_TOLERANCE, PO_MAX_ITERATIONS = 0, 1, 2, 3
+PO_MIN_RADIUS, PO_INVALID_STEPS, PO_NO_RESIDUALS, PO_EVALUATION_FAILED = 4, 5, 6, 7
 
 _LIB = None
 LIB_NAME = "libdsdtm_amd.so"

@@ -827,6 +827,77 @@ extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* 
     return DSDTM_OK;
 }
 
+// ---- Optimizer::PoseOptimization ---------------------------------------------------------------
+extern "C" int dsdtm_pose_optimization_batch_device(dsdtm_ctx* ctx, int n_frames, int max_features,
+                                                    const int32_t* n_features, const double* bearing,
+                                                    const double* p_world, const int32_t* level, const uint8_t* use,
+                                                    double* T_cur_w, const dsdtm_pose_opt_params* params,
+                                                    double* residual_norm, dsdtm_pose_opt_summary* summary,
+                                                    void* hip_stream) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (n_frames < 0 || max_features < 0 || !params || params->max_iterations < 0) {
+        set_err(ctx, "bad argument"); return DSDTM_ERR_INVALID;
+    }
+    if (n_frames == 0) return DSDTM_OK;
+    if (!T_cur_w || !summary || (max_features > 0 && (!bearing || !p_world || !level || !use || !residual_norm))) {
+        set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    PoseOptArgs a;
+    a.n_frames = n_frames; a.max_features = max_features; a.max_iterations = params->max_iterations;
+    a.n_features = n_features; a.bearing = bearing; a.p_world = p_world; a.level = level; a.use = use;
+    a.T_cur_w = T_cur_w; a.residual_norm = residual_norm; a.summary = summary;
+    HIP_TRY(ctx, pose_opt_launch(a, (hipStream_t)hip_stream));
+    return DSDTM_OK;
+}
+
+extern "C" int dsdtm_pose_optimization(dsdtm_ctx* ctx, const double* bearing, const double* p_world,
+                                       const int32_t* level, const uint8_t* use, int n_features,
+                                       double T_cur_w[12], const dsdtm_pose_opt_params* params,
+                                       double* residual_norm, dsdtm_pose_opt_summary* summary) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!T_cur_w || !params || !summary || n_features < 0 ||
+        (n_features > 0 && (!bearing || !p_world || !level || !use || !residual_norm))) {
+        set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID;
+    }
+    for (int i = 0; i < n_features; ++i)
+        if (use[i] && (level[i] < 0 || level[i] >= DSDTM_MAX_LEVELS)) {
+            set_err(ctx, "feature %d: level %d out of range", i, level[i]); return DSDTM_ERR_INVALID;
+        }
+    const size_t N = (size_t)n_features;
+    size_t o = 0;
+    const size_t o_T = o;   o += 12 * 8;                       // in/out
+    const size_t o_sm = o;  o += align_up(sizeof(dsdtm_pose_opt_summary), 8);   // out
+    const size_t o_rn = o;  o += N * 8;                        // out
+    const size_t out_end = o;
+    const size_t o_b = o;   o += N * 24;
+    const size_t o_p = o;   o += N * 24;
+    const size_t o_l = o;   o += N * 4;
+    const size_t o_u = o;   o += align_up(N, 8);
+    const size_t total = o;
+    if (int rc = ensure_stage(ctx, total)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    memcpy(h + o_T, T_cur_w, 96);
+    if (N) {
+        memcpy(h + o_b, bearing, N * 24);
+        memcpy(h + o_p, p_world, N * 24);
+        memcpy(h + o_l, level, N * 4);
+        memcpy(h + o_u, use, N);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = dsdtm_pose_optimization_batch_device(ctx, 1, n_features, nullptr, (const double*)(d + o_b),
+                                                      (const double*)(d + o_p), (const int32_t*)(d + o_l), d + o_u,
+                                                      (double*)(d + o_T), params, (double*)(d + o_rn),
+                                                      (dsdtm_pose_opt_summary*)(d + o_sm), ctx->stream)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(h, d, out_end, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(T_cur_w, h + o_T, 96);
+    memcpy(summary, h + o_sm, sizeof(*summary));
+    if (summary->n_residual_blocks > 0) memcpy(residual_norm, h + o_rn, (size_t)summary->n_residual_blocks * 8);
+    return DSDTM_OK;
+}
+
 // ---- debug: device self-test of the FP64 building blocks (not in the public header) ------------
 extern "C" int dsdtm_debug_selftest(dsdtm_ctx* ctx, const double* in, double* out, int n_cases) {
     if (!ctx || !in || !out || n_cases < 0) return DSDTM_ERR_INVALID;

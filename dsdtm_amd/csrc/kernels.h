@@ -113,6 +113,20 @@ struct WarpKernelArgs {
 };
 hipError_t warp_launch(const WarpKernelArgs& args, hipStream_t stream);
 
+// Pose-only refinement (Optimizer::PoseOptimization): one wavefront per frame.
+struct PoseOptArgs {
+    int n_frames, max_features, max_iterations;
+    const int32_t* n_features;     // per frame; null = max_features for every frame
+    const double* bearing;         // n_frames x max_features x 3
+    const double* p_world;         // n_frames x max_features x 3
+    const int32_t* level;          // n_frames x max_features
+    const uint8_t* use;            // n_frames x max_features
+    double* T_cur_w;               // n_frames x 12 (in/out)
+    double* residual_norm;         // n_frames x max_features
+    dsdtm_pose_opt_summary* summary;   // n_frames
+};
+hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream);
+
 // device self-test of the FP64 building blocks (wave reduction, LDLT, SE3); see selftest.hip
 hipError_t selftest_launch(const double* in, double* out, int n_cases, hipStream_t stream);
 

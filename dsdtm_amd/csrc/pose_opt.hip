@@ -1,0 +1,367 @@
+// pose_opt.hip — Optimizer::PoseOptimization (reference src/Optimizer.cpp:20-101): pose-only refinement
+// of one frame against its map-point observations. SURVEY.md §8(f)3.
+//
+// What the reference runs is a Ceres problem with ONE free 6-parameter block [t, log R] (the map
+// points are set constant, :60-61), FullBA_Problem residuals (include/Optimizer.h:129-216),
+// CauchyLoss(1.0), PoseLocalParameterization (include/Optimizer.h:219-252) and the default
+// trust-region Levenberg-Marquardt minimiser, at most 100 iterations (:68-72). The minimiser is
+// restated in oracle/pose_opt_oracle.c (see its header for what is the reference's and what is Ceres');
+// this kernel is the same algorithm with the damped step taken from the 6x6 normal equations.
+//
+// Mapping: one wavefront per frame (problem). Lane l evaluates features l, l+64, ... — residual,
+// 2x6 Jacobian, Cauchy weight — and accumulates its share of J^T J (21), J^T r (6) and the cost in
+// VGPRs; one DPP reduction per value per evaluation (fixed order: deterministic). The trust-region
+// logic, the 6x6 Cholesky and the SE(3) algebra are wave-uniform and run redundantly on all lanes
+// (the cost of one lane). Every candidate is evaluated WITH its Jacobian, so an accepted step — the
+// common case — needs no second pass over the features. Nothing is staged: a frame's feature columns
+// (<= ~60 B per feature) stay in L1/L2 across the <= 100 iterations.
+// Roofline: the kernel is FP64-latency bound on one wave per problem (five divisions per feature and
+// evaluation); throughput comes from problems in flight, not from bandwidth.
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+#include "device_math.h"
+#include "kernels.h"
+
+namespace dsdtm {
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v = wave_sum_to_lane63(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// x = [t, w] -> SE3(SO3::exp(w), t) (include/Optimizer.h:147)
+__device__ __forceinline__ SE3d pose_of(const double* x) {
+    const double e[6] = {0.0, 0.0, 0.0, x[3], x[4], x[5]};
+    SE3d T = se3_exp(e);
+    T.tx = x[0]; T.ty = x[1]; T.tz = x[2];
+    return T;
+}
+
+// Sophus SO3::log (atan form) of a unit quaternion
+__device__ __forceinline__ void so3_log(const SE3d& q, double* w) {
+    const double n = sqrt(q.qx * q.qx + q.qy * q.qy + q.qz * q.qz);
+    const double qw = q.qw;
+    double f;
+    if (n < 1e-10) f = 2. / qw - 2. * (n * n) / (qw * (qw * qw));
+    else f = 2 * atan(n / qw) / n;
+    w[0] = f * q.qx; w[1] = f * q.qy; w[2] = f * q.qz;
+}
+
+// PoseLocalParameterization::Plus (include/Optimizer.h:222-236)
+__device__ __forceinline__ void pose_plus(const double* x, const double* d, double* out) {
+    const SE3d To = pose_of(x);
+    const SE3d Td = pose_of(d);
+    const SE3d Tn = se3_mul(Td, To);
+    out[0] = Tn.tx; out[1] = Tn.ty; out[2] = Tn.tz;
+    so3_log(Tn, out + 3);
+}
+
+__device__ __forceinline__ bool finite6(const double* v) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ok = ok && isfinite(v[i]);
+    return ok;
+}
+
+struct Frame {
+    const double* bearing;
+    const double* pw;
+    const int32_t* level;
+    const uint8_t* use;
+    int n;
+};
+
+// FullBA_Problem::Evaluate of one feature at pose T (include/Optimizer.h:139-197); false when unused
+__device__ __forceinline__ bool block_residual(const Frame& f, int i, const SE3d& T, double& r0, double& r1,
+                                               double& px, double& py, double& pz) {
+    if (i >= f.n || !f.use[i]) return false;
+    const double b0 = f.bearing[3 * (size_t)i], b1 = f.bearing[3 * (size_t)i + 1], b2 = f.bearing[3 * (size_t)i + 2];
+    const double X = f.pw[3 * (size_t)i], Y = f.pw[3 * (size_t)i + 1], Z = f.pw[3 * (size_t)i + 2];
+    double rx, ry, rz;
+    quat_rotate(T, X, Y, Z, rx, ry, rz);
+    px = rx + T.tx; py = ry + T.ty; pz = rz + T.tz;
+    const double inv_scale = __hiloint2double((1023 - (f.level[i] & 31)) << 20, 0);   // 1 / (1 << level), exact
+    r0 = (b0 / b2 - px / pz) * inv_scale;
+    r1 = (b1 / b2 - py / pz) * inv_scale;
+    return true;
+}
+
+// Program evaluation at x: cost = sum 1/2 rho(|r|^2); H = J^T J (upper triangle, row-major), g = J^T r of
+// the loss-corrected blocks. All outputs wave-uniform. ok = false when anything was not finite.
+__device__ void evaluate(const Frame& f, int lane, const double* x, double& cost, double* H, double* g, bool& ok) {
+    const SE3d T = pose_of(x);
+    double c = 0.0, h[21], gg[6];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) h[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gg[k] = 0.0;
+    for (int i = lane; i < f.n; i += 64) {
+        double r0, r1, px, py, pz;
+        if (!block_residual(f, i, T, r0, r1, px, py, pz)) continue;
+        const double z_inv = 1.0 / pz;
+        const double z_inv2 = z_inv * z_inv;
+        double J0[6], J1[6];
+        J0[0] = -z_inv; J0[1] = 0.0; J0[2] = px * z_inv2; J0[3] = py * J0[2]; J0[4] = -(1.0 + px * J0[2]); J0[5] = py * z_inv;
+        J1[0] = 0.0; J1[1] = -z_inv; J1[2] = py * z_inv2; J1[3] = 1.0 + py * J1[2]; J1[4] = -px * J1[2]; J1[5] = -px * z_inv;
+        bad = bad || !(isfinite(r0) && isfinite(r1) && finite6(J0) && finite6(J1));
+        const double s = r0 * r0 + r1 * r1;
+        const double sum = 1.0 + s;                         // CauchyLoss(1.0): b = c = 1
+        const double inv = 1.0 / sum;
+        c += 0.5 * log(sum);
+        const double sq = sqrt(fmax(inv, DBL_MIN));         // Corrector, alpha = 0 (rho'' < 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { J0[k] *= sq; J1[k] *= sq; }
+        r0 *= sq; r1 *= sq;
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            gg[a] += J0[a] * r0 + J1[a] * r1;
+#pragma unroll
+            for (int b = a; b < 6; ++b) { h[q] += J0[a] * J0[b] + J1[a] * J1[b]; ++q; }
+        }
+    }
+    cost = wave_sum_all(c);
+#pragma unroll
+    for (int k = 0; k < 21; ++k) H[k] = wave_sum_all(h[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[k] = wave_sum_all(gg[k]);
+    ok = __ballot(bad) == 0ull && isfinite(cost);
+}
+
+#define PO_U(i, j) ((i) * 6 - ((i) * ((i) - 1)) / 2 + ((j) - (i)))   /* packed upper index, i <= j */
+
+// Cholesky solve of the SPD system M y = v; M as packed upper triangle. false on a non-positive pivot.
+__device__ __forceinline__ bool chol6_solve(const double* M, const double* v, double* y) {
+    double L[21];   // lower factor, packed by rows: L(i,j) at i(i+1)/2 + j
+#define PO_L(i, j) L[((i) * ((i) + 1)) / 2 + (j)]
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = M[PO_U(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= PO_L(j, k) * PO_L(j, k);
+        ok = ok && (d > 0.0);
+        const double ljj = sqrt(d);
+        PO_L(j, j) = ljj;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s = M[PO_U(j, i)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= PO_L(i, k) * PO_L(j, k);
+            PO_L(i, j) = s / ljj;
+        }
+    }
+    double z[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = v[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= PO_L(i, k) * z[k];
+        z[i] = s / PO_L(i, i);
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = z[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= PO_L(k, i) * y[k];
+        y[i] = s / PO_L(i, i);
+    }
+#undef PO_L
+    return ok;
+}
+
+__device__ __forceinline__ double norm6(const double* v) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += v[i] * v[i];
+    return sqrt(s);
+}
+
+__device__ __forceinline__ double gradient_max_norm(const double* x, const double* g) {
+    double ng[6], xp[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ng[k] = -g[k];
+    pose_plus(x, ng, xp);
+    double m = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m = fmax(m, fabs(x[k] - xp[k]));
+    return m;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void pose_opt_kernel(PoseOptArgs a) {
+    const int frame = blockIdx.x;
+    if (frame >= a.n_frames) return;
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)frame * a.max_features;
+    Frame f;
+    f.bearing = a.bearing + base * 3;
+    f.pw = a.p_world + base * 3;
+    f.level = a.level + base;
+    f.use = a.use + base;
+    f.n = a.n_features ? a.n_features[frame] : a.max_features;
+    if (f.n > a.max_features) f.n = a.max_features;
+    double* Tio = a.T_cur_w + (size_t)frame * 12;
+
+    // residual blocks (src/Optimizer.cpp:45-65)
+    int n_blocks = 0;
+    for (int b0 = 0; b0 < f.n; b0 += 64) {
+        const int i = b0 + lane;
+        n_blocks += __popcll(__ballot(i < f.n && f.use[i]));
+    }
+
+    // parameter block (src/Optimizer.cpp:35-37)
+    const SE3d T0 = se3_from_rt(Tio);
+    double x[6] = {T0.tx, T0.ty, T0.tz, 0.0, 0.0, 0.0};
+    so3_log(T0, x + 3);
+
+    int termination = DSDTM_PO_MAX_ITERATIONS, iterations = 0, successful = 0;
+    double x_cost = 0.0, initial_cost = 0.0;
+    double H[21], g[6];
+    bool ok;
+    if (n_blocks == 0) {
+        termination = DSDTM_PO_NO_RESIDUALS;
+    } else {
+        evaluate(f, lane, x, x_cost, H, g, ok);
+        if (!ok) {
+            termination = DSDTM_PO_EVALUATION_FAILED;
+            x_cost = 0.0;
+        } else {
+            initial_cost = x_cost;
+            double scale[6], diagonal[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) scale[k] = 1.0 / (1.0 + sqrt(H[PO_U(k, k)]));   // Jacobi scaling, fixed
+            double x_norm = norm6(x);
+            double gmax = gradient_max_norm(x, g);
+            double radius = 1e4, decrease_factor = 2.0;
+            bool reuse_diagonal = false;
+            int invalid_steps = 0, it = 0;
+            for (;;) {
+                if (it >= a.max_iterations) { termination = DSDTM_PO_MAX_ITERATIONS; break; }
+                if (gmax <= 1e-10) { termination = DSDTM_PO_GRADIENT_TOLERANCE; break; }
+                if (radius <= 1e-32) { termination = DSDTM_PO_MIN_RADIUS; break; }
+                ++it;
+                // scaled system: As = S H S, gs = S g
+                double As[21], gs[6], M[21];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    gs[i] = scale[i] * g[i];
+#pragma unroll
+                    for (int j = i; j < 6; ++j) As[PO_U(i, j)] = (scale[i] * H[PO_U(i, j)]) * scale[j];
+                }
+                if (!reuse_diagonal) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) diagonal[k] = fmin(fmax(As[PO_U(k, k)], 1e-6), 1e32);
+                }
+#pragma unroll
+                for (int k = 0; k < 21; ++k) M[k] = As[k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double lm = sqrt(diagonal[k] / radius);
+                    M[PO_U(k, k)] += lm * lm;
+                }
+                double y[6], step[6];
+                bool solved = chol6_solve(M, gs, y);
+                solved = solved && finite6(y);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) step[k] = -y[k];
+                double lin = 0.0, quad = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    lin += gs[i] * step[i];
+                    double s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) s += As[i <= j ? PO_U(i, j) : PO_U(j, i)] * step[j];
+                    quad += step[i] * s;
+                }
+                const double model_cost_change = -(lin + quad / 2.0);
+                reuse_diagonal = true;
+                if (!(solved && model_cost_change > 0.0)) {
+                    if (++invalid_steps >= 5) { termination = DSDTM_PO_INVALID_STEPS; break; }
+                    radius = radius / decrease_factor;
+                    decrease_factor *= 2.0;
+                    continue;
+                }
+                invalid_steps = 0;
+                double delta[6], cand[6], cand_cost, Hc[21], gc[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) delta[k] = step[k] * scale[k];
+                pose_plus(x, delta, cand);
+                bool cand_ok = finite6(cand);
+                if (cand_ok) evaluate(f, lane, cand, cand_cost, Hc, gc, cand_ok);
+                if (!cand_ok) cand_cost = DBL_MAX;
+                double diff[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) diff[k] = x[k] - cand[k];
+                if (norm6(diff) <= 1e-8 * (x_norm + 1e-8)) { termination = DSDTM_PO_PARAMETER_TOLERANCE; break; }
+                const double cost_change = x_cost - cand_cost;
+                if (fabs(cost_change) <= 1e-6 * x_cost) { termination = DSDTM_PO_FUNCTION_TOLERANCE; break; }
+                const double relative_decrease = cost_change / model_cost_change;
+                if (relative_decrease > 1e-3) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) { x[k] = cand[k]; g[k] = gc[k]; }
+#pragma unroll
+                    for (int k = 0; k < 21; ++k) H[k] = Hc[k];
+                    x_cost = cand_cost;
+                    x_norm = norm6(x);
+                    gmax = gradient_max_norm(x, g);
+                    ++successful;
+                    const double t = 2.0 * relative_decrease - 1.0;
+                    radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+                    radius = fmin(1e16, radius);
+                    decrease_factor = 2.0;
+                    reuse_diagonal = false;
+                } else {
+                    radius = radius / decrease_factor;
+                    decrease_factor *= 2.0;
+                    reuse_diagonal = true;
+                }
+            }
+            iterations = it;
+        }
+    }
+
+    // Set_Pose(SE3(SO3::exp(x.tail<3>()), x.head<3>())) (src/Optimizer.cpp:78)
+    const SE3d Tf = pose_of(x);
+    double R[9];
+    quat_to_matrix(Tf, R);
+    if (lane == 0) {
+        Tio[0] = R[0]; Tio[1] = R[1]; Tio[2] = R[2];  Tio[3] = Tf.tx;
+        Tio[4] = R[3]; Tio[5] = R[4]; Tio[6] = R[5];  Tio[7] = Tf.ty;
+        Tio[8] = R[6]; Tio[9] = R[7]; Tio[10] = R[8]; Tio[11] = Tf.tz;
+        dsdtm_pose_opt_summary& sm = a.summary[frame];
+        sm.iterations = iterations;
+        sm.successful_steps = successful;
+        sm.termination = termination;
+        sm.n_residual_blocks = n_blocks;
+        sm.initial_cost = initial_cost;
+        sm.final_cost = x_cost;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sm.x[k] = x[k];
+    }
+    // GetReprojectReidual (src/Optimizer.cpp:297-317): raw residual norms, in residual-block order
+    double* rn = a.residual_norm + base;
+    int done = 0;
+    for (int b0 = 0; b0 < f.n; b0 += 64) {
+        const int i = b0 + lane;
+        double r0 = 0.0, r1 = 0.0, px, py, pz;
+        const bool u = block_residual(f, i, Tf, r0, r1, px, py, pz);
+        const unsigned long long m = __ballot(u);
+        if (u) rn[done + __popcll(m & ((1ull << lane) - 1ull))] = sqrt(r0 * r0 + r1 * r1);
+        done += __popcll(m);
+    }
+}
+
+hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream) {
+    if (args.n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pose_opt_kernel, dim3((unsigned)args.n_frames), dim3(64), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace dsdtm

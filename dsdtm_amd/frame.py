@@ -23,6 +23,7 @@ class Config:
         "Optimization.MaxIter": 8,     # src/Tracking.cpp:24
         "Camera.Max_fts": 200,         # src/Feature_detection.cpp:14 (Config/EuRoc.yaml:27)
         "Camera.Min_dist": 30,         # src/Frame.cpp:52 (Config/EuRoc.yaml:28)
+        "Optimization.LocalBAthreshhold": 2.0,   # src/Optimizer.cpp:22 (Config/default.yaml:94)
     }
 
     @classmethod

@@ -80,6 +80,14 @@ class MapPoint:
     def IncreaseFound(self, n=1):
         self.mnFound += n
 
+    def EraseFound(self, n=1):
+        """MapPoint::EraseFound (src/MapPoint.cpp:183-198): at zero the point is flagged bad and loses its
+        observations (SetBadFlag :91-109; the keyframe/map side of that is outside this path)."""
+        self.mnFound -= n
+        if self.mnFound <= 0:
+            self.mbBad = True
+            self.mObservations = {}
+
 
 class KeyFrame(Frame):
     """Frame + the identity the observations refer to (include/Keyframe.h:78 shares mvImg_Pyr)."""

@@ -190,3 +190,38 @@ def random_xi(rng, t_max=0.02, w_max=0.01):
 
 def random_pose(rng, t_max=1.0, w_max=0.5):
     return se3_exp(np.concatenate([rng.uniform(-t_max, t_max, 3), rng.uniform(-w_max, w_max, 3)]))[:3]
+
+
+class PoseProblem:
+    """Inputs of Optimizer::PoseOptimization (src/Optimizer.cpp:20-101) for one frame."""
+
+    def __init__(self, bearing, p_world, level, use, T_seed, T_true):
+        self.bearing, self.p_world, self.level, self.use = bearing, p_world, level, use
+        self.T_seed, self.T_true = T_seed, T_true
+
+
+def make_pose_problem(seed=0, n=200, cam: Camera | None = None, noise_px=0.3, outlier_frac=0.05,
+                      seed_t=0.03, seed_w=0.02, unused_frac=0.1, max_level=3) -> PoseProblem:
+    """Map points in front of a camera at a random pose, observed with pixel noise on pyramid levels
+    0..max_level (noise grows with the level, as the detector's does); a fraction of gross outliers
+    (what PoseOptimization's Cauchy loss and EraseFound walk are for); a fraction of features without
+    a usable map point; the seed pose is the true pose perturbed (the output of sparse alignment)."""
+    cam = cam or Camera.tum()
+    rng = np.random.default_rng(seed)
+    T_true = random_pose(rng, 0.5, 0.3)                          # world -> camera
+    level = rng.integers(0, max_level + 1, n).astype(np.int32)
+    px = np.stack([rng.uniform(20, cam.width - 20, n), rng.uniform(20, cam.height - 20, n)], 1)
+    depth = rng.uniform(0.8, 6.0, n)
+    ray = np.stack([(px[:, 0] - cam.cx) / cam.fx, (px[:, 1] - cam.cy) / cam.fy, np.ones(n)], 1)
+    p_cam = ray * depth[:, None]
+    R, t = T_true[:3, :3], T_true[:3, 3]
+    p_world = (p_cam - t) @ R                                     # R^T (p - t)
+    obs = px + rng.standard_normal((n, 2)) * noise_px * (1 << level)[:, None]
+    out = rng.random(n) < outlier_frac
+    obs[out] += rng.uniform(-60, 60, (int(out.sum()), 2))
+    bearing = bearing_from_px(cam, obs)
+    use = (rng.random(n) >= unused_frac).astype(np.uint8)
+    xi = np.concatenate([rng.uniform(-seed_t, seed_t, 3), rng.uniform(-seed_w, seed_w, 3)])
+    T_seed = (se3_exp(xi) @ np.vstack([T_true[:3], [0, 0, 0, 1]]))[:3]
+    return PoseProblem(np.ascontiguousarray(bearing), np.ascontiguousarray(p_world), level, use,
+                       np.ascontiguousarray(T_seed), np.ascontiguousarray(T_true[:3]))

@@ -229,6 +229,68 @@ int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame, const uin
                              int32_t* cell_y, int32_t* cell_level);
 
 
+/* ---- Optimizer::PoseOptimization ------------------------------ */
+/*
+ * Replaces: static void Optimizer::PoseOptimization(FramePtr tCurFrame, int tIterations = 100)
+ *           (include/Optimizer.h:29, src/Optimizer.cpp:20-101; call site src/Tracking.cpp:236, right after
+ *           SearchLocalPoints) — the numerical part: the Ceres solve of the 6-parameter pose block
+ *           [t, log R] over the frame's map-point observations with FullBA_Problem residuals
+ *           (include/Optimizer.h:129-216; map points held constant, src/Optimizer.cpp:60-61),
+ *           ceres::CauchyLoss(1.0) (:33), PoseLocalParameterization (include/Optimizer.h:219-252),
+ *           Solver::Options defaults + max_num_iterations = 100 (:68-72), then Set_Pose (:78) and the
+ *           per-block residual norms of GetReprojectReidual (src/Optimizer.cpp:297-317).
+ *           The EraseFound walk over those norms (:80-92) is host bookkeeping on MapPoint objects
+ *           (dsdtm_amd/optimizer.py, dsdtm_amd/host/dsdtm_host.hpp).
+ * Ceres is not under /root/reference (README.md:7 links its repository, no version): the solver is a
+ * restatement of Ceres 1.13's TrustRegionMinimizer + LevenbergMarquardtStrategy with the dense
+ * linear solve done on the 6x6 normal equations — see DESIGN.md §3.6 and oracle/pose_opt_oracle.c.
+ *
+ * bearing   : N x 3 doubles  Feature::mNormal  (observation = (n0/n2, n1/n2), include/Optimizer.h:160)
+ * p_world   : N x 3 doubles  Feature::Mpt->Get_Pose()
+ * level     : N              Feature::mlevel   (residual is divided by 1 << level, include/Optimizer.h:162)
+ * use       : N x u8         1 where the reference adds a residual block: Mpt != NULL && !Mpt->IsBad()
+ *                            && mbInitial (src/Optimizer.cpp:47-55)
+ * T_cur_w   : [R|t] 3x4 row-major; in: tCurFrame->Get_Pose(), out: the pose handed to Set_Pose
+ * residual_norm : N doubles; the first summary->n_residual_blocks entries are the norms in residual-
+ *                 block order (the order of the features with use != 0), the rest is untouched
+ */
+typedef struct dsdtm_pose_opt_params {
+    int32_t max_iterations;   /* 100 (src/Optimizer.cpp:72; the tIterations argument is ignored there) */
+    int32_t reserved;
+} dsdtm_pose_opt_params;
+enum dsdtm_pose_opt_termination {
+    DSDTM_PO_FUNCTION_TOLERANCE = 0, /* |cost change| <= 1e-6 * cost                      */
+    DSDTM_PO_PARAMETER_TOLERANCE = 1, /* |step| <= 1e-8 * (|x| + 1e-8)                     */
+    DSDTM_PO_GRADIENT_TOLERANCE = 2,  /* max |x - Plus(x, -g)| <= 1e-10                    */
+    DSDTM_PO_MAX_ITERATIONS = 3,
+    DSDTM_PO_MIN_RADIUS = 4,          /* trust-region radius <= 1e-32                      */
+    DSDTM_PO_INVALID_STEPS = 5,       /* 5 consecutive steps without model decrease        */
+    DSDTM_PO_NO_RESIDUALS = 6,        /* no feature with use != 0: pose only re-normalised */
+    DSDTM_PO_EVALUATION_FAILED = 7    /* non-finite residual/Jacobian at the start         */
+};
+typedef struct dsdtm_pose_opt_summary {
+    int32_t iterations;        /* trust-region iterations run (Ceres: summary.iterations.size() - 1) */
+    int32_t successful_steps;
+    int32_t termination;       /* dsdtm_pose_opt_termination */
+    int32_t n_residual_blocks;
+    double initial_cost, final_cost;   /* 1/2 sum rho(|r_i|^2) */
+    double x[6];               /* final parameter block [t, log R] */
+} dsdtm_pose_opt_summary;
+int dsdtm_pose_optimization(dsdtm_ctx* ctx, const double* bearing, const double* p_world,
+                            const int32_t* level, const uint8_t* use, int n_features,
+                            double T_cur_w[12], const dsdtm_pose_opt_params* params,
+                            double* residual_norm, dsdtm_pose_opt_summary* summary);
+/* n_frames independent problems (e.g. one per tracked sequence) in one launch. All pointers are DEVICE
+ * pointers; frame i's feature columns start at element i * max_features of each array (bearing and
+ * p_world: i * max_features * 3), its pose at T_cur_w + 12 * i, its norms at residual_norm +
+ * i * max_features, its summary at summary + i. Asynchronous on `hip_stream`. */
+int dsdtm_pose_optimization_batch_device(dsdtm_ctx* ctx, int n_frames, int max_features,
+                                         const int32_t* n_features, const double* bearing,
+                                         const double* p_world, const int32_t* level, const uint8_t* use,
+                                         double* T_cur_w, const dsdtm_pose_opt_params* params,
+                                         double* residual_norm, dsdtm_pose_opt_summary* summary,
+                                         void* hip_stream);
+
 /* Enqueues the alignment of all pairs on `hip_stream` (a hipStream_t, NULL = default
  * stream). Asynchronous: results are valid after the stream is synchronised. */
 int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* batch,

@@ -22,6 +22,7 @@
  *   Eigen 3.2.0 (LDLT with diagonal pivoting + pseudo-inverse solve; Matrix3f::inverse
  *                by cofactors; Quaternion product / _transformVector / toRotationMatrix)
  *   OpenCV 2.4.13 cv::pyrDown for CV_8UC1.
+ *   Ceres Solver (version not stated; 1.13 semantics): trust-region LM of PoseOptimization, pose_opt_oracle.c.
  */
 #ifndef DSDTM_ORACLE_H
 #define DSDTM_ORACLE_H
@@ -80,6 +81,20 @@ float oracle_shi_tomasi(const uint8_t* img, int w, int h, int stride, int u, int
 void oracle_detect_cells(const dsdtm_pyramid* pyr, int levels, int cell_size, int grid_cols, int grid_rows,
                          const uint8_t* grid_occupied, double detection_threshold, int barrier,
                          float* cell_score, int32_t* cell_x, int32_t* cell_y, int32_t* cell_level);
+
+/* --- Optimizer::PoseOptimization (src/Optimizer.cpp:20-101), SURVEY §8(f)3: see pose_opt_oracle.c ---- */
+/* Argument meaning of dsdtm_pose_optimization. linear_solver: 0 = Householder QR of [J; D] (what Ceres'
+ * DENSE_QR does), 1 = Cholesky of the 6x6 normal equations (what the HIP kernel does).
+ * trace (optional, 4 doubles per iteration incl. iteration 0, at most trace_cap iterations):
+ * cost, trust-region radius, gradient max norm, successful steps so far. */
+int oracle_pose_optimization(const double* bearing, const double* p_world, const int32_t* level,
+                             const uint8_t* use, int n_features, double T_cur_w[12],
+                             const dsdtm_pose_opt_params* prm, int linear_solver,
+                             double* residual_norm, dsdtm_pose_opt_summary* summary,
+                             double* trace, int trace_cap);
+void oracle_so3_log(const double q[4], double w[3]);
+void oracle_pose_plus(const double x[6], const double delta[6], double out[6]);
+int oracle_chol6_solve(const double M[36], const double v[6], double y[6]);
 
 /* --- building blocks exported for unit tests ------------------------------------ */
 /* SE3 as Sophus stores it: unit quaternion (w,x,y,z) + translation. */

@@ -32,8 +32,8 @@ def load(native: bool = False):
         return _LIBS[key]
     name = "liboracle_native.so" if native else "liboracle.so"
     path = os.path.join(_ORACLE_DIR, "_build", name)
-    src = os.path.join(_ORACLE_DIR, "dsdtm_oracle.c")
-    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("dsdtm_oracle.c", "pose_opt_oracle.c", "dsdtm_oracle.h")]
+    if not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
         build(native)
     lib = C.CDLL(path)
     capi.declare_signatures(lib, "oracle_", with_ctx=False)
@@ -61,8 +61,42 @@ def load(native: bool = False):
     lib.oracle_detect_cells.restype = None
     lib.oracle_detect_cells.argtypes = [C.POINTER(capi.Pyramid), C.c_int, C.c_int, C.c_int, C.c_int, capi.u8p, C.c_double,
                                         C.c_int, C.POINTER(C.c_float), ip32, ip32, ip32]
+    lib.oracle_pose_optimization.restype = C.c_int
+    lib.oracle_pose_optimization.argtypes = [dp, dp, ip32, capi.u8p, C.c_int, dp, C.POINTER(capi.PoseOptParams), C.c_int,
+                                             dp, C.POINTER(capi.PoseOptSummary), dp, C.c_int]
+    lib.oracle_so3_log.argtypes = [dp, dp]
+    lib.oracle_pose_plus.argtypes = [dp, dp, dp]
+    lib.oracle_chol6_solve.restype = C.c_int
+    lib.oracle_chol6_solve.argtypes = [dp, dp, dp]
     _LIBS[key] = lib
     return lib
+
+
+def pose_optimization(bearing, p_world, level, use, T_cur_w, max_iterations=100, linear_solver=0, trace=False):
+    """oracle_pose_optimization: returns (T 3x4, residual norms in block order, summary dict[, trace rows])."""
+    lib = load()
+    bearing = np.ascontiguousarray(bearing, np.float64).reshape(-1, 3)
+    pw = np.ascontiguousarray(p_world, np.float64).reshape(-1, 3)
+    level = np.ascontiguousarray(level, np.int32)
+    use = np.ascontiguousarray(use, np.uint8)
+    n = len(level)
+    T = np.ascontiguousarray(T_cur_w, np.float64).reshape(12).copy()
+    prm = capi.PoseOptParams(max_iterations, 0)
+    sm = capi.PoseOptSummary()
+    rn = np.full(max(n, 1), np.nan)
+    cap = max_iterations + 2
+    tr = np.zeros((cap, 4))
+    dp = C.POINTER(C.c_double)
+    rc = lib.oracle_pose_optimization(bearing.ctypes.data_as(dp), pw.ctypes.data_as(dp),
+                                      level.ctypes.data_as(C.POINTER(C.c_int32)), use.ctypes.data_as(capi.u8p), n,
+                                      T.ctypes.data_as(dp), C.byref(prm), linear_solver, rn.ctypes.data_as(dp),
+                                      C.byref(sm), tr.ctypes.data_as(dp) if trace else None, cap if trace else 0)
+    assert rc == 0, rc
+    d = sm.as_dict()
+    out = (T.reshape(3, 4), rn[:d["n_residual_blocks"]].copy(), d)
+    if trace:
+        out += (tr[:d["iterations"] + 1].copy(),)
+    return out
 
 
 # ---- the reference's own FAST build (oracle/_ref/libfast_ref.so, `make -C oracle ref`) ------------
