@@ -5,8 +5,8 @@
 // points are set constant, :60-61), FullBA_Problem residuals (include/Optimizer.h:129-216),
 // CauchyLoss(1.0), PoseLocalParameterization (include/Optimizer.h:219-252) and the default
 // trust-region Levenberg-Marquardt minimiser, at most 100 iterations (:68-72). The minimiser is
-// restated in oracle/pose_opt_oracle.c (see its header for what is the reference's and what is Ceres');
-// this kernel is the same algorithm with the damped step taken from the 6x6 normal equations.
+// restated from Ceres 1.13 (DESIGN.md §3.6 lists what is the reference's and what is Ceres'); the damped
+// step is taken from the 6x6 normal equations instead of a QR of the stacked Jacobian.
 //
 // Mapping: one wavefront per frame (problem). Lane l evaluates features l, l+64, ... — residual,
 // 2x6 Jacobian, Cauchy weight — and accumulates its share of J^T J (21), J^T r (6) and the cost in

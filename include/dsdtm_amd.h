@@ -243,7 +243,7 @@ int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame, const uin
  *           (dsdtm_amd/optimizer.py, dsdtm_amd/host/dsdtm_host.hpp).
  * Ceres is not under /root/reference (README.md:7 links its repository, no version): the solver is a
  * restatement of Ceres 1.13's TrustRegionMinimizer + LevenbergMarquardtStrategy with the dense
- * linear solve done on the 6x6 normal equations — see DESIGN.md §3.6 and oracle/pose_opt_oracle.c.
+ * linear solve done on the 6x6 normal equations — see DESIGN.md §3.6.
  *
  * bearing   : N x 3 doubles  Feature::mNormal  (observation = (n0/n2, n1/n2), include/Optimizer.h:160)
  * p_world   : N x 3 doubles  Feature::Mpt->Get_Pose()
