@@ -27,16 +27,39 @@ namespace dsdtm {
 
 namespace {
 
-__device__ __forceinline__ double wave_sum_all(double v) {
-    v = wave_sum_to_lane63(v);
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
-                            __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
-
-// x = [t, w] -> SE3(SO3::exp(w), t) (include/Optimizer.h:147)
+// The libm calls of this kernel (sincos, atan, log) sit in functions that are NOT inlined: inlined into the
+// iteration loop, their ~60 polynomial coefficients are hoisted out of it as loop invariants and held in
+// registers for the whole kernel (296 VGPRs, one wave per SIMD); out of line the kernel needs 2/3 of that.
+// Scalar in, scalar out: arguments and results travel in registers, nothing goes through the stack.
+__device__ __attribute__((noinline)) double log_out_of_line(double v) { return log(v); }
+__device__ __attribute__((noinline)) double atan_out_of_line(double v) { return atan(v); }
+__device__ __attribute__((noinline)) double sin_out_of_line(double v) { return sin(v); }
+__device__ __attribute__((noinline)) double cos_out_of_line(double v) { return cos(v); }
+// x = [t, w] -> SE3(SO3::exp(w), t) (include/Optimizer.h:147). The quaternion part of se3_exp
+// (device_math.h) on its own: same series / closed forms, same normalisation, no V matrix.
 __device__ __forceinline__ SE3d pose_of(const double* x) {
-    const double e[6] = {0.0, 0.0, 0.0, x[3], x[4], x[5]};
-    SE3d T = se3_exp(e);
+    const double wx = x[3], wy = x[4], wz = x[5];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    double ch, imag_factor;
+    if (theta_sq < 0.01) {
+        const double h2 = 0.25 * theta_sq;
+        ch = 1.0 + h2 * (-1.0 / 2 + h2 * (1.0 / 24 + h2 * (-1.0 / 720 + h2 * (1.0 / 40320 + h2 * (-1.0 / 3628800)))));
+        const double sinc = 1.0 + h2 * (-1.0 / 6 + h2 * (1.0 / 120 + h2 * (-1.0 / 5040 + h2 * (1.0 / 362880 +
+                            h2 * (-1.0 / 39916800)))));
+        imag_factor = 0.5 * sinc;
+        if (theta_sq < 1e-20) {          // Sophus: theta < SMALL_EPS
+            const double theta_po4 = theta_sq * theta_sq;
+            imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+        }
+    } else {
+        const double theta = sqrt(theta_sq);
+        const double sh = sin_out_of_line(0.5 * theta);
+        ch = cos_out_of_line(0.5 * theta);
+        imag_factor = sh * (1.0 / theta);
+    }
+    SE3d T;
+    T.qw = ch; T.qx = imag_factor * wx; T.qy = imag_factor * wy; T.qz = imag_factor * wz;
+    quat_normalize(T);
     T.tx = x[0]; T.ty = x[1]; T.tz = x[2];
     return T;
 }
@@ -47,18 +70,18 @@ __device__ __forceinline__ void so3_log(const SE3d& q, double* w) {
     const double qw = q.qw;
     double f;
     if (n < 1e-10) f = 2. / qw - 2. * (n * n) / (qw * (qw * qw));
-    else f = 2 * atan(n / qw) / n;
+    else f = 2 * atan_out_of_line(n / qw) / n;
     w[0] = f * q.qx; w[1] = f * q.qy; w[2] = f * q.qz;
 }
 
 // PoseLocalParameterization::Plus (include/Optimizer.h:222-236)
-__device__ __forceinline__ void pose_plus(const double* x, const double* d, double* out) {
-    const SE3d To = pose_of(x);
+__device__ __forceinline__ void pose_plus(const SE3d& To /* pose_of(x) */, const double* d, double* out) {
     const SE3d Td = pose_of(d);
     const SE3d Tn = se3_mul(Td, To);
     out[0] = Tn.tx; out[1] = Tn.ty; out[2] = Tn.tz;
     so3_log(Tn, out + 3);
 }
+
 
 __device__ __forceinline__ bool finite6(const double* v) {
     bool ok = true;
@@ -90,10 +113,16 @@ __device__ __forceinline__ bool block_residual(const Frame& f, int i, const SE3d
     return true;
 }
 
-// Program evaluation at x: cost = sum 1/2 rho(|r|^2); H = J^T J (upper triangle, row-major), g = J^T r of
-// the loss-corrected blocks. All outputs wave-uniform. ok = false when anything was not finite.
-__device__ void evaluate(const Frame& f, int lane, const double* x, double& cost, double* H, double* g, bool& ok) {
-    const SE3d T = pose_of(x);
+// Program evaluation at pose T: cost = sum 1/2 rho(|r|^2) (wave-uniform); H = J^T J (upper triangle,
+// row-major) and g = J^T r of the loss-corrected blocks go to hg[0..20], hg[21..26] in LDS (the solver part
+// reads what it needs, when it needs it; the 27 totals are not live in registers across the next
+// evaluation). ok = false when anything was not finite.
+#define PO_PART_STRIDE 29
+#ifndef PO_REDUCE_LDS
+#define PO_REDUCE_LDS 1
+#endif
+__device__ void evaluate(const Frame& f, int lane, const SE3d& T /* pose_of(x) */, double& cost, double* hg, double* part,
+                         bool& ok) {
     double c = 0.0, h[21], gg[6];
     bool bad = false;
 #pragma unroll
@@ -112,7 +141,7 @@ __device__ void evaluate(const Frame& f, int lane, const double* x, double& cost
         const double s = r0 * r0 + r1 * r1;
         const double sum = 1.0 + s;                         // CauchyLoss(1.0): b = c = 1
         const double inv = 1.0 / sum;
-        c += 0.5 * log(sum);
+        c += 0.5 * log_out_of_line(sum);
         const double sq = sqrt(fmax(inv, DBL_MIN));         // Corrector, alpha = 0 (rho'' < 0)
 #pragma unroll
         for (int k = 0; k < 6; ++k) { J0[k] *= sq; J1[k] *= sq; }
@@ -125,11 +154,51 @@ __device__ void evaluate(const Frame& f, int lane, const double* x, double& cost
             for (int b = a; b < 6; ++b) { h[q] += J0[a] * J0[b] + J1[a] * J1[b]; ++q; }
         }
     }
-    cost = wave_sum_all(c);
+#if PO_REDUCE_LDS
+    // Cross-lane totals through LDS: every lane parks its 28 partials (row stride 29 doubles: the column
+    // reads below are conflict-free), then lane k (k < 28) adds column k over lanes 0..31 and lane 32 + k
+    // over lanes 32..63 in lane order, and lane k folds the two halves. The order is fixed, so runs repeat
+    // bit for bit.
+    double* row = part + lane * PO_PART_STRIDE;
 #pragma unroll
-    for (int k = 0; k < 21; ++k) H[k] = wave_sum_all(h[k]);
+    for (int k = 0; k < 21; ++k) row[k] = h[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) g[k] = wave_sum_all(gg[k]);
+    for (int k = 0; k < 6; ++k) row[21 + k] = gg[k];
+    row[27] = c;
+    __syncthreads();                                        // one wave per workgroup: orders LDS writes and reads
+    const int col = lane & 31, half = lane >> 5;
+    double acc = 0.0;
+    if (col < 28) {
+        const double* src = part + (half * 32) * PO_PART_STRIDE + col;
+#pragma unroll 8
+        for (int l = 0; l < 32; ++l) acc += src[l * PO_PART_STRIDE];
+    }
+    __syncthreads();
+    if (half == 1 && col < 28) part[col] = acc;             // row 0 is free again: hand the upper half over
+    __syncthreads();
+    if (half == 0 && col < 28) hg[col] = acc + part[col];   // hg[0..20] H, hg[21..26] g, hg[27] cost
+    __syncthreads();
+#else
+    // Cross-lane totals: one DPP butterfly per value (fixed order: runs repeat bit for bit), stored by the
+    // lane it ends in
+    (void)part;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) {
+        const double v = wave_sum_to_lane63(h[k]);
+        if (lane == 63) hg[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double v = wave_sum_to_lane63(gg[k]);
+        if (lane == 63) hg[21 + k] = v;
+    }
+    {
+        const double v = wave_sum_to_lane63(c);
+        if (lane == 63) hg[27] = v;
+    }
+    __syncthreads();                                        // one wave per workgroup: orders the LDS writes
+#endif
+    cost = hg[27];
     ok = __ballot(bad) == 0ull && isfinite(cost);
 }
 
@@ -182,11 +251,11 @@ __device__ __forceinline__ double norm6(const double* v) {
     return sqrt(s);
 }
 
-__device__ __forceinline__ double gradient_max_norm(const double* x, const double* g) {
+__device__ __forceinline__ double gradient_max_norm(const SE3d& Tx, const double* x, const double* hg) {
     double ng[6], xp[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ng[k] = -g[k];
-    pose_plus(x, ng, xp);
+    for (int k = 0; k < 6; ++k) ng[k] = -hg[21 + k];
+    pose_plus(Tx, ng, xp);
     double m = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) m = fmax(m, fabs(x[k] - xp[k]));
@@ -195,7 +264,11 @@ __device__ __forceinline__ double gradient_max_norm(const double* x, const doubl
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void pose_opt_kernel(PoseOptArgs a) {
+#ifndef PO_WAVES_PER_EU
+#define PO_WAVES_PER_EU 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PO_WAVES_PER_EU, PO_WAVES_PER_EU)))
+void pose_opt_kernel(PoseOptArgs a) {
     const int frame = blockIdx.x;
     if (frame >= a.n_frames) return;
     const int lane = threadIdx.x;
@@ -220,15 +293,18 @@ __global__ __launch_bounds__(64) void pose_opt_kernel(PoseOptArgs a) {
     const SE3d T0 = se3_from_rt(Tio);
     double x[6] = {T0.tx, T0.ty, T0.tz, 0.0, 0.0, 0.0};
     so3_log(T0, x + 3);
+    SE3d Tx = pose_of(x);              // the pose every evaluation of x uses; recomputed from x only when x changes
 
     int termination = DSDTM_PO_MAX_ITERATIONS, iterations = 0, successful = 0;
     double x_cost = 0.0, initial_cost = 0.0;
-    double H[21], g[6];
+    __shared__ double s_hg[2][28];     // H (21), g (6), cost of the accepted point [cur] and of the candidate [cur ^ 1]
+    __shared__ double s_part[PO_REDUCE_LDS ? 64 * PO_PART_STRIDE : 1];   // per-lane partials of one evaluation
+    int cur = 0;
     bool ok;
     if (n_blocks == 0) {
         termination = DSDTM_PO_NO_RESIDUALS;
     } else {
-        evaluate(f, lane, x, x_cost, H, g, ok);
+        evaluate(f, lane, Tx, x_cost, s_hg[0], s_part, ok);
         if (!ok) {
             termination = DSDTM_PO_EVALUATION_FAILED;
             x_cost = 0.0;
@@ -236,9 +312,9 @@ __global__ __launch_bounds__(64) void pose_opt_kernel(PoseOptArgs a) {
             initial_cost = x_cost;
             double scale[6], diagonal[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) scale[k] = 1.0 / (1.0 + sqrt(H[PO_U(k, k)]));   // Jacobi scaling, fixed
+            for (int k = 0; k < 6; ++k) scale[k] = 1.0 / (1.0 + sqrt(s_hg[0][PO_U(k, k)]));   // Jacobi scaling, fixed
             double x_norm = norm6(x);
-            double gmax = gradient_max_norm(x, g);
+            double gmax = gradient_max_norm(Tx, x, s_hg[0]);
             double radius = 1e4, decrease_factor = 2.0;
             bool reuse_diagonal = false;
             int invalid_steps = 0, it = 0;
@@ -249,11 +325,12 @@ __global__ __launch_bounds__(64) void pose_opt_kernel(PoseOptArgs a) {
                 ++it;
                 // scaled system: As = S H S, gs = S g
                 double As[21], gs[6], M[21];
+                const double* hg = s_hg[cur];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    gs[i] = scale[i] * g[i];
+                    gs[i] = scale[i] * hg[21 + i];
 #pragma unroll
-                    for (int j = i; j < 6; ++j) As[PO_U(i, j)] = (scale[i] * H[PO_U(i, j)]) * scale[j];
+                    for (int j = i; j < 6; ++j) As[PO_U(i, j)] = (scale[i] * hg[PO_U(i, j)]) * scale[j];
                 }
                 if (!reuse_diagonal) {
 #pragma unroll
@@ -289,12 +366,13 @@ __global__ __launch_bounds__(64) void pose_opt_kernel(PoseOptArgs a) {
                     continue;
                 }
                 invalid_steps = 0;
-                double delta[6], cand[6], cand_cost, Hc[21], gc[6];
+                double delta[6], cand[6], cand_cost;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) delta[k] = step[k] * scale[k];
-                pose_plus(x, delta, cand);
+                pose_plus(Tx, delta, cand);
                 bool cand_ok = finite6(cand);
-                if (cand_ok) evaluate(f, lane, cand, cand_cost, Hc, gc, cand_ok);
+                const SE3d Tc = pose_of(cand);
+                if (cand_ok) evaluate(f, lane, Tc, cand_cost, s_hg[cur ^ 1], s_part, cand_ok);
                 if (!cand_ok) cand_cost = DBL_MAX;
                 double diff[6];
 #pragma unroll
@@ -305,12 +383,12 @@ __global__ __launch_bounds__(64) void pose_opt_kernel(PoseOptArgs a) {
                 const double relative_decrease = cost_change / model_cost_change;
                 if (relative_decrease > 1e-3) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) { x[k] = cand[k]; g[k] = gc[k]; }
-#pragma unroll
-                    for (int k = 0; k < 21; ++k) H[k] = Hc[k];
+                    for (int k = 0; k < 6; ++k) x[k] = cand[k];
+                    cur ^= 1;                                  // the candidate's H, g become the accepted ones
                     x_cost = cand_cost;
                     x_norm = norm6(x);
-                    gmax = gradient_max_norm(x, g);
+                    Tx = Tc;
+                    gmax = gradient_max_norm(Tx, x, s_hg[cur]);
                     ++successful;
                     const double t = 2.0 * relative_decrease - 1.0;
                     radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
@@ -328,7 +406,7 @@ __global__ __launch_bounds__(64) void pose_opt_kernel(PoseOptArgs a) {
     }
 
     // Set_Pose(SE3(SO3::exp(x.tail<3>()), x.head<3>())) (src/Optimizer.cpp:78)
-    const SE3d Tf = pose_of(x);
+    const SE3d Tf = Tx;
     double R[9];
     quat_to_matrix(Tf, R);
     if (lane == 0) {
