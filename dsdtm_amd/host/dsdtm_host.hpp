@@ -35,6 +35,7 @@ struct Config {
     static int& MaxPyraLevels() { static int v = 5; return v; }       // :13
     static int& Max_fts() { static int v = 200; return v; }           // :14
     static int& Min_dist() { static int v = 30; return v; }           // src/Frame.cpp:52
+    static float& LocalBAthreshhold() { static float v = 2.0f; return v; }   // src/Optimizer.cpp:22 (Config/default.yaml:94)
 };
 
 struct Image8 {                                   // cv::Mat CV_8UC1
@@ -54,12 +55,14 @@ struct Camera {                                   // include/Camera.h:138-142 (f
 };
 typedef std::shared_ptr<Camera> CameraPtr;
 
+struct MapPoint;
 struct Feature {                                  // include/Feature.h:16-36 (+ the map point position)
     float mpx_x = 0, mpx_y = 0;
     int mlevel = 0;
     bool mbInitial = false;
     std::array<double, 3> mNormal{{0, 0, 0}};
-    std::array<double, 3> mMptPose{{0, 0, 0}};    // Mpt->Get_Pose()
+    std::array<double, 3> mMptPose{{0, 0, 0}};    // Mpt->Get_Pose() as Sprase_ImgAlign::Run snapshots it
+    MapPoint* Mpt = nullptr;                      // include/Feature.h:33 (read by Optimizer::PoseOptimization)
 };
 
 namespace detail { inline dsdtm_ctx* ctx(); }
@@ -175,6 +178,10 @@ struct MapPoint {                                 // include/MapPoint.h (what th
     bool IsBad() const { return mbBad; }
     int Get_FoundNums() const { return mnFound; }
     void IncreaseFound(int n = 1) { mnFound += n; }
+    void EraseFound(int n = 1) {                  // src/MapPoint.cpp:183-198; SetBadFlag :91-109 (map side not modelled)
+        mnFound -= n;
+        if (mnFound <= 0) { mbBad = true; mObservations.clear(); }
+    }
 };
 
 inline int cvRound(double v) { return (int)std::nearbyint(v); }      // OpenCV 2.4 cvRound: round half to even
@@ -446,6 +453,49 @@ public:
 
     int mImg_height, mImg_width, mCell_size, mPyr_levels, mGrid_rows, mGrid_cols, mMax_fts;
     std::vector<uint8_t> mvGrid_occupy;
+};
+
+// ---- Optimizer::PoseOptimization (include/Optimizer.h:29, src/Optimizer.cpp:20-101) -----------------------
+// Called by Tracking::TrackWithLocalMap right after SearchLocalPoints (src/Tracking.cpp:236). The Ceres solve and
+// the residual norms are ONE library call (HIP, one wavefront); the EraseFound walk (:80-92) stays here.
+class Optimizer {
+public:
+    static dsdtm_pose_opt_summary& LastSummary() { static thread_local dsdtm_pose_opt_summary s{}; return s; }
+    static void PoseOptimization(FramePtr tCurFrame, int /*tIterations: never read by the reference*/ = 100) {
+        std::vector<Feature>& fts = tCurFrame->mvFeatures;
+        const int N = (int)fts.size();
+        std::vector<double> bearing(3 * (size_t)N), pw(3 * (size_t)N, 0.0), rn((size_t)std::max(N, 1));
+        std::vector<int32_t> level((size_t)N);
+        std::vector<uint8_t> use((size_t)N, 0);
+        std::map<int, MapPoint*> tvMpts;                                     // :43 keyed by FEATURE index (:57)
+        for (int i = 0; i < N; ++i) {                                        // :45-65
+            for (int k = 0; k < 3; ++k) bearing[3 * (size_t)i + k] = fts[(size_t)i].mNormal[k];
+            level[(size_t)i] = fts[(size_t)i].mlevel;
+            MapPoint* mp = fts[(size_t)i].Mpt;
+            if (!mp || mp->IsBad() || !fts[(size_t)i].mbInitial) continue;
+            use[(size_t)i] = 1;
+            for (int k = 0; k < 3; ++k) pw[3 * (size_t)i + k] = mp->Get_Pose()[(size_t)k];
+            tvMpts[i] = mp;
+        }
+        SE3 T = tCurFrame->Get_Pose();
+        dsdtm_pose_opt_params prm;
+        prm.max_iterations = 100; prm.reserved = 0;                          // :72
+        dsdtm_pose_opt_summary& sm = LastSummary();
+        const int rc = dsdtm_pose_optimization(detail::ctx(), bearing.data(), pw.data(), level.data(), use.data(), N, T.m.data(),
+                                               &prm, rn.data(), &sm);
+        if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_pose_optimization: ") + dsdtm_last_error(detail::ctx()));
+        tCurFrame->Set_Pose(T);                                              // :78
+        double tOutlineThres = Config::LocalBAthreshhold();                  // :22-24: double(float) / float mf
+        tOutlineThres = tOutlineThres / tCurFrame->mCamera->mf;
+        for (int i = 0; i < sm.n_residual_blocks; ++i) {                     // :80-92: residual i is in BLOCK order, the
+            if (rn[(size_t)i] > tOutlineThres) {                             // map is keyed by FEATURE index: kept as is
+                auto it = tvMpts.find(i);
+                if (it == tvMpts.end() || !it->second) continue;
+                if (it->second->IsBad()) continue;
+                it->second->EraseFound();
+            }
+        }
+    }
 };
 
 }  // namespace DSDTM

@@ -44,7 +44,7 @@ def dump_scene(path, sc, params, min_fts, border, patch, px0):
 
 
 def test_cpp_host_layer_builds_against_the_c_abi():
-    assert os.path.exists(build_example()) and os.path.exists(build_example("example_search"))
+    assert all(os.path.exists(build_example(n)) for n in ("example_align", "example_search", "example_pose_opt"))
 
 
 @pytest.mark.gpu
@@ -128,3 +128,38 @@ def test_cpp_search_local_points_matches_the_python_mirror(tmp_path, gpu_ctx):
         assert np.float32(x) == g[2][0] and np.float32(y) == g[2][1]
     assert int(out[2 + len(got)].split()[1]) == int(mask.astype(np.uint64).sum())
     assert out[3 + len(got)].split() == ["resident_same", "1"]         # device-resident frames: one library call, same matches
+
+
+@pytest.mark.gpu
+def test_cpp_pose_optimization_matches_the_python_mirror(tmp_path, gpu_ctx):
+    """Optimizer::PoseOptimization of the C++ layer against dsdtm_amd.Optimizer (itself held to the CPU
+    restatement and a sequential restatement of the EraseFound walk in test_pose_opt_gpu.py): the same
+    library call underneath, so pose, summary and every map-point counter agree exactly."""
+    from dsdtm_amd import Optimizer
+    from dsdtm_amd.frame import Frame
+    from dsdtm_amd.search import MapPoint
+    exe = build_example("example_pose_opt")
+    cam = synth.Camera.tum()
+    P = synth.make_pose_problem(91, n=260, cam=cam, outlier_frac=0.2, unused_frac=0.0, max_level=3)
+    rng = np.random.default_rng(4)
+    n = 260
+    mps = [MapPoint(P.p_world[i].copy(), {}, int(rng.integers(1, 4)), bool(rng.random() < 0.05)) for i in range(n)]
+    mp_idx = np.arange(n); mp_idx[rng.random(n) < 0.1] = -1
+    initial = (rng.random(n) > 0.08).astype(np.uint8)
+    with open(tmp_path / "frame.bin", "wb") as f:
+        f.write(struct.pack("<2i", n, n) + struct.pack("<f", cam.f) + np.ascontiguousarray(P.T_seed, "<f8").tobytes())
+        for mp in mps:
+            f.write(np.asarray(mp.mPose, "<f8").tobytes() + struct.pack("<2i", mp.mnFound, int(mp.mbBad)))
+        for i in range(n):
+            f.write(P.bearing[i].astype("<f8").tobytes() + struct.pack("<3i", int(P.level[i]), int(initial[i]), int(mp_idx[i])))
+    out = subprocess.run([exe, str(tmp_path / "frame.bin")], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    fr = Frame(cam, [np.zeros((8, 8), np.uint8)], P.T_seed)
+    fr.set_features(np.zeros((n, 2), np.float32), P.bearing, P.p_world, initial, P.level)
+    fr.mvMapPoints = [mps[k] if k >= 0 else None for k in mp_idx]
+    sm = Optimizer.PoseOptimization(fr, 10, ctx=gpu_ctx)
+    got = out[0].split()
+    assert [int(v) for v in got[1:5]] == [sm["iterations"], sm["successful_steps"], sm["termination"], sm["n_residual_blocks"]]
+    assert float(got[5]) == sm["initial_cost"] and float(got[6]) == sm["final_cost"] and sm["iterations"] > 3
+    assert np.array_equal(np.array([float(v) for v in out[1].split()[1:]]), fr.Get_Pose().reshape(12))
+    assert [tuple(int(v) for v in l.split()) for l in out[2:2 + n]] == [(mp.mnFound, int(mp.mbBad)) for mp in mps]
+    assert sum(mp.mbBad for mp in mps) > 15                      # the walk erased something
