@@ -1,6 +1,6 @@
 """One tracking step of DSDTM's front end on device-resident frames (src/Tracking.cpp:45-145): what the GPU
 side costs per frame when the library replaces Frame::ComputeImagePyramid, Sprase_ImgAlign::Run,
-FindMatchDirect (all candidates of SearchLocalPoints) and Feature_detector::detect. Library-call times
+FindMatchDirect (all candidates of SearchLocalPoints), Optimizer::PoseOptimization and Feature_detector::detect. Library-call times
 (host wall clock around the C ABI calls, medians); the reference-shaped bookkeeping around them is
 Python here and not timed. CPU column: the oracle's restatement of the same steps, one thread.
 Usage: python tools/track_step.py   (MI355X)"""
@@ -70,11 +70,21 @@ def cpu_match():
     return oracle_lib.align2d_batch(cur.mvImg_Pyr, pb, pp, sl_o, cpx / (1 << sl_o)[:, None], 10)
 t_cpu, (conv_o, _) = med(cpu_match, n=3, warm=1)
 rows.append((f"FindMatchDirect x {len(cand)} candidates (warp prelude + Align2D; {int(conv.sum())} converged, CPU {int(conv_o.sum())})", t, t_cpu))
-# 4. keyframe: Feature_detector::detect (per-cell corners)
+# 4. Optimizer::PoseOptimization on the matched map points (src/Tracking.cpp:236)
+from dsdtm_amd.optimizer import pose_optimization
+ok = conv.astype(bool)
+bear = synth.bearing_from_px(cam, pxo[ok].astype(np.float32)); lvl = sl[ok].astype(np.int32); pws = pw[ok]; use = np.ones(int(ok.sum()), np.uint8)
+def po():
+    T = np.ascontiguousarray(cur.Get_Pose(), np.float64).reshape(12).copy()
+    return pose_optimization(ctx, bear, pws, lvl, use, T)
+t, (rn, sm) = med(po)
+t_cpu, _ = med(lambda: oracle_lib.pose_optimization(bear, pws, lvl, use, cur.Get_Pose(), linear_solver=0), n=5, warm=1)
+rows.append((f"Optimizer::PoseOptimization ({int(ok.sum())} map-point observations, {sm['iterations']} trust-region iterations)", t, t_cpu))
+# 5. keyframe: Feature_detector::detect (per-cell corners)
 det = Feature_detector(cam.width, cam.height, ctx=ctx)
 t, cells = med(lambda: det.detect_cells(cur, 5.0))
 t_cpu, _ = med(lambda: oracle_lib.detect_cells(cur.mvImg_Pyr, L, det.mCell_size, det.mGrid_cols, det.mGrid_rows, None, 5.0), n=3, warm=1)
 rows.append(("Feature_detector::detect, per-cell corners (keyframes only)", t, t_cpu))
 print("step | GPU library call, ms | CPU oracle (1 thread), ms")
 for name, g, c in rows: print(f"{name} | {g:.3f} | {c:.2f}")
-print(f"per tracked frame (steps 1-3): {sum(r[1] for r in rows[:3]):.3f} ms on the GPU vs {sum(r[2] for r in rows[:3]):.1f} ms for the CPU restatement")
+print(f"per tracked frame (steps 1-4): {sum(r[1] for r in rows[:4]):.3f} ms on the GPU vs {sum(r[2] for r in rows[:4]):.1f} ms for the CPU restatement")
