@@ -33,8 +33,12 @@ namespace {
 // Scalar in, scalar out: arguments and results travel in registers, nothing goes through the stack.
 __device__ __attribute__((noinline)) double log_out_of_line(double v) { return log(v); }
 __device__ __attribute__((noinline)) double atan_out_of_line(double v) { return atan(v); }
-__device__ __attribute__((noinline)) double sin_out_of_line(double v) { return sin(v); }
-__device__ __attribute__((noinline)) double cos_out_of_line(double v) { return cos(v); }
+struct SinCos { double s, c; };
+__device__ __attribute__((noinline)) SinCos sincos_out_of_line(double v) {
+    SinCos r;
+    sincos(v, &r.s, &r.c);
+    return r;
+}
 // x = [t, w] -> SE3(SO3::exp(w), t) (include/Optimizer.h:147). The quaternion part of se3_exp
 // (device_math.h) on its own: same series / closed forms, same normalisation, no V matrix.
 __device__ __forceinline__ SE3d pose_of(const double* x) {
@@ -53,9 +57,9 @@ __device__ __forceinline__ SE3d pose_of(const double* x) {
         }
     } else {
         const double theta = sqrt(theta_sq);
-        const double sh = sin_out_of_line(0.5 * theta);
-        ch = cos_out_of_line(0.5 * theta);
-        imag_factor = sh * (1.0 / theta);
+        const SinCos sc = sincos_out_of_line(0.5 * theta);
+        ch = sc.c;
+        imag_factor = sc.s * (1.0 / theta);
     }
     SE3d T;
     T.qw = ch; T.qx = imag_factor * wx; T.qy = imag_factor * wy; T.qz = imag_factor * wz;
@@ -205,8 +209,11 @@ __device__ void evaluate(const Frame& f, int lane, const SE3d& T /* pose_of(x) *
 #define PO_U(i, j) ((i) * 6 - ((i) * ((i) - 1)) / 2 + ((j) - (i)))   /* packed upper index, i <= j */
 
 // Cholesky solve of the SPD system M y = v; M as packed upper triangle. false on a non-positive pivot.
+// One reciprocal per pivot, reused by the column scaling and both substitutions (6 divisions instead of 27
+// on the iteration's dependent chain).
 __device__ __forceinline__ bool chol6_solve(const double* M, const double* v, double* y) {
     double L[21];   // lower factor, packed by rows: L(i,j) at i(i+1)/2 + j
+    double rl[6];   // 1 / L(j,j)
 #define PO_L(i, j) L[((i) * ((i) + 1)) / 2 + (j)]
     bool ok = true;
 #pragma unroll
@@ -217,12 +224,13 @@ __device__ __forceinline__ bool chol6_solve(const double* M, const double* v, do
         ok = ok && (d > 0.0);
         const double ljj = sqrt(d);
         PO_L(j, j) = ljj;
+        rl[j] = 1.0 / ljj;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double s = M[PO_U(j, i)];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= PO_L(i, k) * PO_L(j, k);
-            PO_L(i, j) = s / ljj;
+            PO_L(i, j) = s * rl[j];
         }
     }
     double z[6];
@@ -231,14 +239,14 @@ __device__ __forceinline__ bool chol6_solve(const double* M, const double* v, do
         double s = v[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= PO_L(i, k) * z[k];
-        z[i] = s / PO_L(i, i);
+        z[i] = s * rl[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = z[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= PO_L(k, i) * y[k];
-        y[i] = s / PO_L(i, i);
+        y[i] = s * rl[i];
     }
 #undef PO_L
     return ok;

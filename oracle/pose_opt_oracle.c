@@ -209,9 +209,10 @@ static void householder_ls(double* A, double* rhs, int m, double y[6]) {
     }
 }
 
-/* Cholesky solve of the SPD 6x6 system M y = v (row-major full matrix); returns 0 on a non-positive pivot */
+/* Cholesky solve of the SPD 6x6 system M y = v (row-major full matrix); returns 0 on a non-positive pivot.
+ * One reciprocal per pivot, as the kernel does it. */
 int oracle_chol6_solve(const double M[36], const double v[6], double y[6]) {
-    double L[36];
+    double L[36], rl[6];
     memset(L, 0, sizeof(L));
     for (int j = 0; j < 6; ++j) {
         double d = M[j * 6 + j];
@@ -219,22 +220,23 @@ int oracle_chol6_solve(const double M[36], const double v[6], double y[6]) {
         if (!(d > 0.0)) return 0;
         const double ljj = sqrt(d);
         L[j * 6 + j] = ljj;
+        rl[j] = 1.0 / ljj;
         for (int i = j + 1; i < 6; ++i) {
             double s = M[i * 6 + j];
             for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = s / ljj;
+            L[i * 6 + j] = s * rl[j];
         }
     }
     double z[6];
     for (int i = 0; i < 6; ++i) {
         double s = v[i];
         for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * z[k];
-        z[i] = s / L[i * 6 + i];
+        z[i] = s * rl[i];
     }
     for (int i = 5; i >= 0; --i) {
         double s = z[i];
         for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * y[k];
-        y[i] = s / L[i * 6 + i];
+        y[i] = s * rl[i];
     }
     return 1;
 }
