@@ -42,6 +42,31 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.BatchDesc) == 112 + 64 + 8 + 88
     assert C.sizeof(capi.ImageDesc) == 4 + 3 * 32 + 4 + 64 + 8 + 8
     assert C.sizeof(capi.DetectParams) == 5 * 4 + 4
+    assert C.sizeof(capi.PoseOptParams) == 8 and C.sizeof(capi.PoseOptSummary) == 16 + 16 + 48
+
+
+def test_struct_layouts_match_the_compiled_header(tmp_path):
+    """sizeof / offsetof as a C compiler sees include/dsdtm_amd.h against the ctypes mirrors."""
+    import subprocess
+    pairs = [("dsdtm_camera", capi.Camera, []), ("dsdtm_pyramid", capi.Pyramid, []), ("dsdtm_align_params", capi.AlignParams, []),
+             ("dsdtm_align_stats", capi.AlignStats, []), ("dsdtm_batch_desc", capi.BatchDesc, []),
+             ("dsdtm_detect_params", capi.DetectParams, ["detection_threshold"]),
+             ("dsdtm_pose_opt_params", capi.PoseOptParams, ["max_iterations"]),
+             ("dsdtm_pose_opt_summary", capi.PoseOptSummary, ["termination", "n_residual_blocks", "initial_cost", "final_cost", "x"])]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "dsdtm_amd.h"', 'int main(void) {']
+    for cname, _, fields in pairs:
+        src.append(f'  printf("%zu", sizeof({cname}));')
+        for fld in fields:
+            src.append(f'  printf(" %zu", offsetof({cname}, {fld}));')
+        src.append('  printf("\\n");')
+    src += ['  return 0;', '}']
+    (tmp_path / "layout.c").write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(tmp_path / "layout.c")], check=True)
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    for (cname, ct, fields), line in zip(pairs, lines):
+        want = [C.sizeof(ct)] + [getattr(ct, f).offset for f in fields]
+        assert [int(v) for v in line.split()] == want, (cname, line, want)
 
 
 def test_no_cpu_fallback_without_device():
