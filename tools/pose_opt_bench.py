@@ -1,7 +1,7 @@
 """Pose-only refinement (Optimizer::PoseOptimization) on the MI355X: device-resident batch
 throughput (HIP events on the launch stream), one-frame latency through the host entry point
 (PCIe-inclusive), and the CPU restatement on this host beside it.
-Usage: python tools/pose_opt_bench.py [frames] [features]   (MI355X)"""
+Usage: python tools/pose_opt_bench.py [frames] [features] [nolatency]   (MI355X)"""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,6 +52,8 @@ print(f"  {ms:.3f} ms per launch -> {F/ms*1e3/1e3:.1f} k refinements/s, {(evals*
 flop_eval = 330                                 # FP64 flops per block evaluation, divisions counted as one
 print(f"  ~{(evals*blocks).sum()*flop_eval/ms*1e3/1e12:.2f} TFLOP/s FP64 of ~78 (vector peak): latency-bound, one wave per frame")
 
+if len(sys.argv) > 3 and sys.argv[3] == "nolatency":      # profiling runs: the batch launches only
+    sys.exit(0)
 # one frame through the host entry point (what Tracking::TrackWithLocalMap would call)
 P = probs[0]
 T = np.ascontiguousarray(P.T_seed).reshape(12).copy()
