@@ -50,7 +50,7 @@ struct SAKernelArgs {
 #endif
 #define DSDTM_STR2(x) #x
 #define DSDTM_STR(x) DSDTM_STR2(x)
-enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2, SA_REG128 = 3, SA_REG192 = 4, SA_REG256 = 5 };
+enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2, SA_REG128 = 3, SA_REG192 = 4, SA_REG256 = 5, SA_REG704 = 6 };
 SAVariant sparse_align_pick_variant(int max_features);
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features);
 hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream);

@@ -1332,13 +1332,14 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
 // Register-kernel shapes: NPW patch waves + 1 solver wave per pair slot, PPW slots per workgroup,
 // always <= 12 waves (3 per SIMD at 168 VGPRs = the whole register file of a CU):
 //   <= 128 features: 2+1 waves x 4 slots     <= 192: 3+1 x 3     <= 256: 4+1 x 2
-//   <= 320 features: 5+1 x 2 (BASELINE shape) <= 448: 7+1 x 1
+//   <= 320 features: 5+1 x 2 (BASELINE shape) <= 448: 7+1 x 1     <= 704: 11+1 x 1
 SAVariant sparse_align_pick_variant(int max_features) {
     if (max_features <= 128) return SA_REG128;
     if (max_features <= 192) return SA_REG192;
     if (max_features <= 256) return SA_REG256;
     if (max_features <= 320) return SA_REG320;
     if (max_features <= 448) return SA_REG448;
+    if (max_features <= 704) return SA_REG704;
     return SA_WS;
 }
 
@@ -1393,6 +1394,7 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
         case SA_REG256: return launch_reg<4, 2, false>(args, num_cus, stream);
         case SA_REG320: return launch_reg<5, SA_PPW, false>(args, num_cus, stream);
         case SA_REG448: return launch_reg<7, 1, false>(args, num_cus, stream);
+        case SA_REG704: return launch_reg<11, 1, false>(args, num_cus, stream);
         case SA_WS:
             hipLaunchKernelGGL((sparse_align_ws_kernel<7>), dim3((unsigned)args.n_pairs), dim3(8 * 64), 0, stream, args);
             break;

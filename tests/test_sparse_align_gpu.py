@@ -90,9 +90,10 @@ def test_random_scenes_match_oracle(gpu_ctx, oracle, seed):
     assert sg["n_ref"] == so["n_ref"] and sg["n_vis"] == so["n_vis"]
 
 
-@pytest.mark.parametrize("n_patches,size", [(330, (320, 240)), (448, (320, 240)), (1000, (640, 480)), (2000, (640, 480))])
+@pytest.mark.parametrize("n_patches,size", [(330, (320, 240)), (448, (320, 240)), (449, (320, 240)), (600, (640, 480)), (704, (640, 480)),
+                                             (705, (640, 480)), (1000, (640, 480)), (2000, (640, 480))])
 def test_large_patch_counts(gpu_ctx, oracle, n_patches, size):
-    """448-lane register kernel and the workspace kernel (configs 3 and 5 patch counts)."""
+    """448- and 704-lane register kernels and the workspace kernel (configs 3 and 5 patch counts)."""
     sc = cached_scene(width=size[0], height=size[1], levels=3, n_patches=n_patches, seed=77, margin=12)
     To, no, so = oracle.sparse_align(sc, 3, 0, 8)
     Tg, ng, sg = H.gpu_sparse_align(sc, 3, 0, 8, ctx=gpu_ctx)
