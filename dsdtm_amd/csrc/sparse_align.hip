@@ -1247,10 +1247,10 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
 #pragma unroll
                 for (int i = 0; i < 3; ++i) s.to[i] = s.u.t[i];
             }
+            double hrow[6];                                            // row of H^+, rebuilt when a wave reports a new visible set
             for (int it = 0; it < a.max_iters; ++it) {
                 __syncthreads();                                       // B1
-                double hrow[6];                                        // (this kernel's partials always report "changed":
-                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow);   // H^+ is rebuilt every iteration)
+                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow);
                 __syncthreads();                                       // B2
                 if (ctrl) break;
             }
@@ -1282,6 +1282,11 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
         }
         const int n_ref_wave = (int)wave_sum_to_lane63((double)n_valid_lane);   // valid in lane 63
 
+        // H only depends on which patches are visible (inverse-compositional Jacobians): it is summed on the
+        // level's first pass and again only when a lane of this wave sees a patch enter or leave the image —
+        // the same numbers the reference recomputes every iteration (:289-291), bit for bit.
+        unsigned long long vis_old = 0ull;
+        const bool maskable = npad <= (size_t)PT * 64;                 // one bit per patch of this lane
         for (int it = 0; it < a.max_iters; ++it) {
             double b[6] = {0, 0, 0, 0, 0, 0};
             double H[21];
@@ -1289,7 +1294,9 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
             for (int i = 0; i < 21; ++i) H[i] = 0.0;
             double chi2 = 0.0;
             int cnt = 0;
-            for (int p = tid; p < (int)npad; p += PT) {
+            const bool sum_h = (it == 0) || !maskable;
+            unsigned long long vis_new = 0ull, bit = 1ull;
+            for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
                 PatchRegs<double> P;
                 ws_load(ws, npad, p, P);
                 double c2, bp[6];
@@ -1299,25 +1306,45 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
                     for (int i = 0; i < 6; ++i) b[i] += bp[i];
                     chi2 += c2;
                     cnt += 1;
+                    vis_new |= bit;
+                    if (sum_h) {
+                        const PatchHess ph = patch_hess_factors<double>(P, fs);
+                        patch_hess_foreach<0, 0>(ph, [&](int q, double v) { H[q] += v; });
+                    }
+                }
+            }
+            bool h_new = sum_h;
+            if (!sum_h && __ballot(vis_new != vis_old) != 0ull) {      // rare: this wave's visible set changed
+                h_new = true;
+                bit = 1ull;
+                for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
+                    if (!(vis_new & bit)) continue;
+                    PatchRegs<double> P;
+                    ws_load(ws, npad, p, P);
                     const PatchHess ph = patch_hess_factors<double>(P, fs);
                     patch_hess_foreach<0, 0>(ph, [&](int q, double v) { H[q] += v; });
                 }
             }
+            vis_old = vis_new;
 #pragma unroll
             for (int i = 0; i < 6; ++i) b[i] = wave_sum_to_lane63(b[i]);
+            if (h_new) {
 #pragma unroll
-            for (int i = 0; i < 21; ++i) H[i] = wave_sum_to_lane63(H[i]);
+                for (int i = 0; i < 21; ++i) H[i] = wave_sum_to_lane63(H[i]);
+            }
             chi2 = wave_sum_to_lane63(chi2);
             const double cntd = wave_sum_to_lane63((double)cnt);
             if (lane == 63) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) s_part[wave].b[i] = b[i];
+                if (h_new) {
 #pragma unroll
-                for (int i = 0; i < 21; ++i) s_part[wave].H[i] = H[i];
+                    for (int i = 0; i < 21; ++i) s_part[wave].H[i] = H[i];
+                }
                 s_part[wave].chi2 = chi2;
                 s_part[wave].cnt = (int)cntd;
                 s_part[wave].n_ref = n_ref_wave;
-                s_part[wave].h_changed = 1;
+                s_part[wave].h_changed = h_new ? 1 : 0;
             }
             __syncthreads();                                           // B1
             __syncthreads();                                           // B2

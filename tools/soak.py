@@ -17,7 +17,7 @@ for seed in range(n_cfg):
     levels = int(rng.integers(1, 6))
     while levels > 1 and min(width, height) >> (levels - 1) < 20:
         levels -= 1
-    n = int(rng.choice([16, 40, 64, 65, 128, 129, 191, 192, 193, 255, 256, 257, 300, 319, 320, 321, 447, 448, 449, 700]))
+    n = int(rng.choice([16, 40, 64, 65, 128, 129, 191, 192, 193, 255, 256, 257, 300, 319, 320, 321, 447, 448, 449, 700, 704, 705, 1000, 1500]))
     max_level = int(rng.integers(1, levels + 1)); min_level = int(rng.integers(0, max_level))
     iters = int(rng.integers(1, 15))
     xi = tuple(rng.uniform(-1, 1, 6) * np.array([0.012, 0.012, 0.012, 0.006, 0.006, 0.006]) * rng.uniform(0.1, 3.0))
