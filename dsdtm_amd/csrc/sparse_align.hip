@@ -1354,6 +1354,234 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
 }
 
 // ---------------------------------------------------------------------------------------------
+// Team kernel: ONE pair spread over K workgroups (K compute units) for feature counts beyond one
+// workgroup's registers — the live tracker's case (BASELINE configs 3 and 5: 1000 / 2000 patches, one
+// pair at a time), where the workspace kernel above makes a single CU loop over 3..5 chunks per pass.
+// Member m keeps patches [m*448, (m+1)*448) in registers (one per lane, footprint windows in LDS, H summed
+// on visibility changes only: the register kernel's pass). Per Gauss-Newton iteration the members' seven
+// wave partials travel to member 0 through a 16-KB team buffer in HBM (agent-scope atomics: release by
+// the sender, acquire by the receiver), whose solver wave runs the ordinary solver_step over all 7*K
+// partials in fixed order and publishes pose + control word the same way. Members of a team are
+// workgroups b, b + P, b + 2P.. with P a multiple of 8, i.e. on the same XCD (one L2). Launched only
+// when every team is resident at once (teams * K <= half the CUs); a spin that never ends raises the
+// same timeout flag as the register kernel's hand-over and stops the pair.
+// ---------------------------------------------------------------------------------------------
+struct TeamHdr {
+    unsigned arrive;      // relays: +1 per iteration and member
+    unsigned pub;         // member 0: number of pose publications
+    unsigned pad[14];
+    double pose[16];      // R[9], tt[3], Cref[3], ctrl
+};
+constexpr size_t TEAM_BYTES = 16384;
+static_assert(sizeof(TeamHdr) + 8 * 7 * sizeof(WavePartial) <= TEAM_BYTES, "team buffer");
+
+__device__ __forceinline__ void team_store(double* dst, double v) {
+    __hip_atomic_store((unsigned long long*)dst, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double team_load(const double* src) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)src, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+// returns false on timeout
+__device__ __forceinline__ bool team_wait(const unsigned* word, unsigned target) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < SPIN_LIMIT)
+        __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (spins >= SPIN_LIMIT) { spin_timeout(); return false; }
+    return true;
+}
+// member 0: pose block of `s` + control word -> team buffer, publication number n
+__device__ __forceinline__ void team_publish(TeamHdr* th, BlockState& s, int ctrl, unsigned n, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < 16) {
+        const double v = lane < 9 ? s.u.R[lane] : lane < 12 ? s.u.tt[lane - 9] : lane < 15 ? s.u.Cref[lane - 12] : (double)ctrl;
+        team_store(&th->pose[lane], v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&th->pub, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// other members: wait for publication n, copy it into the local pose block; returns the control word
+__device__ __forceinline__ int team_receive(const TeamHdr* th, BlockState& s, unsigned n, int lane, bool& ok) {
+    ok = team_wait(&th->pub, n);
+    double v = 0.0;
+    if (lane < 16) v = team_load(&th->pose[lane]);
+    const int ctrl_in = (int)__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 15),
+                                              __builtin_amdgcn_readlane(__double2loint(v), 15));
+    const int ctrl = ok ? ctrl_in : 1;
+    if (lane < 9) s.u.R[lane] = v;
+    else if (lane < 12) s.u.tt[lane - 9] = v;
+    else if (lane < 15) s.u.Cref[lane - 12] = v;
+    if (lane == 0) s.ctrl = ctrl;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    return ctrl;
+}
+
+template <int K>
+__global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKernelArgs a, int pairs_pad) {
+    constexpr int NPW = 7, PT = NPW * 64, NP = NPW * K, WPD = sizeof(WavePartial) / sizeof(double);
+    __shared__ WavePartial s_part[NP];      // [0, 7): this member's waves; member 0: [7m, 7m+7) = member m's
+    __shared__ BlockState s;
+    __shared__ uint32_t s_win[WIN_ROWS * 3 * PT];
+
+    const int pair = (int)blockIdx.x % pairs_pad, member = (int)blockIdx.x / pairs_pad;
+    if (pair >= a.n_pairs) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nf = a.n_features ? a.n_features[pair] : a.max_features;
+    if (nf < a.min_fts || a.max_level - 1 < a.min_level) {              // the same decision in every member
+        if (member == 0 && tid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
+        return;
+    }
+    char* const tbase = (char*)a.workspace + (size_t)pair * TEAM_BYTES;
+    TeamHdr* const th = (TeamHdr*)tbase;
+    double* const tparts = (double*)(tbase + sizeof(TeamHdr));          // (K-1)*7 WavePartials, as doubles
+
+    if (wave == NPW) {                                                   // solver (member 0) / relay (others)
+        unsigned g = 0;                                                  // iterations so far, over all levels
+        if (member == 0) {
+            solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
+            if (lane == 0) stats_clear(a, pair);
+            team_publish(th, s, 0, 1u, lane);
+        }
+        bool dead = false;                                               // a team wait timed out: drain, keep the barriers matched
+        if (member != 0) {
+            bool ok;
+            (void)team_receive(th, s, 1u, lane, ok);
+            dead = !ok;
+        }
+        __syncthreads();                                                 // B0
+        for (int level = a.max_level - 1; level >= a.min_level; --level) {
+            if (member == 0 && lane == 0) {
+                s.chi2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.qo[i] = s.u.q[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) s.to[i] = s.u.t[i];
+            }
+            double hrow[6];
+            for (int it = 0; it < a.max_iters; ++it) {
+                __syncthreads();                                         // B1: this member's partials are in s_part[0..7)
+                int ctrl;
+                if (dead) {
+                    ctrl = 1;
+                    if (lane == 0) s.ctrl = 1;
+                } else if (member == 0) {
+                    const bool ok = team_wait(&th->arrive, (unsigned)(K - 1) * (g + 1u));
+                    for (int i = lane; i < (K - 1) * NPW * WPD; i += 64) ((double*)&s_part[NPW])[i] = team_load(tparts + i);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hrow);
+                    if (!ok) { ctrl = 1; dead = true; if (lane == 0) s.ctrl = 1; }
+                    team_publish(th, s, ctrl, g + 2u, lane);
+                } else {
+                    for (int i = lane; i < NPW * WPD; i += 64) team_store(tparts + (size_t)(member - 1) * NPW * WPD + i, ((const double*)&s_part[0])[i]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) __hip_atomic_fetch_add(&th->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool ok;
+                    ctrl = team_receive(th, s, g + 2u, lane, ok);
+                    dead = !ok;
+                }
+                ++g;
+                __syncthreads();                                         // B2
+                if (ctrl) break;
+            }
+        }
+        if (member == 0) solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
+        return;
+    }
+
+    // ---- patch waves: one patch per lane, in registers ------------------------------------------
+    const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
+    const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
+    const int p = member * PT + tid;                                     // this lane's feature
+    const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + (p < a.max_features ? p : 0), p < nf && p < a.max_features);
+    __syncthreads();                                                     // B0
+    FeatureRegs F;
+    {
+        const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
+        F = make_feature(fraw, Cref);
+    }
+    LdsU32* const win = (LdsU32*)&s_win[tid];
+    for (int level = a.max_level - 1; level >= a.min_level; --level) {
+        const LevelGeom lg = a.lv[level];
+        const double scale = (double)(1.0f / (float)(1 << level));
+        const double fs = (double)a.f * scale;
+        PatchRegs<double> P;
+        uint32_t worg = WIN_EMPTY;
+        precompute_patch<double>(a, lg, level, ref_base, F, P);
+        const int n_ref_wave = __popcll(__ballot(P.valid));
+        unsigned long long cached_mask = 0ull;
+        bool stop = false;
+        for (int it = 0; it < a.max_iters; ++it) {
+            double chi2, b[6];
+            pin_patch(P);
+            const bool vis = residual_patch<double, PT>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b, win, &worg);
+            const unsigned long long vmask = __ballot(vis);
+            const bool h_new = (it == 0) || (vmask != cached_mask);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b[i] = wave_sum_to_lane63(b[i]);
+            chi2 = wave_sum_to_lane63(chi2);
+            if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s_part[wave].b[i] = b[i];
+                s_part[wave].chi2 = chi2;
+                s_part[wave].cnt = __popcll(vmask);
+                s_part[wave].n_ref = n_ref_wave;
+                s_part[wave].h_changed = h_new ? 1 : 0;
+            }
+            if (h_new) {
+                const PatchHess ph = patch_hess_factors<double>(P, fs);
+                double* Hout = s_part[wave].H;
+                patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
+                    const double hs = wave_sum_to_lane63(vis ? v : 0.0);
+                    if (lane == 63) Hout[q] = hs;
+                    __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
+                });
+                cached_mask = vmask;
+            }
+            __syncthreads();                                             // B1
+            __syncthreads();                                             // B2
+            if (s.ctrl) { stop = true; break; }
+        }
+        (void)stop;
+    }
+}
+
+template <int K>
+static hipError_t launch_team(const SAKernelArgs& args, int pairs_pad, hipStream_t stream) {
+    hipLaunchKernelGGL((sparse_align_team_kernel<K>), dim3((unsigned)(pairs_pad * K)), dim3(8 * 64), 0, stream, args, pairs_pad);
+    return hipGetLastError();
+}
+
+// K members per pair for this feature count, or 0 when the team kernel does not apply (then: workspace kernel)
+int sparse_align_team_size(int n_pairs, int max_features, int num_cus) {
+    if (max_features <= 704 || n_pairs <= 0) return 0;
+    const int k = (max_features + 447) / 448;
+    const int pairs_pad = (n_pairs + 7) / 8 * 8;
+    if (k > 5 || pairs_pad * k > num_cus / 2) return 0;
+    return k;
+}
+size_t sparse_align_team_bytes(int n_pairs) { return (size_t)n_pairs * TEAM_BYTES; }
+
+hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream) {
+    if (args.n_pairs <= 0) return hipSuccess;
+    const int pairs_pad = (args.n_pairs + 7) / 8 * 8;
+    switch (k) {
+        case 2: return launch_team<2>(args, pairs_pad, stream);
+        case 3: return launch_team<3>(args, pairs_pad, stream);
+        case 4: return launch_team<4>(args, pairs_pad, stream);
+        case 5: return launch_team<5>(args, pairs_pad, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 // Register-kernel shapes: NPW patch waves + 1 solver wave per pair slot, PPW slots per workgroup,

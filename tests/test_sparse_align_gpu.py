@@ -578,3 +578,63 @@ def test_batch_launch_is_graph_capturable(gpu_ctx, oracle):
         for i, (To, no, _) in enumerate(want):
             H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"replay {rep} pair {i}")
             assert ntg[i] == no
+
+
+def test_team_kernel_over_several_compute_units(gpu_ctx, oracle):
+    """More features than one workgroup's registers hold (N > 704) and few pairs: every pair runs on a TEAM
+    of K workgroups that exchange their partial sums and the pose through HBM each iteration. Same results
+    as the oracle and — to rounding — as the single-workgroup workspace kernel (DSDTM_NO_TEAM=1), bit-identical
+    from launch to launch, ragged feature counts included; with many pairs the launcher falls back."""
+    import ctypes as C
+    import os
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N = 320, 240, 3, 1000
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=900 + i, margin=12) for i in range(3)]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in scenes]
+
+    def run(t, b, scenes_):
+        t["Tc"].copy_(torch.from_numpy(np.stack([s.T_cur_w_seed.reshape(12) for s in scenes_])).to(dev))
+        torch.cuda.synchronize()
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), None))
+        torch.cuda.synchronize()
+        return t["Tc"].cpu().numpy().copy(), t["nt"].cpu().numpy().copy()
+
+    t, b = _device_batch(torch, dev, scenes, L, W, Hh)
+    T1, n1 = run(t, b, scenes)
+    for i, (To, no, _) in enumerate(want):
+        H.assert_pose_close(T1[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"team pair {i}")
+        assert n1[i] == no
+    for _ in range(3):                                        # no dependence on timing
+        T2, n2 = run(t, b, scenes)
+        assert np.array_equal(T1, T2) and np.array_equal(n1, n2)
+    os.environ["DSDTM_NO_TEAM"] = "1"
+    try:
+        Tw, nw = run(t, b, scenes)
+    finally:
+        del os.environ["DSDTM_NO_TEAM"]
+    assert np.array_equal(n1, nw) and np.abs(T1 - Tw).max() < 1e-12
+    # ragged feature counts: members without a live patch still take part in every exchange
+    nf = np.array([1000, 720, 300], np.int32)
+    t["nf"] = torch.from_numpy(nf).to(dev)
+    b.n_features = t["nf"].data_ptr()
+    T3, n3 = run(t, b, scenes)
+    for i, sc in enumerate(scenes):
+        sub = type("S", (), {})()
+        for k in ("cam", "ref_pyr", "cur_pyr", "T_ref_w", "T_cur_w_seed"):
+            setattr(sub, k, getattr(sc, k))
+        sub.px, sub.bearing, sub.p_world, sub.initial = sc.px[:nf[i]], sc.bearing[:nf[i]], sc.p_world[:nf[i]], sc.initial[:nf[i]]
+        To, no, _ = oracle.sparse_align(sub, L, 0, 10)
+        H.assert_pose_close(T3[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"ragged pair {i}")
+        assert n3[i] == no
+    # 20 pairs still run as teams (24 x 3 workgroups), 60 pairs go to the workspace kernel: same answers
+    for P in (20, 60):
+        many = [scenes[i % 3] for i in range(P)]
+        tm, bm = _device_batch(torch, dev, many, L, W, Hh)
+        Tm, nm = run(tm, bm, many)
+        for i in range(P):
+            assert nm[i] == want[i % 3][1]
+            H.assert_pose_close(Tm[i], want[i % 3][0], H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"{P} pairs, pair {i}")
