@@ -173,6 +173,7 @@ static int validate_params(dsdtm_ctx* ctx, const dsdtm_align_params* p, int leve
 }
 
 static thread_local void* g_stamp_out = nullptr;   // device buffer, set only by the stamps debug entry
+static thread_local unsigned* g_timeout_out = nullptr;   // host-mapped word, set by the single-pair entry points
 
 extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam,
                                                const dsdtm_align_params* prm, void* hip_stream) {
@@ -210,6 +211,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     // the persistent kernels pull pair indices from this word: reset it on the launch stream
     // (a memset node when the stream is being captured into a hipGraph)
     a.pair_counter = ctx->d_counter + (ctx->launch_seq++ & 63u);
+    a.timeout_out = g_timeout_out;
     HIP_TRY(ctx, hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned), (hipStream_t)hip_stream));
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
         if (b->max_features > 320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
@@ -317,7 +319,18 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     memcpy(h + o_px, px_xy, nf * 8);
     memcpy(h + o_ini, initial, nf);
     memcpy(h + o_tc, T_cur_w, 96);
-    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes + 256, hipMemcpyHostToDevice, ctx->stream));
+    // Resident frames: the kernel reads features and poses straight from the pinned staging block (once per
+    // pair, ~17 KB over PCIe) and writes its few results there: no H2D / D2H copy operations around the launch.
+    static const bool zero_copy_enabled = getenv("DSDTM_NO_ZERO_COPY") == nullptr;
+    const bool zero_copy = zero_copy_enabled && !staged_pyr;
+    if (zero_copy) {
+        void* hd = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&hd, ctx->h_pinned, 0));
+        d = (uint8_t*)hd;
+        memset(h + o_nt, 0, total - o_nt);
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes + 256, hipMemcpyHostToDevice, ctx->stream));
+    }
 
     dsdtm_batch_desc b;
     memset(&b, 0, sizeof b);
@@ -329,13 +342,18 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     b.bearing = (const double*)(d + o_bear); b.p_world = (const double*)(d + o_pw); b.initial = d + o_ini;
     b.n_features = nullptr; b.T_ref_w = (const double*)(d + o_tr); b.T_cur_w = (double*)(d + o_tc);
     b.n_tracked = (int32_t*)(d + o_nt); b.stats = (dsdtm_align_stats*)(d + o_st);
-    if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, ctx->stream)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
-    // the kernel's hand-over timeout flag travels back with the results (no extra round trip)
-    if (!ctx->d_timeout_flag) HIP_TRY(ctx, sparse_align_timeout_flag_address(&ctx->d_timeout_flag));
     unsigned* h_flag = (unsigned*)(h + total);
     *h_flag = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(h_flag, ctx->d_timeout_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    g_timeout_out = zero_copy ? (unsigned*)(d + total) : nullptr;        // the kernel writes the flag itself
+    const int rc_launch = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, ctx->stream);
+    g_timeout_out = nullptr;
+    if (rc_launch) return rc_launch;
+    if (!zero_copy) {
+        HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
+        // the kernel's hand-over timeout flag travels back with the results (no extra round trip)
+        if (!ctx->d_timeout_flag) HIP_TRY(ctx, sparse_align_timeout_flag_address(&ctx->d_timeout_flag));
+        HIP_TRY(ctx, hipMemcpyAsync(h_flag, ctx->d_timeout_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_flag) {
         (void)sparse_align_clear_timeout_flag();

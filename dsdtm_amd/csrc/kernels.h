@@ -28,6 +28,7 @@ struct SAKernelArgs {
     dsdtm_align_stats* stats;
     double* workspace;
     unsigned* pair_counter;     // device word, zeroed before each launch: next pair index for the persistent slots
+    unsigned* timeout_out;      // optional (host-mapped) word: receives the hand-over timeout flag when a pair ends
     unsigned long long pyr_pitch;
     int n_pairs, max_features;
     int max_level, min_level, max_iters, min_fts;

@@ -116,6 +116,10 @@ constexpr unsigned SPIN_LIMIT = 1u << 24;
 // terminates) and raises this device-global flag, which the host entry points turn into an error.
 __device__ unsigned g_handover_timeout = 0;
 __device__ __forceinline__ void spin_timeout() { atomicOr(&g_handover_timeout, 1u); }
+// single-pair host calls read the flag from a host-mapped word instead of copying the symbol back
+__device__ __forceinline__ void report_timeout(const SAKernelArgs& a, int lane) {
+    if (a.timeout_out && lane == 0) *a.timeout_out = __hip_atomic_load(&g_handover_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ void pair_signal_arrive(unsigned* counter, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS stores first
@@ -1021,6 +1025,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 }
             }
             solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
+            report_timeout(a, lane);
             if (STAMPS && lane == 0 && a.workspace) {
                 unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 8;
                 o[0] = t_first; o[1] = t_wait; o[2] = t_solve; o[3] = n_it;
@@ -1256,6 +1261,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
             }
         }
         solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
+        report_timeout(a, lane);
         return;
     }
 
@@ -1492,7 +1498,10 @@ __global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKerne
                 if (ctrl) break;
             }
         }
-        if (member == 0) solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
+        if (member == 0) {
+            solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
+            report_timeout(a, lane);
+        }
         return;
     }
 
