@@ -1526,7 +1526,6 @@ __global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKerne
         precompute_patch<double>(a, lg, level, ref_base, F, P);
         const int n_ref_wave = __popcll(__ballot(P.valid));
         unsigned long long cached_mask = 0ull;
-        bool stop = false;
         for (int it = 0; it < a.max_iters; ++it) {
             double chi2, b[6];
             pin_patch(P);
@@ -1556,9 +1555,8 @@ __global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKerne
             }
             __syncthreads();                                             // B1
             __syncthreads();                                             // B2
-            if (s.ctrl) { stop = true; break; }
+            if (s.ctrl) break;
         }
-        (void)stop;
     }
 }
 
