@@ -1364,22 +1364,21 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
 // workgroup's registers — the live tracker's case (BASELINE configs 3 and 5: 1000 / 2000 patches, one
 // pair at a time), where the workspace kernel above makes a single CU loop over 3..5 chunks per pass.
 // Member m keeps patches [m*448, (m+1)*448) in registers (one per lane, footprint windows in LDS, H summed
-// on visibility changes only: the register kernel's pass). Per Gauss-Newton iteration the members' seven
-// wave partials travel to member 0 through a 16-KB team buffer in HBM (agent-scope atomics: release by
-// the sender, acquire by the receiver), whose solver wave runs the ordinary solver_step over all 7*K
-// partials in fixed order and publishes pose + control word the same way. Members of a team are
+// on visibility changes only: the register kernel's pass). Per Gauss-Newton iteration every member publishes
+// its seven wave partials in a team buffer in HBM (agent-scope atomic stores, a release fence, then its
+// flag word; double-buffered by iteration parity) and reads the other members' (poll the flags, acquire,
+// agent-scope loads). Every member's solver wave then runs the ordinary solver_step over the same 7*K
+// partials in the same order, so all members hold the same pose bit for bit without a broadcast: ONE
+// exchange per iteration. Member 0 alone writes pose, count and statistics. Members of a team are
 // workgroups b, b + P, b + 2P.. with P a multiple of 8, i.e. on the same XCD (one L2). Launched only
-// when every team is resident at once (teams * K <= half the CUs); a spin that never ends raises the
-// same timeout flag as the register kernel's hand-over and stops the pair.
+// when every team is resident at once (teams * K <= half the CUs); a wait that never ends raises the
+// same timeout flag as the register kernel's hand-over, stops the pair and drains its barriers.
 // ---------------------------------------------------------------------------------------------
 struct TeamHdr {
-    unsigned arrive;      // relays: +1 per iteration and member
-    unsigned pub;         // member 0: number of pose publications
-    unsigned pad[14];
-    double pose[16];      // R[9], tt[3], Cref[3], ctrl
+    unsigned flag[16];    // flag[m]: iterations whose partials member m has published
 };
-constexpr size_t TEAM_BYTES = 16384;
-static_assert(sizeof(TeamHdr) + 8 * 7 * sizeof(WavePartial) <= TEAM_BYTES, "team buffer");
+constexpr size_t TEAM_BYTES = 32768;
+static_assert(sizeof(TeamHdr) + 2 * 8 * 7 * sizeof(WavePartial) <= TEAM_BYTES, "team buffer");
 
 __device__ __forceinline__ void team_store(double* dst, double v) {
     __hip_atomic_store((unsigned long long*)dst, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
@@ -1389,47 +1388,25 @@ __device__ __forceinline__ double team_load(const double* src) {
     return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)src, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT));
 }
-// returns false on timeout
-__device__ __forceinline__ bool team_wait(const unsigned* word, unsigned target) {
+// lane j < k (j != self) waits until member j has published `target` iterations; returns false on timeout
+__device__ __forceinline__ bool team_wait_all(const TeamHdr* th, int k, int self, unsigned target, int lane) {
     unsigned spins = 0;
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < SPIN_LIMIT)
+    const bool mine = lane < k && lane != self;
+    for (;;) {
+        const bool pending = mine && __hip_atomic_load(&th->flag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target;
+        if (__ballot(pending) == 0ull) break;
+        if (++spins >= SPIN_LIMIT) break;
         __builtin_amdgcn_s_sleep(2);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (spins >= SPIN_LIMIT) { spin_timeout(); return false; }
     return true;
-}
-// member 0: pose block of `s` + control word -> team buffer, publication number n
-__device__ __forceinline__ void team_publish(TeamHdr* th, BlockState& s, int ctrl, unsigned n, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane < 16) {
-        const double v = lane < 9 ? s.u.R[lane] : lane < 12 ? s.u.tt[lane - 9] : lane < 15 ? s.u.Cref[lane - 12] : (double)ctrl;
-        team_store(&th->pose[lane], v);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) __hip_atomic_store(&th->pub, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// other members: wait for publication n, copy it into the local pose block; returns the control word
-__device__ __forceinline__ int team_receive(const TeamHdr* th, BlockState& s, unsigned n, int lane, bool& ok) {
-    ok = team_wait(&th->pub, n);
-    double v = 0.0;
-    if (lane < 16) v = team_load(&th->pose[lane]);
-    const int ctrl_in = (int)__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 15),
-                                              __builtin_amdgcn_readlane(__double2loint(v), 15));
-    const int ctrl = ok ? ctrl_in : 1;
-    if (lane < 9) s.u.R[lane] = v;
-    else if (lane < 12) s.u.tt[lane - 9] = v;
-    else if (lane < 15) s.u.Cref[lane - 12] = v;
-    if (lane == 0) s.ctrl = ctrl;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    return ctrl;
 }
 
 template <int K>
 __global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKernelArgs a, int pairs_pad) {
     constexpr int NPW = 7, PT = NPW * 64, NP = NPW * K, WPD = sizeof(WavePartial) / sizeof(double);
-    __shared__ WavePartial s_part[NP];      // [0, 7): this member's waves; member 0: [7m, 7m+7) = member m's
+    __shared__ WavePartial s_part[NP];      // [7m, 7m+7): member m's waves, the same order in every member
     __shared__ BlockState s;
     __shared__ uint32_t s_win[WIN_ROWS * 3 * PT];
 
@@ -1445,24 +1422,22 @@ __global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKerne
     }
     char* const tbase = (char*)a.workspace + (size_t)pair * TEAM_BYTES;
     TeamHdr* const th = (TeamHdr*)tbase;
-    double* const tparts = (double*)(tbase + sizeof(TeamHdr));          // (K-1)*7 WavePartials, as doubles
+    double* const tparts = (double*)(tbase + sizeof(TeamHdr));          // [parity][member][7] WavePartials, as doubles
+    WavePartial* const my_part = &s_part[member * NPW];                  // this member's slots
 
-    if (wave == NPW) {                                                   // solver (member 0) / relay (others)
+    if (wave == NPW) {
+        // Every member runs the SAME solver on the SAME 7*K partials in the same order, so every member holds
+        // the same pose, bit for bit, without a broadcast: one exchange per iteration (all members publish their
+        // partials, all members read the others') instead of gather + broadcast. Member 0 alone writes results.
+        SAKernelArgs am = a;
+        if (member != 0) am.stats = nullptr;
         unsigned g = 0;                                                  // iterations so far, over all levels
-        if (member == 0) {
-            solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
-            if (lane == 0) stats_clear(a, pair);
-            team_publish(th, s, 0, 1u, lane);
-        }
-        bool dead = false;                                               // a team wait timed out: drain, keep the barriers matched
-        if (member != 0) {
-            bool ok;
-            (void)team_receive(th, s, 1u, lane, ok);
-            dead = !ok;
-        }
+        solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
+        if (member == 0 && lane == 0) stats_clear(a, pair);
         __syncthreads();                                                 // B0
+        bool dead = false;                                               // a team wait timed out: drain, keep the barriers matched
         for (int level = a.max_level - 1; level >= a.min_level; --level) {
-            if (member == 0 && lane == 0) {
+            if (lane == 0) {
                 s.chi2 = 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s.qo[i] = s.u.q[i];
@@ -1471,27 +1446,25 @@ __global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKerne
             }
             double hrow[6];
             for (int it = 0; it < a.max_iters; ++it) {
-                __syncthreads();                                         // B1: this member's partials are in s_part[0..7)
+                __syncthreads();                                         // B1: this member's partials are in my_part[0..7)
                 int ctrl;
                 if (dead) {
                     ctrl = 1;
                     if (lane == 0) s.ctrl = 1;
-                } else if (member == 0) {
-                    const bool ok = team_wait(&th->arrive, (unsigned)(K - 1) * (g + 1u));
-                    for (int i = lane; i < (K - 1) * NPW * WPD; i += 64) ((double*)&s_part[NPW])[i] = team_load(tparts + i);
+                } else {
+                    double* const bank = tparts + (size_t)(g & 1u) * K * NPW * WPD;      // double-buffered by parity
+                    for (int i = lane; i < NPW * WPD; i += 64) team_store(bank + (size_t)member * NPW * WPD + i, ((const double*)my_part)[i]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) __hip_atomic_store(&th->flag[member], g + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = team_wait_all(th, K, member, g + 1u, lane);
+                    for (int i = lane; i < K * NPW * WPD; i += 64) {
+                        if (i / (NPW * WPD) != member) ((double*)s_part)[i] = team_load(bank + i);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hrow);
+                    ctrl = solver_step<NP>(am, pair, level, it, s_part, s, lane, hrow);
                     if (!ok) { ctrl = 1; dead = true; if (lane == 0) s.ctrl = 1; }
-                    team_publish(th, s, ctrl, g + 2u, lane);
-                } else {
-                    for (int i = lane; i < NPW * WPD; i += 64) team_store(tparts + (size_t)(member - 1) * NPW * WPD + i, ((const double*)&s_part[0])[i]);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (lane == 0) __hip_atomic_fetch_add(&th->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bool ok;
-                    ctrl = team_receive(th, s, g + 2u, lane, ok);
-                    dead = !ok;
                 }
                 ++g;
                 __syncthreads();                                         // B2
@@ -1537,15 +1510,15 @@ __global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKerne
             chi2 = wave_sum_to_lane63(chi2);
             if (lane == 63) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) s_part[wave].b[i] = b[i];
-                s_part[wave].chi2 = chi2;
-                s_part[wave].cnt = __popcll(vmask);
-                s_part[wave].n_ref = n_ref_wave;
-                s_part[wave].h_changed = h_new ? 1 : 0;
+                for (int i = 0; i < 6; ++i) my_part[wave].b[i] = b[i];
+                my_part[wave].chi2 = chi2;
+                my_part[wave].cnt = __popcll(vmask);
+                my_part[wave].n_ref = n_ref_wave;
+                my_part[wave].h_changed = h_new ? 1 : 0;
             }
             if (h_new) {
                 const PatchHess ph = patch_hess_factors<double>(P, fs);
-                double* Hout = s_part[wave].H;
+                double* Hout = my_part[wave].H;
                 patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
                     const double hs = wave_sum_to_lane63(vis ? v : 0.0);
                     if (lane == 63) Hout[q] = hs;
