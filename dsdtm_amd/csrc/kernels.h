@@ -58,7 +58,7 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
 // diagnostic (in-kernel stamps) instantiation of the 5+1-wave register kernel; workspace = n_pairs*8 u64
 hipError_t sparse_align_timeout_flag_address(unsigned** addr);   // device-side hand-over timeout flag (should never be set)
 hipError_t sparse_align_clear_timeout_flag();
-// team kernel (one pair over K workgroups, 704 < N <= 2240, few pairs): K or 0; bytes of the zeroed team buffers
+// team kernel (one pair over K workgroups, 704 < N <= 4096, few pairs): K or 0; bytes of the zeroed team buffers
 int sparse_align_team_size(int n_pairs, int max_features, int num_cus);
 size_t sparse_align_team_bytes(int n_pairs);
 hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream);

@@ -1377,8 +1377,8 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
 struct TeamHdr {
     unsigned flag[16];    // flag[m]: iterations whose partials member m has published
 };
-constexpr size_t TEAM_BYTES = 32768;
-static_assert(sizeof(TeamHdr) + 2 * 8 * 7 * sizeof(WavePartial) <= TEAM_BYTES, "team buffer");
+constexpr size_t TEAM_BYTES = 32768;     // two banks of <= 64 WavePartials (240 B each) + the flags
+static_assert(sizeof(TeamHdr) + 2 * 64 * sizeof(WavePartial) <= TEAM_BYTES, "team buffer: two banks of <= 64 wave partials");
 
 __device__ __forceinline__ void team_store(double* dst, double v) {
     __hip_atomic_store((unsigned long long*)dst, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
@@ -1403,10 +1403,11 @@ __device__ __forceinline__ bool team_wait_all(const TeamHdr* th, int k, int self
     return true;
 }
 
-template <int K>
-__global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKernelArgs a, int pairs_pad) {
-    constexpr int NPW = 7, PT = NPW * 64, NP = NPW * K, WPD = sizeof(WavePartial) / sizeof(double);
-    __shared__ WavePartial s_part[NP];      // [7m, 7m+7): member m's waves, the same order in every member
+template <int K, int NPW>
+__global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const SAKernelArgs a, int pairs_pad) {
+    constexpr int PT = NPW * 64, NP = NPW * K, WPD = sizeof(WavePartial) / sizeof(double);
+    static_assert(NP <= 64 && K <= 16, "one solver lane per partial slot, one flag word per member");
+    __shared__ WavePartial s_part[NP];      // [NPW*m, NPW*m+NPW): member m's waves, the same order in every member
     __shared__ BlockState s;
     __shared__ uint32_t s_win[WIN_ROWS * 3 * PT];
 
@@ -1533,32 +1534,38 @@ __global__ __launch_bounds__(8 * 64) void sparse_align_team_kernel(const SAKerne
     }
 }
 
-template <int K>
+template <int K, int NPW>
 static hipError_t launch_team(const SAKernelArgs& args, int pairs_pad, hipStream_t stream) {
-    hipLaunchKernelGGL((sparse_align_team_kernel<K>), dim3((unsigned)(pairs_pad * K)), dim3(8 * 64), 0, stream, args, pairs_pad);
+    hipLaunchKernelGGL((sparse_align_team_kernel<K, NPW>), dim3((unsigned)(pairs_pad * K)), dim3((NPW + 1) * 64), 0, stream, args, pairs_pad);
     return hipGetLastError();
 }
 
-// K members per pair for this feature count, or 0 when the team kernel does not apply (then: workspace kernel)
+// Team shape: members of 4 patch waves (256 patches: every SIMD of a member's CU carries one patch wave, the
+// pass runs at its uncontended ~3 k cycles and the level start's gathers spread over more CUs; members of 7
+// waves were 15 % slower), K = ceil(N / 256) <= 16 members (N <= 4096: one solver lane per partial slot).
+// Returns K, or 0 when the team kernel does not apply (then: workspace kernel).
+constexpr int TEAM_NPW = 4;
 int sparse_align_team_size(int n_pairs, int max_features, int num_cus) {
     if (max_features <= 704 || n_pairs <= 0) return 0;
-    const int k = (max_features + 447) / 448;
     const int pairs_pad = (n_pairs + 7) / 8 * 8;
-    if (k > 5 || pairs_pad * k > num_cus / 2) return 0;
+    const int k = (max_features + TEAM_NPW * 64 - 1) / (TEAM_NPW * 64);
+    if (k > 16 || pairs_pad * k > num_cus / 2) return 0;
     return k;
 }
 size_t sparse_align_team_bytes(int n_pairs) { return (size_t)n_pairs * TEAM_BYTES; }
 
+template <int K>
+static hipError_t launch_team_k(const SAKernelArgs& args, int k, int pairs_pad, hipStream_t stream) {
+    if constexpr (K > 16) return hipErrorInvalidValue;
+    else {
+        if (k == K) return launch_team<K, TEAM_NPW>(args, pairs_pad, stream);
+        return launch_team_k<K + 1>(args, k, pairs_pad, stream);
+    }
+}
+
 hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
-    const int pairs_pad = (args.n_pairs + 7) / 8 * 8;
-    switch (k) {
-        case 2: return launch_team<2>(args, pairs_pad, stream);
-        case 3: return launch_team<3>(args, pairs_pad, stream);
-        case 4: return launch_team<4>(args, pairs_pad, stream);
-        case 5: return launch_team<5>(args, pairs_pad, stream);
-    }
-    return hipErrorInvalidValue;
+    return launch_team_k<3>(args, k, (args.n_pairs + 7) / 8 * 8, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -91,9 +91,10 @@ def test_random_scenes_match_oracle(gpu_ctx, oracle, seed):
 
 
 @pytest.mark.parametrize("n_patches,size", [(330, (320, 240)), (448, (320, 240)), (449, (320, 240)), (600, (640, 480)), (704, (640, 480)),
-                                             (705, (640, 480)), (1000, (640, 480)), (2000, (640, 480))])
+                                             (705, (640, 480)), (1000, (640, 480)), (2000, (640, 480)), (4096, (640, 480)), (4100, (640, 480))])
 def test_large_patch_counts(gpu_ctx, oracle, n_patches, size):
-    """448- and 704-lane register kernels and the workspace kernel (configs 3 and 5 patch counts)."""
+    """448- and 704-lane register kernels, teams of 3..16 compute units (705..4096 features: configs 3 and 5 patch
+    counts) and the workspace kernel beyond."""
     sc = cached_scene(width=size[0], height=size[1], levels=3, n_patches=n_patches, seed=77, margin=12)
     To, no, so = oracle.sparse_align(sc, 3, 0, 8)
     Tg, ng, sg = H.gpu_sparse_align(sc, 3, 0, 8, ctx=gpu_ctx)
@@ -630,7 +631,7 @@ def test_team_kernel_over_several_compute_units(gpu_ctx, oracle):
         To, no, _ = oracle.sparse_align(sub, L, 0, 10)
         H.assert_pose_close(T3[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"ragged pair {i}")
         assert n3[i] == no
-    # 20 pairs still run as teams (24 x 3 workgroups), 60 pairs go to the workspace kernel: same answers
+    # 20 pairs still run as teams (24 x 4 workgroups), 60 pairs go to the workspace kernel: same answers
     for P in (20, 60):
         many = [scenes[i % 3] for i in range(P)]
         tm, bm = _device_batch(torch, dev, many, L, W, Hh)
