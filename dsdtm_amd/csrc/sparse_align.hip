@@ -1374,40 +1374,22 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
 // when every team is resident at once (teams * K <= half the CUs); a wait that never ends raises the
 // same timeout flag as the register kernel's hand-over, stops the pair and drains its barriers.
 // ---------------------------------------------------------------------------------------------
-struct TeamHdr {
-    unsigned flag[16];    // flag[m]: iterations whose partials member m has published
-};
-constexpr size_t TEAM_BYTES = 32768;     // two banks of <= 64 WavePartials (240 B each) + the flags
-static_assert(sizeof(TeamHdr) + 2 * 64 * sizeof(WavePartial) <= TEAM_BYTES, "team buffer: two banks of <= 64 wave partials");
-
-__device__ __forceinline__ void team_store(double* dst, double v) {
-    __hip_atomic_store((unsigned long long*)dst, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double team_load(const double* src) {
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)src, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT));
-}
-// lane j < k (j != self) waits until member j has published `target` iterations; returns false on timeout
-__device__ __forceinline__ bool team_wait_all(const TeamHdr* th, int k, int self, unsigned target, int lane) {
-    unsigned spins = 0;
-    const bool mine = lane < k && lane != self;
-    for (;;) {
-        const bool pending = mine && __hip_atomic_load(&th->flag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target;
-        if (__ballot(pending) == 0ull) break;
-        if (++spins >= SPIN_LIMIT) break;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (spins >= SPIN_LIMIT) { spin_timeout(); return false; }
-    return true;
-}
+// The exchange buffer holds TAGGED WORDS: every 64-bit word carries 32 bits of payload and, in its upper
+// half, the number of the iteration it belongs to. 64-bit atomic stores and loads are single-copy atomic, so
+// a reader that finds the expected tag in a word holds that iteration's payload — no flag, no fence and no
+// second round trip: the writer fires its stores and goes on, a reader polls the words themselves until
+// every tag matches. Two banks (iteration parity): a member can only overwrite the bank of iteration g at
+// iteration g + 2, which it reaches after every other member has published g + 1, i.e. has read all of g.
+constexpr int TEAM_WPD = sizeof(WavePartial) / sizeof(double);          // doubles of one (member) partial
+constexpr size_t TEAM_BYTES = 2 * 16 * TEAM_WPD * 2 * sizeof(unsigned long long);   // banks x members x words
+static_assert(TEAM_BYTES <= 16384, "team buffer");
 
 template <int K, int NPW>
 __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const SAKernelArgs a, int pairs_pad) {
-    constexpr int PT = NPW * 64, NP = NPW * K, WPD = sizeof(WavePartial) / sizeof(double);
-    static_assert(NP <= 64 && K <= 16, "one solver lane per partial slot, one flag word per member");
-    __shared__ WavePartial s_part[NP];      // [NPW*m, NPW*m+NPW): member m's waves, the same order in every member
+    constexpr int PT = NPW * 64, WPD = TEAM_WPD;
+    static_assert(K <= 16 && WPD <= 32, "one solver lane per member partial / per double of a partial");
+    __shared__ WavePartial s_part[NPW];     // this member's wave partials
+    __shared__ WavePartial s_mpart[K];      // one partial per member (its waves summed in wave order), member order
     __shared__ BlockState s;
     __shared__ uint32_t s_win[WIN_ROWS * 3 * PT];
 
@@ -1421,15 +1403,13 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
         if (member == 0 && tid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
         return;
     }
-    char* const tbase = (char*)a.workspace + (size_t)pair * TEAM_BYTES;
-    TeamHdr* const th = (TeamHdr*)tbase;
-    double* const tparts = (double*)(tbase + sizeof(TeamHdr));          // [parity][member][7] WavePartials, as doubles
-    WavePartial* const my_part = &s_part[member * NPW];                  // this member's slots
+    unsigned long long* const twords = (unsigned long long*)((char*)a.workspace + (size_t)pair * TEAM_BYTES);
+    WavePartial* const my_part = s_part;
 
     if (wave == NPW) {
-        // Every member runs the SAME solver on the SAME 7*K partials in the same order, so every member holds
-        // the same pose, bit for bit, without a broadcast: one exchange per iteration (all members publish their
-        // partials, all members read the others') instead of gather + broadcast. Member 0 alone writes results.
+        // Every member runs the SAME solver on the SAME K member partials in the same order, so every member
+        // holds the same pose, bit for bit, without a broadcast: one exchange per iteration. Member 0 alone
+        // writes results.
         SAKernelArgs am = a;
         if (member != 0) am.stats = nullptr;
         unsigned g = 0;                                                  // iterations so far, over all levels
@@ -1447,24 +1427,59 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
             }
             double hrow[6];
             for (int it = 0; it < a.max_iters; ++it) {
-                __syncthreads();                                         // B1: this member's partials are in my_part[0..7)
+                __syncthreads();                                         // B1: this member's wave partials are in s_part
                 int ctrl;
                 if (dead) {
                     ctrl = 1;
                     if (lane == 0) s.ctrl = 1;
                 } else {
-                    double* const bank = tparts + (size_t)(g & 1u) * K * NPW * WPD;      // double-buffered by parity
-                    for (int i = lane; i < NPW * WPD; i += 64) team_store(bank + (size_t)member * NPW * WPD + i, ((const double*)my_part)[i]);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (lane == 0) __hip_atomic_store(&th->flag[member], g + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ok = team_wait_all(th, K, member, g + 1u, lane);
-                    for (int i = lane; i < K * NPW * WPD; i += 64) {
-                        if (i / (NPW * WPD) != member) ((double*)s_part)[i] = team_load(bank + i);
+                    const unsigned long long tag = (unsigned long long)(g + 1u) << 32;
+                    unsigned long long* const bank = twords + (size_t)(g & 1u) * 16 * WPD * 2;
+                    // this member's partial: lane i < WPD folds double i of its wave partials in wave order
+                    // (doubles 7 and 8 are the packed counters: cnt | h_changed and n_ref | pad)
+                    if (lane < WPD) {
+                        unsigned long long raw;
+                        if (lane == 7 || lane == 8) {
+                            int lo = 0, hi = 0;
+#pragma unroll
+                            for (int w = 0; w < NPW; ++w) {
+                                const int* q = (const int*)((const double*)&s_part[w] + lane);
+                                lo += q[0];
+                                hi |= (lane == 7) ? q[1] : 0;
+                            }
+                            raw = (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
+                        } else {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int w = 0; w < NPW; ++w) acc += ((const double*)&s_part[w])[lane];
+                            raw = (unsigned long long)__double_as_longlong(acc);
+                        }
+                        ((unsigned long long*)&s_mpart[member])[lane] = raw;
+                        unsigned long long* dst = bank + ((size_t)member * WPD + lane) * 2;
+                        __hip_atomic_store(dst, (raw & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 1, (raw >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    // the other members' partials: poll the tagged words themselves
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool pending = false;
+                        for (int i = lane; i < K * WPD; i += 64) {
+                            if (i / WPD == member) continue;
+                            const unsigned long long w0 = __hip_atomic_load(bank + 2 * (size_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long w1 = __hip_atomic_load(bank + 2 * (size_t)i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((w0 & 0xffffffff00000000ull) != tag || (w1 & 0xffffffff00000000ull) != tag) pending = true;
+                            else ((unsigned long long*)s_mpart)[i] = (w0 & 0xffffffffull) | (w1 << 32);
+                        }
+                        if (__ballot(pending) == 0ull) break;
+                        if (++spins >= SPIN_LIMIT) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    const bool ok = spins < SPIN_LIMIT;
+                    if (!ok) spin_timeout();
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    ctrl = solver_step<NP>(am, pair, level, it, s_part, s, lane, hrow);
+                    ctrl = solver_step<K>(am, pair, level, it, s_mpart, s, lane, hrow);
                     if (!ok) { ctrl = 1; dead = true; if (lane == 0) s.ctrl = 1; }
                 }
                 ++g;
