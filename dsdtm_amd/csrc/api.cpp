@@ -235,7 +235,9 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     }
     // few pairs with more features than one workgroup holds: one pair over K compute units (the team
     // buffers sit at the start of the workspace, which is larger; their words are zeroed on the stream)
-    if (const int k = (v == SA_WS && getenv("DSDTM_NO_TEAM") == nullptr) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0) {
+    if (const int k = (getenv("DSDTM_NO_TEAM") == nullptr) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0) {
+        if (sparse_align_team_bytes(b->n_pairs) > ctx->ws_cap) { if (int rc = dsdtm_reserve(ctx, sparse_align_team_bytes(b->n_pairs))) return rc; }
+        a.workspace = (double*)ctx->d_ws;
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, sparse_align_team_bytes(b->n_pairs), (hipStream_t)hip_stream));
         HIP_TRY(ctx, sparse_align_launch_team(a, k, (hipStream_t)hip_stream));
         return DSDTM_OK;

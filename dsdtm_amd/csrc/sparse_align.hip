@@ -1555,13 +1555,16 @@ static hipError_t launch_team(const SAKernelArgs& args, int pairs_pad, hipStream
     return hipGetLastError();
 }
 
-// Team shape: members of 4 patch waves (256 patches: every SIMD of a member's CU carries one patch wave, the
+// Team shape (few pairs of more than 448 features): members of 4 patch waves (256 patches: every SIMD of a member's CU carries one patch wave, the
 // pass runs at its uncontended ~3 k cycles and the level start's gathers spread over more CUs; members of 7
-// waves were 15 % slower), K = ceil(N / 256) <= 16 members (N <= 4096: one solver lane per partial slot).
+// waves were 15 % slower), K = ceil(N / 256) = 2..16 members (N <= 4096: one solver lane per member partial).
 // Returns K, or 0 when the team kernel does not apply (then: workspace kernel).
 constexpr int TEAM_NPW = 4;
 int sparse_align_team_size(int n_pairs, int max_features, int num_cus) {
-    if (max_features <= 704 || n_pairs <= 0) return 0;
+    // from 449 features a team of 2..3 CUs beats the 11 + 1 wave register kernel on one CU (N = 600: 0.113 vs
+    // 0.121 ms per Run); below, one CU wins (N = 300: 0.108 vs 0.115 ms). DSDTM_TEAM_MIN overrides (diagnostic).
+    static const int team_min = getenv("DSDTM_TEAM_MIN") ? atoi(getenv("DSDTM_TEAM_MIN")) : 449;
+    if (max_features < team_min || n_pairs <= 0) return 0;
     const int pairs_pad = (n_pairs + 7) / 8 * 8;
     const int k = (max_features + TEAM_NPW * 64 - 1) / (TEAM_NPW * 64);
     if (k > 16 || pairs_pad * k > num_cus / 2) return 0;
@@ -1580,7 +1583,7 @@ static hipError_t launch_team_k(const SAKernelArgs& args, int k, int pairs_pad, 
 
 hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
-    return launch_team_k<3>(args, k, (args.n_pairs + 7) / 8 * 8, stream);
+    return launch_team_k<2>(args, k, (args.n_pairs + 7) / 8 * 8, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
