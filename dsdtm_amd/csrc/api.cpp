@@ -32,6 +32,9 @@ struct dsdtm_ctx {
     // pair counters of the persistent sparse-align kernel: a ring of 64 words, one per launch in flight
     // (each zeroed by a memset node on the launch stream right before its kernel)
     unsigned* d_counter = nullptr;
+    // exchange buffers of the team kernel: a ring of 8 launches x 64 pairs (allocated with the context, so that
+    // launches on several streams and launches captured into a hipGraph need nothing else)
+    uint8_t* d_team = nullptr;
     unsigned launch_seq = 0;
     unsigned* d_timeout_flag = nullptr;   // device address of the kernel's hand-over timeout flag
     int num_cus = 256;
@@ -104,7 +107,9 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
         return DSDTM_ERR_HIP;
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc((void**)&ctx->d_counter, 256) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->d_counter, 256) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_team, 8 * sparse_align_team_bytes(64)) != hipSuccess) {
+        if (ctx->d_counter) (void)hipFree(ctx->d_counter);
         set_err(nullptr, "hipMalloc failed on device %d", device);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -122,6 +127,7 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+    if (ctx->d_team) (void)hipFree(ctx->d_team);
     delete ctx;
 }
 
@@ -219,6 +225,15 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         HIP_TRY(ctx, sparse_align_launch_stamps(a, ctx->num_cus, (hipStream_t)hip_stream));
         return DSDTM_OK;
     }
+    // few pairs of more than 448 features: one pair over K compute units; their exchange buffers come from the
+    // context's ring (one slot per launch in flight) and are zeroed on the stream
+    if (const int k = (b->n_pairs <= 64 && getenv("DSDTM_NO_TEAM") == nullptr) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0) {
+        uint8_t* slot = ctx->d_team + (size_t)(ctx->launch_seq & 7u) * sparse_align_team_bytes(64);
+        a.workspace = (double*)slot;
+        HIP_TRY(ctx, hipMemsetAsync(slot, 0, sparse_align_team_bytes(b->n_pairs), (hipStream_t)hip_stream));
+        HIP_TRY(ctx, sparse_align_launch_team(a, k, (hipStream_t)hip_stream));
+        return DSDTM_OK;
+    }
     const SAVariant v = sparse_align_pick_variant(b->max_features);
     const size_t ws = sparse_align_workspace_bytes(b->n_pairs, b->max_features);
     if (ws) {
@@ -232,15 +247,6 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
             if (int rc = dsdtm_reserve(ctx, ws)) return rc;
         }
         a.workspace = (double*)ctx->d_ws;
-    }
-    // few pairs with more features than one workgroup holds: one pair over K compute units (the team
-    // buffers sit at the start of the workspace, which is larger; their words are zeroed on the stream)
-    if (const int k = (getenv("DSDTM_NO_TEAM") == nullptr) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0) {
-        if (sparse_align_team_bytes(b->n_pairs) > ctx->ws_cap) { if (int rc = dsdtm_reserve(ctx, sparse_align_team_bytes(b->n_pairs))) return rc; }
-        a.workspace = (double*)ctx->d_ws;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, sparse_align_team_bytes(b->n_pairs), (hipStream_t)hip_stream));
-        HIP_TRY(ctx, sparse_align_launch_team(a, k, (hipStream_t)hip_stream));
-        return DSDTM_OK;
     }
     HIP_TRY(ctx, sparse_align_launch(a, v, ctx->num_cus, (hipStream_t)hip_stream));
     return DSDTM_OK;

@@ -302,9 +302,9 @@ int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* batc
  * stream capture; call dsdtm_reserve first when the launch is to be captured into a hipGraph.
  * The workspace belongs to the context: launches that use it (max_features > 704) must not be in
  * flight on two streams of one context at the same time — use one context per stream for those.
- * Few pairs of 449..4096 features (roughly n_pairs * ceil(max_features / 256) <= 128) are each spread over
- * several compute units that exchange their partial sums through a small context-owned buffer every
- * iteration; the same one-launch-at-a-time rule applies to them. */
+ * Few pairs of 449..4096 features (n_pairs <= 64 and roughly n_pairs * ceil(max_features / 256) <= 128) need
+ * no workspace: each is spread over several compute units that exchange their partial sums through a ring
+ * of context-owned buffers (up to 8 such launches in flight). */
 size_t dsdtm_sparse_align_workspace_bytes(const dsdtm_batch_desc* batch);
 int dsdtm_reserve(dsdtm_ctx* ctx, size_t workspace_bytes);
 

@@ -631,6 +631,17 @@ def test_team_kernel_over_several_compute_units(gpu_ctx, oracle):
         To, no, _ = oracle.sparse_align(sub, L, 0, 10)
         H.assert_pose_close(T3[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"ragged pair {i}")
         assert n3[i] == no
+    # two team launches in flight on two streams of one context (each has its own exchange buffers)
+    st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    t2, b2 = _device_batch(torch, dev, scenes[::-1], L, W, Hh)
+    b.n_features = None
+    for tt, sc_ in ((t, scenes), (t2, scenes[::-1])):
+        tt["Tc"].copy_(torch.from_numpy(np.stack([s_.T_cur_w_seed.reshape(12) for s_ in sc_])).to(dev))
+    torch.cuda.synchronize()
+    for bb, s_ in ((b, st[0]), (b2, st[1])):
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(bb), C.byref(cam), C.byref(prm), s_.cuda_stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(t["Tc"].cpu().numpy(), T1) and np.array_equal(t2["Tc"].cpu().numpy(), T1[::-1])
     # 20 pairs still run as teams (24 x 4 workgroups), 60 pairs go to the workspace kernel: same answers
     for P in (20, 60):
         many = [scenes[i % 3] for i in range(P)]
