@@ -531,14 +531,17 @@ def test_device_resident_frames_track_a_sequence(gpu_ctx, oracle):
     df.close()
 
 
-def test_batch_launch_is_graph_capturable(gpu_ctx, oracle):
-    """The device entry point only enqueues (a memset node + one kernel): it can be captured into a
-    hipGraph and replayed — no allocation, no synchronisation in the launch path."""
+@pytest.mark.parametrize("N,P", [(200, 5), (600, 3)])
+def test_batch_launch_is_graph_capturable(gpu_ctx, oracle, N, P):
+    """The device entry point only enqueues (memset nodes + one kernel): it can be captured into a
+    hipGraph and replayed — no allocation, no synchronisation in the launch path. 200 features: the
+    register kernel; 600 features on 3 pairs: teams of 3 compute units (their exchange buffers are
+    zeroed by a memset node of the graph)."""
     import ctypes as C
     import torch
     from dsdtm_amd import capi
     dev = torch.device("cuda", 0)
-    W, Hh, L, N, P = 320, 240, 3, 200, 5
+    W, Hh, L = 320, 240, 3
     scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=700 + i, margin=12) for i in range(P)]
     ws, hs, st, offs, nbytes = capi.pyramid_layout(W, Hh, L)
     pitch = (nbytes + 255) // 256 * 256
