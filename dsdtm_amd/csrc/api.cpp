@@ -832,14 +832,25 @@ extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* 
     memcpy(h + o_rl, ref_level, M * 4);
     memcpy(h + o_rp, ref_px, M * 8);
     memcpy(h + o_px, px_xy, M * 16);
-    HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // Every input is read once per candidate and every result written once: the two kernels take them straight
+    // from / to the pinned block (no copy operations around the launches); only the warped patches, which the
+    // second kernel re-reads at every iteration, live in device memory.
+    static const bool zero_copy = getenv("DSDTM_NO_ZERO_COPY") == nullptr;
+    uint8_t* io = d;
+    if (zero_copy) {
+        void* hd = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&hd, ctx->h_pinned, 0));
+        io = (uint8_t*)hd;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     WarpKernelArgs a;
     memset(&a, 0, sizeof a);
-    a.kf_ptrs = (const uint8_t* const*)(d + o_ptr); a.T_kf_w = (const double*)(d + o_tk);
-    a.cand_kf = (const int32_t*)(d + o_ck); a.ref_px = (const float*)(d + o_rp);
-    a.ref_level = (const int32_t*)(d + o_rl); a.ref_bearing = (const double*)(d + o_rb);
-    a.p_world = (const double*)(d + o_pw); a.affine = (double*)(d + o_af);
-    a.search_level = (int32_t*)(d + o_sl); a.patch_border = d + o_pb; a.patch = d + o_pp;
+    a.kf_ptrs = (const uint8_t* const*)(io + o_ptr); a.T_kf_w = (const double*)(io + o_tk);
+    a.cand_kf = (const int32_t*)(io + o_ck); a.ref_px = (const float*)(io + o_rp);
+    a.ref_level = (const int32_t*)(io + o_rl); a.ref_bearing = (const double*)(io + o_rb);
+    a.p_world = (const double*)(io + o_pw); a.affine = (double*)(d + o_af);
+    a.search_level = (int32_t*)(io + o_sl); a.patch_border = d + o_pb; a.patch = d + o_pp;
     memcpy(a.T_cur_w, T_cur_w, 96);
     a.m = m; a.n_kf = n_kf; a.max_search_level = max_search_level; a.levels = p0.levels;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy;
@@ -847,12 +858,12 @@ extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* 
     HIP_TRY(ctx, warp_launch(a, ctx->stream));
     A2DKernelArgs b;
     memset(&b, 0, sizeof b);
-    b.cur_pyr = cur->d; b.patch_border = d + o_pb; b.patch = d + o_pp; b.level = (const int32_t*)(d + o_sl);
-    b.px_xy = (double*)(d + o_px); b.converged = d + o_cv; b.m = m; b.max_iters = max_iters; b.levels = p0.levels;
+    b.cur_pyr = cur->d; b.patch_border = d + o_pb; b.patch = d + o_pp; b.level = (const int32_t*)(io + o_sl);
+    b.px_xy = (double*)(io + o_px); b.converged = io + o_cv; b.m = m; b.max_iters = max_iters; b.levels = p0.levels;
     b.px_level0 = 1;
     for (int l = 0; l < p0.levels; ++l) b.lv[l] = a.lv[l];
     HIP_TRY(ctx, align2d_launch(b, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(h + o_px, d + o_px, out_end - o_px, hipMemcpyDeviceToHost, ctx->stream));
+    if (!zero_copy) HIP_TRY(ctx, hipMemcpyAsync(h + o_px, d + o_px, out_end - o_px, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(px_xy, h + o_px, M * 16);
     memcpy(search_level, h + o_sl, M * 4);
