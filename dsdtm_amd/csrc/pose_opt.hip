@@ -122,18 +122,20 @@ __device__ __forceinline__ bool block_residual(const Frame& f, int i, const SE3d
 // reads what it needs, when it needs it; the 27 totals are not live in registers across the next
 // evaluation). ok = false when anything was not finite.
 #define PO_PART_STRIDE 29
-#ifndef PO_REDUCE_LDS
-#define PO_REDUCE_LDS 1
-#endif
-__device__ void evaluate(const Frame& f, int lane, const SE3d& T /* pose_of(x) */, double& cost, double* hg, double* part,
-                         bool& ok) {
+// NW waves per frame: one for batches (the wave-uniform solver part is executed once per frame), four for a
+// few frames (the live tracker's single frame: the features spread over 256 lanes, every wave repeats the
+// solver part on the same totals and so takes the same decisions — no broadcast).
+template <int NW>
+__device__ void evaluate(const Frame& f, int tid, const SE3d& T /* pose_of(x) */, double& cost, double* hg, double* part,
+                         double* red, bool& ok) {
+    const int lane = tid & 63, wave = tid >> 6;
     double c = 0.0, h[21], gg[6];
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < 21; ++k) h[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) gg[k] = 0.0;
-    for (int i = lane; i < f.n; i += 64) {
+    for (int i = tid; i < f.n; i += NW * 64) {
         double r0, r1, px, py, pz;
         if (!block_residual(f, i, T, r0, r1, px, py, pz)) continue;
         const double z_inv = 1.0 / pz;
@@ -158,52 +160,41 @@ __device__ void evaluate(const Frame& f, int lane, const SE3d& T /* pose_of(x) *
             for (int b = a; b < 6; ++b) { h[q] += J0[a] * J0[b] + J1[a] * J1[b]; ++q; }
         }
     }
-#if PO_REDUCE_LDS
     // Cross-lane totals through LDS: every lane parks its 28 partials (row stride 29 doubles: the column
-    // reads below are conflict-free), then lane k (k < 28) adds column k over lanes 0..31 and lane 32 + k
-    // over lanes 32..63 in lane order, and lane k folds the two halves. The order is fixed, so runs repeat
-    // bit for bit.
-    double* row = part + lane * PO_PART_STRIDE;
+    // reads below are conflict-free); in every wave lane k (k < 28) adds column k over the wave's lanes 0..31
+    // and lane 32 + k over its lanes 32..63, in lane order; thread k < 28 then folds the 2 NW half sums in
+    // fixed order. The order is fixed, so runs repeat bit for bit.
+    double* row = part + tid * PO_PART_STRIDE;
 #pragma unroll
     for (int k = 0; k < 21; ++k) row[k] = h[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) row[21 + k] = gg[k];
     row[27] = c;
-    __syncthreads();                                        // one wave per workgroup: orders LDS writes and reads
+    const unsigned long long bad_wave = __ballot(bad);
+    __syncthreads();                                        // orders LDS writes and reads
     const int col = lane & 31, half = lane >> 5;
-    double acc = 0.0;
     if (col < 28) {
-        const double* src = part + (half * 32) * PO_PART_STRIDE + col;
+        double acc = 0.0;
+        const double* src = part + (wave * 64 + half * 32) * PO_PART_STRIDE + col;
 #pragma unroll 8
         for (int l = 0; l < 32; ++l) acc += src[l * PO_PART_STRIDE];
+        red[(wave * 2 + half) * 32 + col] = acc;
     }
+    if (lane == 0) red[(2 * NW) * 32 + wave] = bad_wave ? 1.0 : 0.0;
     __syncthreads();
-    if (half == 1 && col < 28) part[col] = acc;             // row 0 is free again: hand the upper half over
-    __syncthreads();
-    if (half == 0 && col < 28) hg[col] = acc + part[col];   // hg[0..20] H, hg[21..26] g, hg[27] cost
-    __syncthreads();
-#else
-    // Cross-lane totals: one DPP butterfly per value (fixed order: runs repeat bit for bit), stored by the
-    // lane it ends in
-    (void)part;
+    if (tid < 28) {
+        double acc = red[tid];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) {
-        const double v = wave_sum_to_lane63(h[k]);
-        if (lane == 63) hg[k] = v;
+        for (int k = 1; k < 2 * NW; ++k) acc += red[k * 32 + tid];
+        hg[tid] = acc;                                      // hg[0..20] H, hg[21..26] g, hg[27] cost
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double v = wave_sum_to_lane63(gg[k]);
-        if (lane == 63) hg[21 + k] = v;
-    }
-    {
-        const double v = wave_sum_to_lane63(c);
-        if (lane == 63) hg[27] = v;
-    }
-    __syncthreads();                                        // one wave per workgroup: orders the LDS writes
-#endif
+    __syncthreads();
     cost = hg[27];
-    ok = __ballot(bad) == 0ull && isfinite(cost);
+    bool any_bad = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) any_bad = any_bad || red[(2 * NW) * 32 + w] != 0.0;
+    ok = !any_bad && isfinite(cost);
+    __syncthreads();                                        // red / part are free again
 }
 
 #define PO_U(i, j) ((i) * 6 - ((i) * ((i) - 1)) / 2 + ((j) - (i)))   /* packed upper index, i <= j */
@@ -275,11 +266,13 @@ __device__ __forceinline__ double gradient_max_norm(const SE3d& Tx, const double
 #ifndef PO_WAVES_PER_EU
 #define PO_WAVES_PER_EU 2
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PO_WAVES_PER_EU, PO_WAVES_PER_EU)))
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? PO_WAVES_PER_EU : 1, NW == 1 ? PO_WAVES_PER_EU : 2)))
 void pose_opt_kernel(PoseOptArgs a) {
     const int frame = blockIdx.x;
     if (frame >= a.n_frames) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const size_t base = (size_t)frame * a.max_features;
     Frame f;
     f.bearing = a.bearing + base * 3;
@@ -306,13 +299,14 @@ void pose_opt_kernel(PoseOptArgs a) {
     int termination = DSDTM_PO_MAX_ITERATIONS, iterations = 0, successful = 0;
     double x_cost = 0.0, initial_cost = 0.0;
     __shared__ double s_hg[2][28];     // H (21), g (6), cost of the accepted point [cur] and of the candidate [cur ^ 1]
-    __shared__ double s_part[PO_REDUCE_LDS ? 64 * PO_PART_STRIDE : 1];   // per-lane partials of one evaluation
+    __shared__ double s_part[NW * 64 * PO_PART_STRIDE];   // per-lane partials of one evaluation
+    __shared__ double s_red[(2 * NW + 1) * 32];           // half-wave sums, then the waves' not-finite flags
     int cur = 0;
     bool ok;
     if (n_blocks == 0) {
         termination = DSDTM_PO_NO_RESIDUALS;
     } else {
-        evaluate(f, lane, Tx, x_cost, s_hg[0], s_part, ok);
+        evaluate<NW>(f, tid, Tx, x_cost, s_hg[0], s_part, s_red, ok);
         if (!ok) {
             termination = DSDTM_PO_EVALUATION_FAILED;
             x_cost = 0.0;
@@ -380,7 +374,7 @@ void pose_opt_kernel(PoseOptArgs a) {
                 pose_plus(Tx, delta, cand);
                 bool cand_ok = finite6(cand);
                 const SE3d Tc = pose_of(cand);
-                if (cand_ok) evaluate(f, lane, Tc, cand_cost, s_hg[cur ^ 1], s_part, cand_ok);
+                if (cand_ok) evaluate<NW>(f, tid, Tc, cand_cost, s_hg[cur ^ 1], s_part, s_red, cand_ok);
                 if (!cand_ok) cand_cost = DBL_MAX;
                 double diff[6];
 #pragma unroll
@@ -417,6 +411,7 @@ void pose_opt_kernel(PoseOptArgs a) {
     const SE3d Tf = Tx;
     double R[9];
     quat_to_matrix(Tf, R);
+    if (tid >= 64) return;                                  // results: the first wave (all waves hold the same state)
     if (lane == 0) {
         Tio[0] = R[0]; Tio[1] = R[1]; Tio[2] = R[2];  Tio[3] = Tf.tx;
         Tio[4] = R[3]; Tio[5] = R[4]; Tio[6] = R[5];  Tio[7] = Tf.ty;
@@ -446,7 +441,12 @@ void pose_opt_kernel(PoseOptArgs a) {
 
 hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream) {
     if (args.n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pose_opt_kernel, dim3((unsigned)args.n_frames), dim3(64), 0, stream, args);
+    // a few frames (the live tracker refines one): latency counts, four waves share a frame's features;
+    // batches: one wave per frame, the solver part is not repeated
+    if (args.n_frames <= 32 && args.max_features > 64)
+        hipLaunchKernelGGL(pose_opt_kernel<4>, dim3((unsigned)args.n_frames), dim3(256), 0, stream, args);
+    else
+        hipLaunchKernelGGL(pose_opt_kernel<1>, dim3((unsigned)args.n_frames), dim3(64), 0, stream, args);
     return hipGetLastError();
 }
 
