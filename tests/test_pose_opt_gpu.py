@@ -90,13 +90,16 @@ def test_edge_cases(gpu_ctx, oracle):
         pose_optimization(gpu_ctx, P.bearing, P.p_world, lv, P.use, T12)
 
 
-def test_batch_on_the_device(gpu_ctx, oracle):
-    """n_frames independent problems in one launch (ragged feature counts), device pointers, own stream."""
+@pytest.mark.parametrize("F", [96, 8])
+def test_batch_on_the_device(gpu_ctx, oracle, F):
+    """n_frames independent problems in one launch (ragged feature counts), device pointers, own stream.
+    96 frames: one wavefront per frame; 8 frames: four wavefronts per frame (the few-frames shape)."""
     import torch
     dev = torch.device("cuda:0")
-    F, maxf = 96, 512
+    maxf = 512
     rng = np.random.default_rng(3)
-    probs = [synth.make_pose_problem(100 + k, n=int(rng.integers(1, maxf + 1)) if k else maxf, max_level=int(rng.integers(0, 5)))
+    probs = [synth.make_pose_problem(100 + k, n=(maxf if k == 0 else 3 if k == 1 else int(rng.integers(1, maxf + 1))),
+                                     max_level=int(rng.integers(0, 5)), unused_frac=(0.0 if k == 1 else 0.1))
              for k in range(F)]
     bearing = np.zeros((F, maxf, 3)); pw = np.zeros((F, maxf, 3)); level = np.zeros((F, maxf), np.int32)
     use = np.ones((F, maxf), np.uint8)        # garbage beyond n_features must not be read
