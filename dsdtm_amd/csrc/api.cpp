@@ -108,7 +108,8 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc((void**)&ctx->d_counter, 256) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_team, 8 * sparse_align_team_bytes(64)) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_team, 8 * sparse_align_team_bytes(64)) != hipSuccess ||
+        hipMemset(ctx->d_counter, 0, 256) != hipSuccess) {
         if (ctx->d_counter) (void)hipFree(ctx->d_counter);
         set_err(nullptr, "hipMalloc failed on device %d", device);
         (void)hipStreamDestroy(ctx->stream);
@@ -214,11 +215,10 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     a.pyr_pitch = b->pyr_pitch; a.n_pairs = b->n_pairs; a.max_features = b->max_features;
     a.max_level = prm->max_level; a.min_level = prm->min_level; a.max_iters = prm->max_iters; a.min_fts = prm->min_fts;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy; a.f = cam->f;
-    // the persistent kernels pull pair indices from this word: reset it on the launch stream
-    // (a memset node when the stream is being captured into a hipGraph)
+    // the persistent kernels pull pair indices from this word of a ring of 64; it is zero when a launch starts:
+    // zeroed with the context, and put back to zero by the launch's last claim (no memset per launch)
     a.pair_counter = ctx->d_counter + (ctx->launch_seq++ & 63u);
     a.timeout_out = g_timeout_out;
-    HIP_TRY(ctx, hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned), (hipStream_t)hip_stream));
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
         if (b->max_features > 320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
         a.workspace = (double*)g_stamp_out;
@@ -365,6 +365,7 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_flag) {
         (void)sparse_align_clear_timeout_flag();
+        (void)hipMemset(ctx->d_counter, 0, 256);      // a pair that was stopped may have left its counter behind
         set_err(ctx, "sparse-align kernel: intra-workgroup hand-over timed out");
         return DSDTM_ERR_HIP;
     }

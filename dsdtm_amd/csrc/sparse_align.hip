@@ -949,6 +949,14 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             return v;
         };
         auto claim_value = [&](int raw) -> int { return __builtin_amdgcn_readfirstlane(raw); };
+        // Every pair that is started issues exactly one claim, so the claim that returns n_pairs - 1 is the last
+        // one of this launch: its owner puts the counter back to zero for the launch that uses it next (the host
+        // needs no memset node per launch).
+        auto claim_taken = [&](int v) -> int {
+            if (lane == 0 && v - first_dynamic == a.n_pairs - 1)
+                __hip_atomic_store(a.pair_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return v;
+        };
         int pair = (int)blockIdx.x * PPW + slot;
         unsigned acks = 0;                                             // acknowledgements expected so far
         while (true) {
@@ -965,7 +973,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             if (!run) {
                 if (lane == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
                 pair_publish(s, ++published, lane);                    // B0 with "skip"
-                pair = claim_value(claim_issue());
+                pair = claim_taken(claim_value(claim_issue()));
                 continue;
             }
             const int next_raw = claim_issue();                        // latency hidden under this pair
@@ -1035,7 +1043,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 o[7] = t_sub[2];
                 ((unsigned long long*)a.workspace)[(size_t)a.n_pairs * 48 + pair] = t_refresh;
             }
-            pair = claim_value(next_raw);
+            pair = claim_taken(claim_value(next_raw));
         }
         return;
     }
