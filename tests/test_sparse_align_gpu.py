@@ -533,10 +533,10 @@ def test_device_resident_frames_track_a_sequence(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("N,P", [(200, 5), (600, 3)])
 def test_batch_launch_is_graph_capturable(gpu_ctx, oracle, N, P):
-    """The device entry point only enqueues (memset nodes + one kernel): it can be captured into a
-    hipGraph and replayed — no allocation, no synchronisation in the launch path. 200 features: the
-    register kernel; 600 features on 3 pairs: teams of 3 compute units (their exchange buffers are
-    zeroed by a memset node of the graph)."""
+    """The device entry point only enqueues (one kernel; for teams a memset node before it): it can be
+    captured into a hipGraph and replayed — no allocation, no synchronisation in the launch path, and the
+    pair counter is back at zero after every replay. 200 features: the register kernel; 600 features on 3
+    pairs: teams of 3 compute units (their exchange buffers are zeroed by a memset node of the graph)."""
     import ctypes as C
     import torch
     from dsdtm_amd import capi
