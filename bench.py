@@ -242,19 +242,27 @@ def main():
     if ws_bytes:
         ctx.check(ctx.lib.dsdtm_reserve(ctx.handle, ws_bytes))
 
-    def step():
-        # re-seed the in/out pose (Tracking seeds cur.pose = last.pose, src/Tracking.cpp:201), then one launch
-        with torch.cuda.stream(stream):
-            d["T_cur_w"].copy_(d["T_seed"], non_blocking=True)
-        ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(desc), C.byref(cam_struct), C.byref(prm),
+    # The pose argument is in/out (seed in, result out: Tracking seeds cur.pose = last.pose, src/Tracking.cpp:201).
+    # Every step gets its own copy of the seed poses, resident in HBM before the timed region like the rest
+    # of the input, so that a step is exactly one launch of the hot path (no re-seeding copy between steps).
+    n_slots = args.warmup + args.steps
+    d["T_steps"] = d["T_seed"].unsqueeze(0).repeat(n_slots, 1, 1).contiguous()
+    descs = []
+    for k in range(n_slots):
+        dk = capi.BatchDesc.from_buffer_copy(bytes(desc))
+        dk.T_cur_w = d["T_steps"][k].data_ptr()
+        descs.append(dk)
+
+    def step(k):
+        ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(descs[k]), C.byref(cam_struct), C.byref(prm),
                                                           stream.cuda_stream))
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     stream.synchronize()
     torch.cuda.synchronize()
 
@@ -263,11 +271,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        with torch.cuda.stream(stream):
-            d["T_cur_w"].copy_(d["T_seed"], non_blocking=True)
         ev[k][0].record(stream)           # HIP events on the stream the kernel is launched on
-        ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(desc), C.byref(cam_struct), C.byref(prm),
-                                                          stream.cuda_stream))
+        step(args.warmup + k)
         ev[k][1].record(stream)
     stream.synchronize()
     torch.cuda.synchronize()
@@ -275,6 +280,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    d["T_cur_w"] = d["T_steps"][n_slots - 1]          # the last step's results are the ones checked below
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
     if rank == 0:
