@@ -123,7 +123,7 @@ def declare_signatures(lib, prefix: str, with_ctx: bool):
 # every symbol include/dsdtm_amd.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "dsdtm_create", "dsdtm_destroy", "dsdtm_last_error", "dsdtm_version", "dsdtm_device_count",
-    "dsdtm_sparse_align", "dsdtm_sparse_align_batch_device", "dsdtm_sparse_align_workspace_bytes",
+    "dsdtm_sparse_align", "dsdtm_sparse_align_batch_device", "dsdtm_sparse_align_check", "dsdtm_sparse_align_workspace_bytes",
     "dsdtm_reserve", "dsdtm_align2d_batch", "dsdtm_align2d_batch_device",
     "dsdtm_pyrdown_batch_device", "dsdtm_pyrdown", "dsdtm_warp_patches",
     "dsdtm_frame_create", "dsdtm_frame_create_from_image", "dsdtm_frame_destroy", "dsdtm_sparse_align_frames",
@@ -194,6 +194,8 @@ def load():
     lib.dsdtm_sparse_align_batch_device.restype = C.c_int
     lib.dsdtm_sparse_align_batch_device.argtypes = [C.c_void_p, C.POINTER(BatchDesc), C.POINTER(Camera),
                                                     C.POINTER(AlignParams), C.c_void_p]
+    lib.dsdtm_sparse_align_check.restype = C.c_int
+    lib.dsdtm_sparse_align_check.argtypes = [C.c_void_p, C.c_void_p]
     lib.dsdtm_sparse_align_workspace_bytes.restype = C.c_size_t
     lib.dsdtm_sparse_align_workspace_bytes.argtypes = [C.POINTER(BatchDesc)]
     lib.dsdtm_reserve.restype = C.c_int

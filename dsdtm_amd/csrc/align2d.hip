@@ -2,13 +2,22 @@
 //
 // Replaces reference src/Feature_alignment.cpp:318-417. lane = one pixel of the 8x8 patch:
 // the lane owns its reference intensity and the gradients derived from the 10x10 bordered
-// patch (:330-343), samples the current image bilinearly each iteration (:381-392) and the three
-// Jres sums are reduced across the wavefront with DPP (no LDS). The 3x3 inverse, the update
-// and the convergence test (:345, :395-411) are evaluated redundantly by all lanes.
+// patch (:330-343) and samples the current image bilinearly each iteration (:381-392). The 3x3
+// inverse, the update and the convergence test (:345, :395-411) are evaluated redundantly by all lanes.
 // float32 throughout, as the reference (Matrix3f, float u,v) — including its float/double mixing
 // in the bilinear weights (:373-376).
+//
+// The three Jres sums (:389-391) are float sums over the 64 pixels in raster order, and the result
+// feeds a threshold (du^2 + dv^2 < 0.03^2, :400) that decides "matched or not" for SearchLocalPoints:
+// a differently associated sum can flip that bit for a candidate sitting on the threshold. So the
+// sums run in the REFERENCE'S ORDER: every lane parks its three products in LDS and lanes 0..2 each
+// fold one of the sums sequentially (64 dependent float subtractions, the three chains side by side
+// on three lanes) — pixels and flags are bit-identical to the CPU restatement. (H needs no such care:
+// its entries are sums of multiples of 1/4 below 2^22, exact in float in any order.) The DPP tree
+// version is kept as a template parameter for the cost comparison (DSDTM_A2D_TREE=1, tools/kernels.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -30,12 +39,39 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Jres[k] -= res * J[k] over the pixels q = 0..63 in order, starting from 0 (:389-391): lane k < 3 folds chain k.
+// `prod` is this wave's 3 x 64 floats of LDS; all lanes return the three sums.
+__device__ __forceinline__ void jres_in_reference_order(float* prod, int lane, float p0, float p1, float p2,
+                                                        float& j0, float& j1, float& j2) {
+#pragma clang fp contract(off)
+    prod[lane] = p0; prod[64 + lane] = p1; prod[128 + lane] = p2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float acc = 0.0f;
+    if (lane < 3) {
+        const float4* src = (const float4*)(prod + 64 * lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = src[q];
+            acc = acc - v.x; acc = acc - v.y; acc = acc - v.z; acc = acc - v.w;
+        }
+    }
+    j0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+    j1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 1));
+    j2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 2));
+    __builtin_amdgcn_wave_barrier();      // the next iteration's stores come after every lane's loads
+}
+
+template <bool TREE>
 __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
     // no FMA contraction: the reference build has none (CMakeLists.txt:5-8, SSE only) and the
     // 0.03^2 convergence threshold (:400) is compared on float values
 #pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float s_prod[4][192];
     const int lane = threadIdx.x & 63;
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform
+    float* const prod = s_prod[threadIdx.x >> 6];
     if (f >= a.m) return;
     const int lvl = a.level[f];
     if (lvl < 0 || lvl >= a.levels) {                    // invalid level: report "not converged"
@@ -101,9 +137,9 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
         const float p11 = (o + lg.stride + 1 < img_size) ? (float)img[o + lg.stride + 1] : 0.0f;
         const float search = wTL * p00 + wTR * p01 + wBL * p10 + wBR * p11;  // :386
         const float res = search - ref + mean_diff;                          // :387
-        const float j0 = -wave_sum_f32(res * dx);                            // :389-391
-        const float j1 = -wave_sum_f32(res * dy);
-        const float j2 = -wave_sum_f32(res);
+        float j0, j1, j2;                                                    // :389-391
+        if (TREE) { j0 = -wave_sum_f32(res * dx); j1 = -wave_sum_f32(res * dy); j2 = -wave_sum_f32(res); }
+        else jres_in_reference_order(prod, lane, res * dx, res * dy, res, j0, j1, j2);
         const float up0 = (i00 * j0 + i01 * j1) + i02 * j2;                  // :395
         const float up1 = (i10 * j0 + i11 * j1) + i12 * j2;
         const float up2 = (i20 * j0 + i21 * j1) + i22 * j2;
@@ -121,7 +157,9 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
 
 hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream) {
     if (args.m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(align2d_kernel, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
+    // DSDTM_A2D_TREE=1 (diagnostic, cost comparison only): DPP tree sums instead of the reference's order
+    if (getenv("DSDTM_A2D_TREE")) hipLaunchKernelGGL(align2d_kernel<true>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(align2d_kernel<false>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -29,13 +29,26 @@ struct dsdtm_ctx {
     // workspace for the generic sparse-align kernel
     void* d_ws = nullptr;
     size_t ws_cap = 0;
-    // pair counters of the persistent sparse-align kernel: a ring of 64 words, one per launch in flight
-    // (each zeroed by a memset node on the launch stream right before its kernel)
+    // Pair counters of the persistent sparse-align kernel (a launch's slots pull pair indices from one word; the
+    // word is zero when a launch starts and the launch's last claim puts it back to zero). A word must never be
+    // shared by two launches that can run at the same time, so:
+    //  * every stream that launches through this context owns a ring of COUNTERS_PER_STREAM words (a stream runs
+    //    its launches in order, so the previous user of a word has finished when the next one starts);
+    //  * a launch captured into a hipGraph gets a word of its own from the graph pool, for the life of the
+    //    context, and a memset node in front of it (a hipGraphExec never overlaps itself).
     unsigned* d_counter = nullptr;
-    // exchange buffers of the team kernel: a ring of 8 launches x 64 pairs (allocated with the context, so that
-    // launches on several streams and launches captured into a hipGraph need nothing else)
+    struct StreamRing { hipStream_t stream; unsigned seq; bool used; };
+    static constexpr int MAX_STREAMS = 16, COUNTERS_PER_STREAM = 8, GRAPH_COUNTERS = 256;
+    StreamRing rings[MAX_STREAMS] = {};
+    int graph_counters_used = 0;
+    // Exchange buffers of the team kernel: a ring of 8 launches x 64 pairs. Team launches of one context are
+    // totally ordered (a launch on another stream first waits for the previous team launch's event), because the
+    // members of a team spin on each other and must all be resident at once.
     uint8_t* d_team = nullptr;
-    unsigned launch_seq = 0;
+    unsigned team_seq = 0;
+    hipEvent_t team_event = nullptr;      // recorded behind the last team launch that ran on a caller's stream
+    hipStream_t team_last_stream = nullptr;
+    bool team_any = false;
     unsigned* d_timeout_flag = nullptr;   // device address of the kernel's hand-over timeout flag
     int num_cus = 256;
 };
@@ -107,9 +120,11 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
         return DSDTM_ERR_HIP;
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc((void**)&ctx->d_counter, 256) != hipSuccess ||
+    const size_t counter_bytes = sizeof(unsigned) * (dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + dsdtm_ctx::GRAPH_COUNTERS);
+    if (hipMalloc((void**)&ctx->d_counter, counter_bytes) != hipSuccess ||
         hipMalloc((void**)&ctx->d_team, 8 * sparse_align_team_bytes(64)) != hipSuccess ||
-        hipMemset(ctx->d_counter, 0, 256) != hipSuccess) {
+        hipMemset(ctx->d_counter, 0, counter_bytes) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->team_event, hipEventDisableTiming) != hipSuccess) {
         if (ctx->d_counter) (void)hipFree(ctx->d_counter);
         set_err(nullptr, "hipMalloc failed on device %d", device);
         (void)hipStreamDestroy(ctx->stream);
@@ -129,6 +144,7 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->d_team) (void)hipFree(ctx->d_team);
+    if (ctx->team_event) (void)hipEventDestroy(ctx->team_event);
     delete ctx;
 }
 
@@ -215,32 +231,66 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     a.pyr_pitch = b->pyr_pitch; a.n_pairs = b->n_pairs; a.max_features = b->max_features;
     a.max_level = prm->max_level; a.min_level = prm->min_level; a.max_iters = prm->max_iters; a.min_fts = prm->min_fts;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy; a.f = cam->f;
-    // the persistent kernels pull pair indices from this word of a ring of 64; it is zero when a launch starts:
-    // zeroed with the context, and put back to zero by the launch's last claim (no memset per launch)
-    a.pair_counter = ctx->d_counter + (ctx->launch_seq++ & 63u);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    // the word the launch's persistent slots pull pair indices from (see dsdtm_ctx::d_counter)
+    if (capturing) {
+        if (ctx->graph_counters_used >= dsdtm_ctx::GRAPH_COUNTERS) {
+            set_err(ctx, "more than %d launches captured into hipGraphs through one context: create another context",
+                    dsdtm_ctx::GRAPH_COUNTERS);
+            return DSDTM_ERR_INVALID;
+        }
+        a.pair_counter = ctx->d_counter + dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + ctx->graph_counters_used++;
+        HIP_TRY(ctx, hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned), stream));   // memset node: replays heal themselves
+    } else {
+        int ri = -1;
+        for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
+            if (ctx->rings[i].used && ctx->rings[i].stream == stream) ri = i;
+        for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
+            if (!ctx->rings[i].used) { ctx->rings[i].used = true; ctx->rings[i].stream = stream; ctx->rings[i].seq = 0; ri = i; }
+        if (ri < 0) {
+            set_err(ctx, "more than %d streams launch through one context: use one context per group of streams", dsdtm_ctx::MAX_STREAMS);
+            return DSDTM_ERR_INVALID;
+        }
+        a.pair_counter = ctx->d_counter + ri * dsdtm_ctx::COUNTERS_PER_STREAM + (ctx->rings[ri].seq++ % dsdtm_ctx::COUNTERS_PER_STREAM);
+    }
     a.timeout_out = g_timeout_out;
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
         if (b->max_features > 320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
         a.workspace = (double*)g_stamp_out;
-        HIP_TRY(ctx, sparse_align_launch_stamps(a, ctx->num_cus, (hipStream_t)hip_stream));
+        HIP_TRY(ctx, sparse_align_launch_stamps(a, ctx->num_cus, stream));
         return DSDTM_OK;
     }
-    // few pairs of more than 448 features: one pair over K compute units; their exchange buffers come from the
-    // context's ring (one slot per launch in flight) and are zeroed on the stream
-    if (const int k = (b->n_pairs <= 64 && getenv("DSDTM_NO_TEAM") == nullptr) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0) {
-        uint8_t* slot = ctx->d_team + (size_t)(ctx->launch_seq & 7u) * sparse_align_team_bytes(64);
+    // Few pairs of more than 448 features: one pair over K compute units. The members of a team spin on each
+    // other, so all of a launch's workgroups must be resident together: sparse_align_team_size admits a launch
+    // only when it fills at most half the CUs, and the team launches of a context are totally ordered — one on
+    // another stream first waits for the previous one's event — so two of them never compete for CUs (kernels
+    // of OTHER kinds on other streams can still delay a member: such a wait ends when their workgroups drain; a
+    // wait that does not end raises the timeout flag, see dsdtm_sparse_align_check). Not used while capturing
+    // (a graph replay could not be ordered against live team launches): those shapes take the one-CU kernels.
+    const bool no_team = getenv("DSDTM_NO_TEAM") != nullptr;      // diagnostic switch, read per call (tests toggle it)
+    if (const int k = (b->n_pairs <= 64 && !no_team && !capturing) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0) {
+        if (ctx->team_any && ctx->team_last_stream != stream) {
+            // the context's own stream is alive as long as the context: its event is recorded on demand;
+            // launches on a caller's stream left theirs behind (that stream may be gone by now)
+            if (ctx->team_last_stream == ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->team_event, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->team_event, 0));
+        }
+        uint8_t* slot = ctx->d_team + (size_t)(ctx->team_seq++ & 7u) * sparse_align_team_bytes(64);
         a.workspace = (double*)slot;
-        HIP_TRY(ctx, hipMemsetAsync(slot, 0, sparse_align_team_bytes(b->n_pairs), (hipStream_t)hip_stream));
-        HIP_TRY(ctx, sparse_align_launch_team(a, k, (hipStream_t)hip_stream));
+        HIP_TRY(ctx, hipMemsetAsync(slot, 0, sparse_align_team_bytes(b->n_pairs), stream));
+        HIP_TRY(ctx, sparse_align_launch_team(a, k, stream));
+        if (stream != ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->team_event, stream));
+        ctx->team_any = true; ctx->team_last_stream = stream;
         return DSDTM_OK;
     }
     const SAVariant v = sparse_align_pick_variant(b->max_features);
     const size_t ws = sparse_align_workspace_bytes(b->n_pairs, b->max_features);
     if (ws) {
         if (ws > ctx->ws_cap) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hip_stream && hipStreamIsCapturing((hipStream_t)hip_stream, &cs) == hipSuccess &&
-                cs != hipStreamCaptureStatusNone) {
+            if (capturing) {
                 set_err(ctx, "workspace of %zu bytes needed: call dsdtm_reserve before capturing", ws);
                 return DSDTM_ERR_INVALID;
             }
@@ -248,7 +298,27 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         }
         a.workspace = (double*)ctx->d_ws;
     }
-    HIP_TRY(ctx, sparse_align_launch(a, v, ctx->num_cus, (hipStream_t)hip_stream));
+    HIP_TRY(ctx, sparse_align_launch(a, v, ctx->num_cus, stream));
+    return DSDTM_OK;
+}
+
+// Result check for callers of the asynchronous batch entry point: waits for `hip_stream`, then reads (and clears)
+// the kernels' hand-over timeout flag. DSDTM_OK, or DSDTM_ERR_HIP when a wait inside a kernel ran out — the
+// results of the launches since the last check are then not to be trusted. (The single-pair host entry points
+// do this themselves.)
+extern "C" int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
+    if (!ctx->d_timeout_flag) HIP_TRY(ctx, sparse_align_timeout_flag_address(&ctx->d_timeout_flag));
+    unsigned flag = 0;
+    HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_timeout_flag, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {
+        (void)sparse_align_clear_timeout_flag();
+        (void)hipMemset(ctx->d_counter, 0, sizeof(unsigned) * (dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + dsdtm_ctx::GRAPH_COUNTERS));
+        set_err(ctx, "sparse-align kernel: a hand-over wait timed out (results since the last check are invalid)");
+        return DSDTM_ERR_HIP;
+    }
     return DSDTM_OK;
 }
 
@@ -365,7 +435,7 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (*h_flag) {
         (void)sparse_align_clear_timeout_flag();
-        (void)hipMemset(ctx->d_counter, 0, 256);      // a pair that was stopped may have left its counter behind
+        (void)hipMemset(ctx->d_counter, 0, sizeof(unsigned) * (dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + dsdtm_ctx::GRAPH_COUNTERS));   // a pair that was stopped may have left its counter behind
         set_err(ctx, "sparse-align kernel: intra-workgroup hand-over timed out");
         return DSDTM_ERR_HIP;
     }
@@ -595,6 +665,7 @@ extern "C" int dsdtm_align2d_batch_device(dsdtm_ctx* ctx, const dsdtm_image_desc
     if (!cur || m < 0 || cur->levels <= 0 || cur->levels > DSDTM_MAX_LEVELS) { set_err(ctx, "bad image descriptor"); return DSDTM_ERR_INVALID; }
     if (m == 0) return DSDTM_OK;
     if (!cur->data || !patch_border || !patch || !level || !px_xy || !converged) { set_err(ctx, "NULL device pointer"); return DSDTM_ERR_INVALID; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     A2DKernelArgs a;
     memset(&a, 0, sizeof a);
     for (int l = 0; l < cur->levels; ++l) {
@@ -669,6 +740,7 @@ extern "C" int dsdtm_pyrdown_batch_device(dsdtm_ctx* ctx, uint8_t* pyr, size_t p
             set_err(ctx, "level %d is not ((w+1)/2,(h+1)/2) of level %d", l, l - 1); return DSDTM_ERR_INVALID;
         }
     }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int l = 1; l < levels; ++l)
         HIP_TRY(ctx, pyrdown_launch(pyr, pyr_pitch, n_images, width[l - 1], height[l - 1], stride[l - 1],
                                     level_offset[l - 1], stride[l], level_offset[l], (hipStream_t)hip_stream));

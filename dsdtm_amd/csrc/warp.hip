@@ -5,13 +5,110 @@
 // integer-division quirk W1 (`1/(1<<lvl)` is 0 for lvl>=1, :231) and the float->u8 truncation.
 // One 128-thread group per candidate: the 2x2 affine is evaluated in FP64 by every lane
 // (wave-uniform), lanes 0..99 each produce one sample of the 10x10 bordered patch.
+//
+// The outputs are BYTES (float sample positions truncated to u8) and a search level decided by a
+// threshold on det(A): a last-bit difference in the FP64 pose chain can flip either. So this file
+// evaluates the chain in the reference's own operation order — Sophus' SE3 from a rotation matrix,
+// inverse, product and action on a point (Eigen quaternion normalisation as coeffs / norm), no FMA
+// contraction, no reciprocals, IEEE division and sqrt — instead of the solver-oriented shortcuts of
+// device_math.h (series normalisation, contracted products), and its results are bit-identical to
+// the line-by-line CPU restatement (tests/test_align2d_gpu.py::test_warp_patches_match_oracle).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "device_math.h"
 #include "kernels.h"
 
+#pragma clang fp contract(off)      // file scope: every function below, helpers included
+
 namespace dsdtm {
+
+namespace {
+struct SE3x { double qw, qx, qy, qz, tx, ty, tz; };
+
+// Eigen QuaternionBase::normalize(): coeffs /= norm()
+__device__ __forceinline__ void xq_normalize(SE3x& T) {
+    const double n = sqrt(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz);
+    T.qw /= n; T.qx /= n; T.qy /= n; T.qz /= n;
+}
+// Eigen QuaternionBase::_transformVector: uv = 2 * vec x v; v + w*uv + vec x uv
+__device__ __forceinline__ void xq_rotate(const SE3x& T, double vx, double vy, double vz, double& ox, double& oy, double& oz) {
+    double ux = T.qy * vz - T.qz * vy;
+    double uy = T.qz * vx - T.qx * vz;
+    double uz = T.qx * vy - T.qy * vx;
+    ux += ux; uy += uy; uz += uz;
+    const double cx = T.qy * uz - T.qz * uy;
+    const double cy = T.qz * ux - T.qx * uz;
+    const double cz = T.qx * uy - T.qy * ux;
+    ox = vx + T.qw * ux + cx;
+    oy = vy + T.qw * uy + cy;
+    oz = vz + T.qw * uz + cz;
+}
+// SO3(Matrix3d) -> Eigen rotation-matrix-to-quaternion, then normalise; translation copied
+__device__ __forceinline__ SE3x xse3_from_rt(const double* __restrict__ T) {
+    const double m00 = T[0], m01 = T[1], m02 = T[2];
+    const double m10 = T[4], m11 = T[5], m12 = T[6];
+    const double m20 = T[8], m21 = T[9], m22 = T[10];
+    SE3x o;
+    double t = m00 + m11 + m22;
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        o.qw = 0.5 * t;
+        t = 0.5 / t;
+        o.qx = (m21 - m12) * t;
+        o.qy = (m02 - m20) * t;
+        o.qz = (m10 - m01) * t;
+    } else {
+        // i = argmax of the diagonal as Eigen picks it: i = 0; if (m11 > m00) i = 1; if (m22 > m[i][i]) i = 2
+        const bool i1 = m11 > m00;
+        const bool i2 = m22 > (i1 ? m11 : m00);
+        if (i2) {                                   // i = 2, j = 0, k = 1
+            t = sqrt(m22 - m00 - m11 + 1.0);
+            o.qz = 0.5 * t;
+            t = 0.5 / t;
+            o.qw = (m10 - m01) * t;
+            o.qx = (m02 + m20) * t;
+            o.qy = (m12 + m21) * t;
+        } else if (i1) {                            // i = 1, j = 2, k = 0
+            t = sqrt(m11 - m22 - m00 + 1.0);
+            o.qy = 0.5 * t;
+            t = 0.5 / t;
+            o.qw = (m02 - m20) * t;
+            o.qz = (m21 + m12) * t;
+            o.qx = (m01 + m10) * t;
+        } else {                                    // i = 0, j = 1, k = 2
+            t = sqrt(m00 - m11 - m22 + 1.0);
+            o.qx = 0.5 * t;
+            t = 0.5 / t;
+            o.qw = (m21 - m12) * t;
+            o.qy = (m10 + m01) * t;
+            o.qz = (m20 + m02) * t;
+        }
+    }
+    xq_normalize(o);
+    o.tx = T[3]; o.ty = T[7]; o.tz = T[11];
+    return o;
+}
+// SE3::inverse: so3_.inverse() (conjugate); translation = so3_inv * (translation * -1.)
+__device__ __forceinline__ SE3x xse3_inverse(const SE3x& a) {
+    SE3x r;
+    r.qw = a.qw; r.qx = -a.qx; r.qy = -a.qy; r.qz = -a.qz;
+    xq_rotate(r, a.tx * -1., a.ty * -1., a.tz * -1., r.tx, r.ty, r.tz);
+    return r;
+}
+// SE3::operator*=: translation += so3 * other.translation; quaternion product, normalize()
+__device__ __forceinline__ SE3x xse3_mul(const SE3x& a, const SE3x& b) {
+    SE3x r;
+    double rx, ry, rz;
+    xq_rotate(a, b.tx, b.ty, b.tz, rx, ry, rz);
+    r.tx = a.tx + rx; r.ty = a.ty + ry; r.tz = a.tz + rz;
+    r.qw = a.qw * b.qw - a.qx * b.qx - a.qy * b.qy - a.qz * b.qz;
+    r.qx = a.qw * b.qx + a.qx * b.qw + a.qy * b.qz - a.qz * b.qy;
+    r.qy = a.qw * b.qy + a.qy * b.qw + a.qz * b.qx - a.qx * b.qz;
+    r.qz = a.qw * b.qz + a.qz * b.qw + a.qx * b.qy - a.qy * b.qx;
+    xq_normalize(r);
+    return r;
+}
+}  // namespace
 
 __device__ __forceinline__ void cam2px(const WarpKernelArgs& a, double x, double y, double z, double& u, double& v) {
     u = (double)a.fx * x / z + (double)a.cx;          // src/Camera.cpp:167-171
@@ -19,7 +116,6 @@ __device__ __forceinline__ void cam2px(const WarpKernelArgs& a, double x, double
 }
 
 __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
-#pragma clang fp contract(off)
     const int c = blockIdx.x;
     if (c >= a.m) return;
     const int j = threadIdx.x;
@@ -32,9 +128,9 @@ __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
         return;
     }
     // ---- SolveAffineMatrix (:160-190) ----
-    const SE3d Tcur = se3_from_rt(a.T_cur_w);
-    const SE3d Tkf = se3_from_rt(a.T_kf_w + 12 * (size_t)k);
-    const SE3d Tki = se3_inverse(Tkf);
+    const SE3x Tcur = xse3_from_rt(a.T_cur_w);
+    const SE3x Tkf = xse3_from_rt(a.T_kf_w + 12 * (size_t)k);
+    const SE3x Tki = xse3_inverse(Tkf);
     const double* P = a.p_world + 3 * (size_t)c;
     const double* nb = a.ref_bearing + 3 * (size_t)c;
     const double d0 = Tki.tx - P[0], d1 = Tki.ty - P[1], d2 = Tki.tz - P[2];
@@ -56,11 +152,11 @@ __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
         U0 *= sU; U1 *= sU; U2 *= sU;
         V0 *= sV; V1 *= sV; V2 *= sV;
     }
-    const SE3d Tc2r = se3_mul(Tcur, Tki);                                              // :181
+    const SE3x Tc2r = xse3_mul(Tcur, Tki);                                             // :181
     double q0x, q0y, q0z, qUx, qUy, qUz, qVx, qVy, qVz;
-    quat_rotate(Tc2r, rp0, rp1, rp2, q0x, q0y, q0z); q0x += Tc2r.tx; q0y += Tc2r.ty; q0z += Tc2r.tz;
-    quat_rotate(Tc2r, U0, U1, U2, qUx, qUy, qUz);    qUx += Tc2r.tx; qUy += Tc2r.ty; qUz += Tc2r.tz;
-    quat_rotate(Tc2r, V0, V1, V2, qVx, qVy, qVz);    qVx += Tc2r.tx; qVy += Tc2r.ty; qVz += Tc2r.tz;
+    xq_rotate(Tc2r, rp0, rp1, rp2, q0x, q0y, q0z); q0x += Tc2r.tx; q0y += Tc2r.ty; q0z += Tc2r.tz;
+    xq_rotate(Tc2r, U0, U1, U2, qUx, qUy, qUz);    qUx += Tc2r.tx; qUy += Tc2r.ty; qUz += Tc2r.tz;
+    xq_rotate(Tc2r, V0, V1, V2, qVx, qVy, qVz);    qVx += Tc2r.tx; qVy += Tc2r.ty; qVz += Tc2r.tz;
     double c0u, c0v, cUu, cUv, cVu, cVv;
     cam2px(a, q0x, q0y, q0z, c0u, c0v);
     cam2px(a, qUx, qUy, qUz, cUu, cUv);

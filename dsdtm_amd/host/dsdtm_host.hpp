@@ -86,6 +86,18 @@ struct Frame {                                    // include/Frame.h (what the p
                      z = m[8] * P[0] + m[9] * P[1] + m[10] * P[2] + m[11];
         return {{(double)mCamera->mfx * x / z + (double)mCamera->mcx, (double)mCamera->mfy * y / z + (double)mCamera->mcy}};
     }
+    // Frame::Add_Feature (src/Frame.cpp:83-92): mNormal = Pixel2Camera(mpx, 1.0).normalized(). The cv::Point2f
+    // overload of Pixel2Camera (src/Camera.cpp:173-178) works in float; the Vector3d is normalised in double.
+    void Add_Feature(Feature f, bool tbNormal = true) {
+        if (tbNormal) {
+            const float one = 1.0f;
+            const double x = (double)((one * (f.mpx_x - mCamera->mcx)) / mCamera->mfx);
+            const double y = (double)((one * (f.mpx_y - mCamera->mcy)) / mCamera->mfy);
+            const double n = std::sqrt(x * x + y * y + 1.0 * 1.0);
+            f.mNormal = {{x / n, y / n, 1.0 / n}};
+        }
+        mvFeatures.push_back(f);
+    }
     // Frame::ComputeImagePyramid (src/Frame.cpp:74-81) on the device: level 0 crosses PCIe once, the
     // other levels are built by the library's bit-exact pyrDown and stay there for every Run.
     void ComputeImagePyramidOnDevice(int levels) {
@@ -139,7 +151,10 @@ public:
         std::vector<uint8_t> ini((size_t)n);
         for (int i = 0; i < n; ++i) {
             px[2 * i] = f[i].mpx_x; px[2 * i + 1] = f[i].mpx_y; ini[i] = f[i].mbInitial ? 1 : 0;
-            for (int k = 0; k < 3; ++k) { bearing[3 * i + k] = f[i].mNormal[k]; pw[3 * i + k] = f[i].mMptPose[k]; }
+            // :93 mvFeatures[i]->Mpt->Get_Pose(), snapshotted once per Run (features without a MapPoint object
+            // carry the position themselves)
+            const std::array<double, 3>& P = f[i].Mpt ? map_point_pose(f[i].Mpt) : f[i].mMptPose;
+            for (int k = 0; k < 3; ++k) { bearing[3 * i + k] = f[i].mNormal[k]; pw[3 * i + k] = P[k]; }
         }
         const Camera& c = *tRefFrame->mCamera;
         const dsdtm_camera cam{c.mfx, c.mfy, c.mcx, c.mcy, c.mf, c.mwidth, c.mheight};
@@ -166,6 +181,7 @@ public:
     dsdtm_align_stats last_stats{};
 
 protected:
+    static const std::array<double, 3>& map_point_pose(const MapPoint* mp);   // MapPoint is complete below
     int mnMaxLevel, mnMinLevel, mnMaxIterators, mnMinfts;
 };
 
@@ -183,6 +199,8 @@ struct MapPoint {                                 // include/MapPoint.h (what th
         if (mnFound <= 0) { mbBad = true; mObservations.clear(); }
     }
 };
+
+inline const std::array<double, 3>& Sprase_ImgAlign::map_point_pose(const MapPoint* mp) { return mp->Get_Pose(); }
 
 inline int cvRound(double v) { return (int)std::nearbyint(v); }      // OpenCV 2.4 cvRound: round half to even
 inline bool IsInImage(const Camera& c, double x, double y, int boundary, int level = 0) {   // src/Camera.cpp:187-193
@@ -324,8 +342,9 @@ public:
                 FillCircle(img_mask, cvRound(x), cvRound(y), Config::CellSize(), 0);  // :111
                 Match mt; mt.cell = (int)ci; mt.mp = mp; mt.px[0] = (float)x; mt.px[1] = (float)y; mt.level = sl[i];
                 matches.push_back(mt);
-                Feature f; f.mpx_x = mt.px[0]; f.mpx_y = mt.px[1]; f.mlevel = mt.level;   // :113-114 Add_Feature / Add_MapPoint
-                tFrame.mvFeatures.push_back(f);
+                Feature f; f.mpx_x = mt.px[0]; f.mpx_y = mt.px[1]; f.mlevel = mt.level;   // :108 new Feature(frame, px, level)
+                f.Mpt = mp; f.mbInitial = true; f.mMptPose = mp->Get_Pose();              // :109 SetPose (include/Feature.h:41-45)
+                tFrame.Add_Feature(f);                                                // :113 (bearing); :114 Add_MapPoint = f.Mpt
                 break;                                                                // :117 first success wins
             }
             if (matches.size() >= 200) break;                                         // :80

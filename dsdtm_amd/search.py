@@ -121,6 +121,36 @@ def get_closest_obs(mp: MapPoint, frame: Frame, keyframes):
     return best, mp.mObservations[best]
 
 
+def bearing_of_pixel(cam, px) -> np.ndarray:
+    """Frame::Add_Feature (src/Frame.cpp:83-92): mNormal = Camera::Pixel2Camera(mpx, 1.0).normalized(). The
+    cv::Point2f overload (src/Camera.cpp:173-178) evaluates depth*(x - mcx)/mfx in FLOAT (all operands are
+    float), the Eigen::Vector3d it returns is then normalised in double."""
+    px = np.asarray(px, np.float32).reshape(-1, 2)
+    one = np.float32(1.0)
+    x = (one * (px[:, 0] - np.float32(cam.cx))) / np.float32(cam.fx)
+    y = (one * (px[:, 1] - np.float32(cam.cy))) / np.float32(cam.fy)
+    v = np.stack([x.astype(np.float64), y.astype(np.float64), np.ones(len(px))], axis=1)
+    return v / np.sqrt(v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1] + v[:, 2] * v[:, 2])[:, None]
+
+
+def add_matched_features(frame: Frame, px, level, map_points):
+    """What ReprojectCell gives a matched candidate (src/Feature_alignment.cpp:108-114): a Feature at the
+    refined pixel and search level with Mpt = the map point and mbInitial = true, its bearing, and the map
+    point in the frame's mvMapPoints. p_world is the snapshot of Mpt->Get_Pose() that Sprase_ImgAlign::Run
+    reads when this frame is the reference frame (src/Sprase_ImageAlign.cpp:93)."""
+    new_px = np.asarray(px, np.float32).reshape(-1, 2)
+    n_old = frame.n_features
+    mpts = list(getattr(frame, "mvMapPoints", [None] * n_old))
+    assert len(mpts) == n_old
+    new = dict(px=new_px, level=np.asarray(level, np.int32), bearing=bearing_of_pixel(frame.mCamera, new_px),
+               p_world=np.array([mp.Get_Pose() for mp in map_points], np.float64).reshape(-1, 3),
+               initial=np.ones(len(new_px), np.uint8))
+    for k, v in new.items():
+        old = getattr(frame, k)
+        setattr(frame, k, np.concatenate([old, v]) if n_old else v)
+    frame.mvMapPoints = mpts + list(map_points)
+
+
 class LocalPointSearch(FA.Feature_Alignment):
     """Feature_Alignment(CameraPtr) with ResetGrid / ReprojectPoint / SearchLocalPoints."""
 
@@ -217,10 +247,10 @@ class LocalPointSearch(FA.Feature_Alignment):
                 break                                                        # :117 first success wins
             if n_matches >= 200:                                             # :80
                 break
-        # Frame::Add_Feature / Add_MapPoint (:113-114)
+        # new Feature(frame, px, level); SetPose(map point) => Mpt, mbInitial = true (include/Feature.h:41-45);
+        # Frame::Add_Feature (bearing, src/Frame.cpp:83-92) and Add_MapPoint (:113-114): the frame can now be
+        # refined by Optimizer::PoseOptimization and serve as the reference frame of the next Run
         if matches:
-            new_px = np.array([m[2] for m in matches], np.float32)
-            tFrame.px = np.concatenate([tFrame.px, new_px]) if tFrame.n_features else new_px
-            tFrame.level = np.concatenate([tFrame.level, np.array([m[3] for m in matches], np.int32)])
+            add_matched_features(tFrame, [m[2] for m in matches], [m[3] for m in matches], [m[1] for m in matches])
         self.last_stats = dict(candidates=len(cand), matched=n_matches)
         return matches

@@ -297,14 +297,27 @@ int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* batc
                                     const dsdtm_camera* cam, const dsdtm_align_params* params,
                                     void* hip_stream);
 
+/* Result check for callers of the asynchronous batch entry point: waits for `hip_stream`, then reads (and
+ * clears) the kernels' hand-over timeout flag. DSDTM_OK, or DSDTM_ERR_HIP when a bounded wait inside a kernel
+ * ran out (a workgroup waited for a partner that never became resident): the results of the launches since the
+ * last check are then not to be trusted. The reference has no counterpart (its path is one CPU thread); the
+ * single-pair host entry points above perform this check themselves. */
+int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream);
+
+/* Streams and hipGraphs. Launches of one context may be in flight on up to 16 different streams at once; a
+ * launch captured into a hipGraph owns a pair-counter word of the context for good (256 per context) and is
+ * preceded by a memset node, so graph replays need nothing from the host. Shapes that spread one pair over
+ * several compute units (few pairs of more than 448 features) are ordered against each other across streams by
+ * the library and are not used inside a capture (the single-CU kernels run instead). */
+
 /* Bytes of scratch HBM the batch call needs for `batch` (0 when the register-resident
  * kernel applies: max_features <= 704). The context grows its own workspace on demand OUTSIDE
  * stream capture; call dsdtm_reserve first when the launch is to be captured into a hipGraph.
  * The workspace belongs to the context: launches that use it (max_features > 704) must not be in
  * flight on two streams of one context at the same time — use one context per stream for those.
  * Few pairs of 449..4096 features (n_pairs <= 64 and roughly n_pairs * ceil(max_features / 256) <= 128) need
- * no workspace: each is spread over several compute units that exchange their partial sums through a ring
- * of context-owned buffers (up to 8 such launches in flight). */
+ * no workspace: each is spread over several compute units that exchange their partial sums through
+ * context-owned buffers; this function does not know the device and may over-estimate for those shapes. */
 size_t dsdtm_sparse_align_workspace_bytes(const dsdtm_batch_desc* batch);
 int dsdtm_reserve(dsdtm_ctx* ctx, size_t workspace_bytes);
 

@@ -22,15 +22,33 @@ class OracleSE3(C.Structure):
     _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3)]
 
 
+def _cpu_tag() -> str:
+    """Tag of the host CPU (model + ISA flags): a -march=native build is only loaded on the CPU it was made on."""
+    import hashlib
+    model, flags = "", ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and not model:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("flags") and not flags:
+                    flags = line.split(":", 1)[1].strip()
+                if model and flags:
+                    break
+    except OSError:
+        pass
+    return hashlib.sha1((model + "|" + flags).encode()).hexdigest()[:10]
+
+
 def build(native: bool = False):
-    subprocess.run(["make", "-s", "-C", _ORACLE_DIR] + (["native"] if native else []), check=True)
+    subprocess.run(["make", "-s", "-C", _ORACLE_DIR] + (["native", "NATIVE_TAG=" + _cpu_tag()] if native else []), check=True)
 
 
 def load(native: bool = False):
     key = "native" if native else "ref"
     if key in _LIBS:
         return _LIBS[key]
-    name = "liboracle_native.so" if native else "liboracle.so"
+    name = f"liboracle_native_{_cpu_tag()}.so" if native else "liboracle.so"
     path = os.path.join(_ORACLE_DIR, "_build", name)
     srcs = [os.path.join(_ORACLE_DIR, f) for f in ("dsdtm_oracle.c", "pose_opt_oracle.c", "dsdtm_oracle.h")]
     if not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):

@@ -1,0 +1,209 @@
+"""GPU parity at the FULL shape of every BASELINE.json config:
+  config 1  an RGB-D sequence through the C++ driver in the shape of Test/test_SpraseImg_alignment.cpp
+            (TUM data is not in the image: a generated RGB-D sequence stands in)
+  config 2  tests/test_sparse_align_gpu.py::test_config2_pose_matches_oracle
+  config 3  640x480, Tracking's (5, 0, 8), ~1000 patches, a stream of chained frames on device-resident frames
+  config 4  the per-GPU share: ONE launch over 1024 independent 640x480 pairs, every pair against the oracle
+  config 5  1280x960, 4 levels, 2000 patches: Run, then 2000 Align2D refinements on the same frame
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from dsdtm_amd import capi, synth
+from tests import helpers as H
+from tests.conftest import cached_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config4_share_1024_pairs_in_one_launch(gpu_ctx, oracle):
+    """BASELINE config 4's per-GPU share (8192 pairs / 8 GPUs): 1024 independent 640x480 pairs, 4 levels,
+    300 patches, cap 10, ONE launch of dsdtm_sparse_align_batch_device — every pose, tracked count,
+    iteration count and exit code against the CPU oracle on the same bytes; then the same launch on a second
+    stream while the first is still running (what bench.py --streams 2 does): bit-identical results."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    cam = synth.Camera.tum(640, 480)
+    d = bench.build_batch(torch, dev, gpu_ctx, cam, 1024, 640, 480, 4, 300, seed=0xD5D7, stream=stream)
+    cs = capi.camera_struct(cam)
+    prm = capi.AlignParams(4, 0, 10, 15)
+    d["T_cur_w"].copy_(d["T_seed"])
+    torch.cuda.synchronize()
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(d["desc"]), C.byref(cs), C.byref(prm), stream.cuda_stream))
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, stream.cuda_stream))
+    Tg = d["T_cur_w"].cpu().numpy().copy()
+    ntg = d["n_tracked"].cpu().numpy().copy()
+    stg = np.frombuffer(d["stats"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE).copy()
+    hb = bench.HostBatch(d, 1024)
+    hb.run(oracle.load(), cs, prm, bench.usable_cpus())
+    dl = np.array([synth.pose_error(Tg[i], hb.T[i]) for i in range(1024)])
+    assert dl[:, 0].max() <= H.TIGHT_RAD and dl[:, 1].max() <= H.TIGHT_M, dl.max(axis=0)
+    assert np.array_equal(ntg, hb.nt)
+    for k in ("iters", "n_ref", "n_vis", "exit_code"):
+        assert np.array_equal(stg[k], hb.st[k]), k
+    assert np.allclose(stg["chi2"], hb.st["chi2"], rtol=1e-9, atol=0, equal_nan=True)
+    err = np.array([synth.pose_error(Tg[i], d["T_true"][i]) for i in range(1024)])
+    assert np.median(err[:, 0]) < 5e-4 and np.median(err[:, 1]) < 2e-3      # and they are alignments, not no-ops
+    # two launches in flight on two streams (each stream has its own pair counters): same bits
+    T2 = d["T_seed"].clone()
+    d2 = capi.BatchDesc.from_buffer_copy(bytes(d["desc"]))
+    d2.T_cur_w = T2.data_ptr()
+    nt2 = torch.zeros_like(d["n_tracked"])
+    d2.n_tracked, d2.stats = nt2.data_ptr(), None
+    s2 = torch.cuda.Stream(device=dev)
+    d["T_cur_w"].copy_(d["T_seed"])
+    torch.cuda.synchronize()
+    for rep in range(3):
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(d["desc"]), C.byref(cs), C.byref(prm), stream.cuda_stream))
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(d2), C.byref(cs), C.byref(prm), s2.cuda_stream))
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, stream.cuda_stream))
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, s2.cuda_stream))
+        assert np.array_equal(d["T_cur_w"].cpu().numpy(), Tg) and np.array_equal(T2.cpu().numpy(), Tg), rep
+        assert np.array_equal(nt2.cpu().numpy(), ntg)
+        d["T_cur_w"].copy_(d["T_seed"]); T2.copy_(d["T_seed"])
+        torch.cuda.synchronize()
+
+
+def test_config5_1280x960_2000_patches_then_align2d(gpu_ctx, oracle):
+    """BASELINE config 5: 1280x960 pyramid, 4 levels, 2000 patches (one pair over a team of 8 compute units),
+    then the per-feature Align2D refinement of all 2000 features on the same current frame (10x10 / 8x8
+    patches cut from the reference at level 0, start offset U(-1.5, 1.5) px, 10 iterations)."""
+    from dsdtm_amd import feature_alignment as FA
+    sc = cached_scene(width=1280, height=960, levels=4, n_patches=2000, seed=0xC5, margin=40)
+    To, no, so = oracle.sparse_align(sc, 4, 0, 10)
+    for resident in (False, True):
+        from dsdtm_amd.frame import Config, frames_from_scene
+        from dsdtm_amd.sparse_align import Sprase_ImgAlign
+        Config.Set("Camera.Min_fts", 15)
+        cur, ref = frames_from_scene(sc)
+        al = Sprase_ImgAlign(4, 0, 10, ctx=gpu_ctx, resident_frames=resident)
+        ng = al.Run(cur, ref)
+        H.assert_pose_close(cur.Get_Pose(), To, H.TIGHT_RAD, H.TIGHT_M, what=f"config 5 (resident={resident})")
+        assert ng == no
+        for k in ("iters", "n_ref", "n_vis", "exit_code"):
+            assert al.last_stats[k] == so[k], (k, al.last_stats[k], so[k])
+    ea, et = synth.pose_error(cur.Get_Pose(), sc.T_cur_w_true)
+    assert ea < 2e-4 and et < 5e-4, (ea, et)
+    # Align2D: every feature's reference patch at level 0, searched in the current level 0 around its true
+    # position (the feature reprojected with the aligned pose) plus the start offset
+    rng = np.random.default_rng(55)
+    T = cur.Get_Pose()
+    Pc = sc.p_world @ T[:, :3].T + T[:, 3]
+    uv = np.stack([sc.cam.fx * Pc[:, 0] / Pc[:, 2] + sc.cam.cx, sc.cam.fy * Pc[:, 1] / Pc[:, 2] + sc.cam.cy], axis=1)
+    keep = (uv[:, 0] > 12) & (uv[:, 0] < 1280 - 12) & (uv[:, 1] > 12) & (uv[:, 1] < 960 - 12)
+    assert keep.sum() >= 1950
+    pb, p = H.make_border_patches(sc.ref_pyr[0], [tuple(c) for c in sc.px[keep].astype(np.float64)])
+    px0 = uv[keep] + rng.uniform(-1.5, 1.5, (keep.sum(), 2))
+    level = np.zeros(keep.sum(), np.int32)
+    co, pxo = oracle.align2d_batch(sc.cur_pyr, pb, p, level, px0, 10)
+    cg, pxg = FA.align2d_batch(sc.cur_pyr, pb, p, level, px0, 10, ctx=gpu_ctx)
+    assert np.array_equal(cg, co)
+    assert np.array_equal(pxg[co], pxo[co])                      # exact-order float sums: identical pixels
+    assert co.mean() > 0.9
+    d = np.hypot(*(pxg[co] - uv[keep][co]).T)
+    assert np.median(d) < 0.2, np.median(d)
+
+
+def test_config3_stream_of_1000_patch_frames_with_tracking_parameters(gpu_ctx, oracle):
+    """BASELINE config 3's shape: a 640x480 stream, ~1000 patches per frame after the moving-object mask (a
+    tenth of the features carry mbInitial = false, as masked-out features do), the live tracker's
+    Sprase_ImgAlign(5, 0, 8) (src/Tracking.cpp:20-24,37), device-resident frames, every frame seeded with
+    the previous frame's pose (src/Tracking.cpp:201-204), seven frames against the oracle chain."""
+    import copy
+    from dsdtm_amd.frame import Config, Frame
+    from dsdtm_amd.sparse_align import Sprase_ImgAlign
+    Config.Set("Camera.Min_fts", 15)
+    rng = np.random.default_rng(303)
+    L = 5
+    base = cached_scene(width=640, height=480, levels=L, n_patches=1000, seed=303, margin=40, frac_uninitial=0.1)
+    tex = synth.make_texture(480, 640, 303)
+    al = Sprase_ImgAlign(5, 0, 8, ctx=gpu_ctx, resident_frames=True)
+    ref = Frame(base.cam, base.ref_pyr, base.T_ref_w)
+    ref.set_features(base.px, base.bearing, base.p_world, base.initial)
+    To = base.T_cur_w_seed.copy()
+    prev_pose = base.T_cur_w_seed.copy()
+    xi = np.zeros(6)
+    for k in range(7):
+        xi = xi + np.concatenate([rng.uniform(-0.008, 0.008, 3), rng.uniform(-0.004, 0.004, 3)])
+        T_cr = synth.se3_exp(xi)
+        img = synth.warp_plane(tex, base.cam, T_cr, base.depth)
+        cur = Frame(base.cam, [img], prev_pose)                       # level 0 only: the pyramid is built on the device
+        cur._device_frame = capi.DeviceFrame.from_image(gpu_ctx, img, L)
+        ng = al.Run(cur, ref)
+        sc = copy.copy(base)
+        sc.cur_pyr = synth.build_pyramid(img, L)
+        To, no, so = oracle.sparse_align(sc, 5, 0, 8, T_seed=To)
+        H.assert_pose_close(cur.Get_Pose(), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"frame {k}")
+        assert ng == no and al.last_stats["iters"] == so["iters"] and al.last_stats["exit_code"] == so["exit_code"], k
+        truth = (T_cr @ np.vstack([base.T_ref_w, [0, 0, 0, 1]]))[:3]
+        ea, et = synth.pose_error(cur.Get_Pose(), truth)
+        assert ea < 5e-4 and et < 1.5e-3, (k, ea, et)
+        prev_pose = cur.Get_Pose().copy()
+        cur._device_frame.close()
+
+
+def test_config1_rgbd_sequence_through_the_cpp_driver(gpu_ctx, oracle, tmp_path):
+    """BASELINE config 1 (TUM fr1/xyz through Test/test_SpraseImg_alignment.cpp) with a generated RGB-D
+    sequence standing in for the dataset: dsdtm_amd/host/example_rgbd.cpp follows the reference test line
+    by line — detector on the first frame, 3-D points from the depth map, Sprase_ImgAlign(4, 0, 30),
+    Run(cur, ref) per frame seeded with the previous pose, error against ground truth printed — and the
+    poses it prints are held to the CPU oracle run on the very features the driver used."""
+    from tests.test_host_cpp import build_example
+    exe = build_example("example_rgbd")
+    W, Hh, L, depth, n_frames = 640, 480, 4, 2.0, 5
+    cam = synth.Camera.tum(W, Hh)
+    tex = synth.make_texture(Hh, W, 0x7A)
+    rng = np.random.default_rng(11)
+    T_ref = synth.random_pose(rng)
+    T4 = np.vstack([T_ref, [0, 0, 0, 1]])
+    frames, poses = [np.clip(np.rint(tex), 0, 255).astype(np.uint8)], [T_ref]
+    xi = np.zeros(6)
+    for k in range(1, n_frames):
+        xi = xi + np.concatenate([rng.uniform(-0.01, 0.01, 3), rng.uniform(-0.005, 0.005, 3)])
+        T_cr = synth.se3_exp(xi)
+        frames.append(synth.warp_plane(tex, cam, T_cr, depth))
+        poses.append((T_cr @ T4)[:3])
+    seq = tmp_path / "seq.bin"
+    with open(seq, "wb") as f:
+        f.write(struct.pack("<6i", W, Hh, L, n_frames, 20, 400))
+        f.write(struct.pack("<5f", cam.fx, cam.fy, cam.cx, cam.cy, cam.f))
+        for k in range(n_frames):
+            f.write(frames[k].tobytes() + np.ascontiguousarray(poses[k], "<f8").tobytes())
+            if k == 0:
+                f.write(np.full((Hh, W), depth, "<f4").tobytes())     # blender-style z-depth of the plane
+    feats = tmp_path / "features.bin"
+    out = subprocess.run([exe, str(seq), str(feats)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    n = int(out[0].split()[1])
+    assert n >= 100, out[0]
+    raw = np.fromfile(feats, dtype=np.uint8)[4:].reshape(n, 56)
+    px = raw[:, :8].copy().view("<f4").reshape(n, 2)
+    bearing = raw[:, 8:32].copy().view("<f8").reshape(n, 3)
+    p_world = raw[:, 32:56].copy().view("<f8").reshape(n, 3)
+    # the 3-D points the driver made from the depth map lie on the plane z = depth of the reference camera
+    Pc = p_world @ T_ref[:, :3].T + T_ref[:, 3]
+    assert np.abs(Pc[:, 2] - depth).max() < 1e-5
+    sc = type("S", (), {})()
+    sc.cam, sc.ref_pyr = cam, synth.build_pyramid(frames[0], L)
+    sc.px, sc.bearing, sc.p_world, sc.initial = px, bearing, p_world, np.ones(n, np.uint8)
+    sc.T_ref_w = T_ref
+    To = T_ref.copy()
+    for k in range(1, n_frames):
+        tok = out[k].split()
+        assert tok[0] == "frame" and int(tok[1]) == k
+        tracked, te, ang = int(tok[3]), float(tok[5]), float(tok[7])
+        T = np.array([float(v) for v in tok[9:21]]).reshape(3, 4)
+        iters = [int(v) for v in tok[22:26]]
+        sc.cur_pyr = synth.build_pyramid(frames[k], L)
+        sc.T_cur_w_seed = To
+        To, no, so = oracle.sparse_align(sc, 4, 0, 30)
+        H.assert_pose_close(T, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"rgbd frame {k}")
+        assert tracked == no and iters == so["iters"][:4]
+        assert te < 2e-3 and ang < 5e-4, (k, te, ang)                  # the error against ground truth the test prints

@@ -58,3 +58,26 @@ def test_pair_range_covers_everything_once():
             lo, hi = shard.pair_range(n, r, w)
             got += list(range(lo, hi))
         assert got == list(range(n))
+
+
+def test_bench_gpus_flag_spawns_one_worker_per_rank():
+    """`python bench.py --gpus 2` without a launcher starts two ranks (spawned before anything touches a GPU) that
+    rendezvous, run the barrier / max-over-ranks path and print ONE line with n_gpus = 2. --stub replaces the
+    GPU steps (this box has no GPU); the spawn path, the environment and the reductions are the real ones."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "4", "--warmup", "1",
+                        "--pairs", "1024"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["pairs_per_step_all_ranks"] == 2048
+    assert out["value"] is None and "stub" in out["data"]          # never mistaken for a measurement
+
+
+def test_bench_refuses_a_world_that_contradicts_the_flag():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
