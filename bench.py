@@ -420,9 +420,10 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSDTM_BENCH_STREAMS", "1")),
-                    help="HIP streams the steps are issued on in turn: with 2, the workgroups of step k+1 take the "
-                         "compute units the tail of step k leaves idle (same launches, same results)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSDTM_BENCH_STREAMS", "4")),
+                    help="HIP streams the steps are issued on in turn (default 4 = HIP's hardware queues): the workgroups "
+                         "of step k+1 take the compute units the tail of step k leaves idle (same launches, same "
+                         "results); 1 = strictly one launch at a time, with HIP events around every launch")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline entries (other shapes, pyrDown)")
@@ -605,8 +606,8 @@ def main():
                 out["value"] = None
                 out["parity_failed"] = True
                 rc = 1
-            if rc == 0 and not args.no_secondary:
-                out["secondary"] = secondary_entries(torch, dev, ctx, cam_struct, stream, args)
+        if rc == 0 and world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_entries(torch, dev, ctx, cam_struct, stream, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

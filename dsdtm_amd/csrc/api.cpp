@@ -1019,7 +1019,7 @@ extern "C" int dsdtm_pose_optimization(dsdtm_ctx* ctx, const double* bearing, co
 extern "C" int dsdtm_debug_selftest(dsdtm_ctx* ctx, const double* in, double* out, int n_cases) {
     if (!ctx || !in || !out || n_cases < 0) return DSDTM_ERR_INVALID;
     if (n_cases == 0) return DSDTM_OK;
-    const size_t ib = align_up((size_t)n_cases * 33 * 8, 256), ob = (size_t)n_cases * 34 * 8;
+    const size_t ib = align_up((size_t)n_cases * 33 * 8, 256), ob = (size_t)n_cases * 120 * 8;   // selftest.hip: SELFTEST_OUT
     if (int rc = ensure_stage(ctx, ib + ob)) return rc;
     uint8_t* h = (uint8_t*)ctx->h_pinned;
     uint8_t* d = (uint8_t*)ctx->d_stage;

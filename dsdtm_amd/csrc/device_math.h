@@ -181,6 +181,36 @@ __device__ inline SE3d se3_exp(const double* x) {
     return o;
 }
 
+// exp of a small twist x = [upsilon, omega] (theta^2 = |omega|^2 < 0.01) in MATRIX form:
+//   dR = I + a W + b W^2,   dt = (I + b W + c W^2) upsilon,   W = hat(omega), W^2 = omega omega^T - theta^2 I
+//   a = sin th / th, b = (1 - cos th) / th^2, c = (th - sin th) / th^3 as power series in theta^2 (six terms:
+//   truncation < 1e-19). The same group element as se3_exp(x) — Rodrigues' formula instead of the quaternion —
+// without sqrt, division or normalisation: the short way from the Gauss-Newton step to the rotation matrix and
+// translation the next residual pass needs (solver_step publishes R_state * dR, t_state + R_state * dt and
+// brings its quaternion state up to date afterwards, see sparse_align.hip).
+__device__ __forceinline__ void se3_exp_matrix_small(const double* x, double theta_sq, double* dR, double* dt) {
+    const double ux = x[0], uy = x[1], uz = x[2];
+    const double wx = x[3], wy = x[4], wz = x[5];
+    const double t2 = theta_sq;
+    const double a = 1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 + t2 * (-1.0 / 39916800)))));
+    const double b = 0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 + t2 * (-1.0 / 479001600.0)))));
+    const double c = 1.0 / 6 + t2 * (-1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800 +
+                     t2 * (-1.0 / 6227020800.0)))));
+    const double xy = wx * wy, xz = wx * wz, yz = wy * wz;
+    const double dxx = wx * wx - t2, dyy = wy * wy - t2, dzz = wz * wz - t2;
+    const double awx = a * wx, awy = a * wy, awz = a * wz;
+    dR[0] = 1.0 + b * dxx;   dR[1] = b * xy - awz;    dR[2] = b * xz + awy;
+    dR[3] = b * xy + awz;    dR[4] = 1.0 + b * dyy;   dR[5] = b * yz - awx;
+    dR[6] = b * xz - awy;    dR[7] = b * yz + awx;    dR[8] = 1.0 + b * dzz;
+    const double bwx = b * wx, bwy = b * wy, bwz = b * wz;
+    const double v00 = 1.0 + c * dxx, v01 = c * xy - bwz, v02 = c * xz + bwy;
+    const double v10 = c * xy + bwz, v11 = 1.0 + c * dyy, v12 = c * yz - bwx;
+    const double v20 = c * xz - bwy, v21 = c * yz + bwx, v22 = 1.0 + c * dzz;
+    dt[0] = v00 * ux + v01 * uy + v02 * uz;
+    dt[1] = v10 * ux + v11 * uy + v12 * uz;
+    dt[2] = v20 * ux + v21 * uy + v22 * uz;
+}
+
 // ---------------------------------------------------------------------------------------
 // Eigen 3.2 LDLT<Matrix<double,6,6>,Lower>::compute + solve, fully unrolled so that every
 // matrix index is a compile-time constant (the matrix stays in VGPRs). The pivot row is a
@@ -355,6 +385,119 @@ __device__ __forceinline__ void ldlt6_apply(const double* m, const double* dinv,
     ldlt_unswap<0>(d, tr0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = d[i];
+}
+
+// H^+ of a well-conditioned H without the transposition cascades of ldlt6_factor / ldlt6_apply.
+// Eigen's left-looking LDLT (ldlt_step above) updates a diagonal entry only at its own step, so every pivot
+// search sees ORIGINAL diagonal entries: the pivot sequence is the diagonal sorted by magnitude, known before
+// the first elimination step. With the permutation applied up front — a gather of the 21 entries — the six
+// steps run without pivoting, on the same numbers in the same order as the pivoted code: factors, reciprocals
+// and the solves of the six unit vectors (lane j < 6 solves e_j: column j of H^+) equal its results up to the
+// compiler's choice of FMA contraction (measured: relative differences <= 1e-12).
+// Returns false — nothing written — for anything but a full-rank matrix with a strictly ordered diagonal
+// (ties, a step below Eigen's rank cutoff, a D_i at or below the pseudo-inverse tolerance, non-finite
+// values): the caller then takes the general path. `Hu`: 21 upper-triangular entries, row-major (any address
+// space); `col`: the lane's column as Hinv[j * 6 + row] is written through `hinv` for lanes < 6.
+template <typename HPtr, typename OPtr>
+__device__ __forceinline__ bool ldlt6_hinv_sorted(HPtr Hu, OPtr hinv, int lane) {
+    auto uidx = [](int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); };   // i <= j
+    double dg[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dg[i] = fabs(Hu[uidx(i, i)]);
+    // rank_i = number of strictly larger entries; order[k] = the index of rank k
+    int order[6] = {0, 0, 0, 0, 0, 0};
+    bool bad = false;
+    double dmax = 0.0, dmin = dg[0];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (j == i) continue;
+            r += (dg[j] > dg[i]) ? 1 : 0;
+            if (j < i) bad |= (dg[j] == dg[i]);
+        }
+        bad |= !(dg[i] == dg[i]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) order[k] += (r == k) ? i : 0;
+        dmax = fmax(dmax, dg[i]); dmin = fmin(dmin, dg[i]);
+    }
+    const double cutoff = fabs(2.220446049250313e-16 * dmax);          // ldlt_step<0>
+    bad |= (dmin < cutoff) | !(dmax < 1.7976931348623157e308);
+    if (__builtin_amdgcn_readfirstlane((int)bad)) return false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) order[k] = __builtin_amdgcn_readfirstlane(order[k]);
+#define DSDTM_M(i, j) m[((i) * ((i) + 1)) / 2 + (j)]
+    double m[21], rD[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const int a = order[i], b = order[j];
+            DSDTM_M(i, j) = Hu[uidx(a < b ? a : b, a < b ? b : a)];
+        }
+    bool ok = true;
+#pragma unroll
+    for (int K = 0; K < 6; ++K) {                                       // ldlt_step<K> without the pivot cases
+        if (K > 0) {
+            double temp[6];
+#pragma unroll
+            for (int j = 0; j < K; ++j) temp[j] = DSDTM_M(j, j) * DSDTM_M(K, j);
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) s += DSDTM_M(K, j) * temp[j];
+            DSDTM_M(K, K) -= s;
+#pragma unroll
+            for (int i = K + 1; i < 6; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) a += DSDTM_M(i, j) * temp[j];
+                DSDTM_M(i, K) -= a;
+            }
+        }
+        rD[K] = 1.0 / DSDTM_M(K, K);
+        ok &= fabs(DSDTM_M(K, K)) > cutoff;
+        if (K < 5) {
+#pragma unroll
+            for (int i = K + 1; i < 6; ++i) DSDTM_M(i, K) *= rD[K];
+        }
+    }
+    {   // pseudo-inverse tolerance of ldlt6_factor: every D_i must be kept
+        double maxd = 0.0, mind = fabs(DSDTM_M(0, 0));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { maxd = fmax(maxd, fabs(DSDTM_M(i, i))); mind = fmin(mind, fabs(DSDTM_M(i, i))); }
+        double tol = maxd * 2.220446049250313e-16;
+        tol = fmax(tol, 1.0 / 1.7976931348623157e308);
+        ok &= (mind > tol) & (maxd < 1.7976931348623157e308);
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) return false;
+    // lane j < 6: d = P e_j, L^-1, D^-1, L^-T, x = P^T d
+    const int jj = lane < 6 ? lane : 5;
+    double d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = (order[i] == jj) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) s += DSDTM_M(i, j) * d[j];
+        d[i] -= s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = d[i] * rD[i];
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s += DSDTM_M(j, i) * d[j];
+        d[i] -= s;
+    }
+    if (lane < 6) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) hinv[jj * 6 + order[i]] = d[i];
+    }
+#undef DSDTM_M
+    return true;
 }
 
 __device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x) {

@@ -10,13 +10,18 @@ namespace dsdtm {
 
 // per case: in[0..20] H upper triangle, in[21..26] b, in[27..32] xi  -> out[0..5] x = H^+ b,
 // out[6..12] exp(xi) (qw,qx,qy,qz,tx,ty,tz), out[13..19] exp(xi)*exp(b) , out[20] DPP wave sum of
-// (lane+1)*in[27], out[21] shuffle wave sum of the same, out[22..33] [R|t] of exp(xi) via from_rt(to_rt)
+// (lane+1)*in[27], out[21] shuffle wave sum of the same, out[22..33] [R|t] of exp(xi) via from_rt(to_rt),
+// out[34..69] H^+ by columns from ldlt6_solve on the unit vectors, out[70..105] the same from ldlt6_hinv_sorted
+// (untouched where it declines), out[106] 1 where it accepted the matrix, out[107..118] dR (9) and dt (3) of
+// se3_exp_matrix_small(xi) (only for |omega|^2 < 0.01), out[119] unused
+constexpr int SELFTEST_OUT = 120;
 __global__ void selftest_kernel(const double* __restrict__ in, double* __restrict__ out, int n_cases) {
     const int c = blockIdx.x;
     if (c >= n_cases) return;
     const int lane = threadIdx.x;
     const double* p = in + (size_t)c * 33;
-    double* o = out + (size_t)c * 34;
+    double* o = out + (size_t)c * SELFTEST_OUT;
+    __shared__ double s_h[21], s_hinv[36];
     double H[21], b[6], xi[6], x[6];
     for (int i = 0; i < 21; ++i) H[i] = p[i];
     for (int i = 0; i < 6; ++i) { b[i] = p[21 + i]; xi[i] = p[27 + i]; }
@@ -32,7 +37,27 @@ __global__ void selftest_kernel(const double* __restrict__ in, double* __restric
     const SE3d Eb = se3_from_rt(T);
     double R2[9];
     quat_to_matrix(Eb, R2);
+    // H^+ twice: the general pivoted code on the unit vectors, and the sorted-diagonal fast path
+    if (lane < 21) s_h[lane] = p[lane];
+    if (lane < 36) s_hinv[lane] = -12345.0;
+    __syncthreads();
+    const bool fast_ok = ldlt6_hinv_sorted((const double*)s_h, (double*)s_hinv, lane);
+    __syncthreads();
+    double dRm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dtm[3] = {0, 0, 0};
+    const double th2 = xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5];
+    if (th2 < 0.01) se3_exp_matrix_small(xi, th2, dRm, dtm);
+    if (lane < 6) {
+        double e[6], colv[6];
+        for (int i = 0; i < 6; ++i) e[i] = (i == lane) ? 1.0 : 0.0;
+        ldlt6_solve(H, e, colv);
+        for (int i = 0; i < 6; ++i) o[34 + lane * 6 + i] = colv[i];
+    }
+    if (lane < 36) o[70 + lane] = s_hinv[lane];
     if (lane == 63) {
+        o[106] = fast_ok ? 1.0 : 0.0;
+        for (int i = 0; i < 9; ++i) o[107 + i] = dRm[i];
+        for (int i = 0; i < 3; ++i) o[116 + i] = dtm[i];
+        o[119] = 0.0;
         for (int i = 0; i < 6; ++i) o[i] = x[i];
         o[6] = E.qw; o[7] = E.qx; o[8] = E.qy; o[9] = E.qz; o[10] = E.tx; o[11] = E.ty; o[12] = E.tz;
         o[13] = E2.qw; o[14] = E2.qx; o[15] = E2.qy; o[16] = E2.qz; o[17] = E2.tx; o[18] = E2.ty; o[19] = E2.tz;

@@ -78,6 +78,8 @@ struct BlockState {
     UnitPose u;                 // live: q/t/qr/tr solver-private, Cref/R/tt read by the patch waves
     // solver-private state
     double qo[4], to[3];        // T_c2r before the last accepted step (tT_c2rOld)
+    double Rs[9];               // rotation matrix of the quaternion state u.q (the published u.R is Rs * dR of the
+                                // last step in matrix form: the same rotation to ~1e-16, available ~1 k cycles earlier)
     double chi2;
     double Hsum[21];            // sum of the per-row H partials of the last change of the visible set
     double Hinv[36];            // H^+ = P^T L^-T D^+ L^-1 P by columns (ldlt6_factor + ldlt6_apply on the unit vectors:
@@ -605,6 +607,7 @@ __device__ __forceinline__ void unit_state_reset(LdsBlockState& s, int lane) {
         const double v = lane < 4 ? s.u.q[lane] : s.u.t[lane - 4];    // tT_c2rOld = T_c2r
         if (lane < 4) s.qo[lane] = v; else s.to[lane - 4] = v;
     }
+    if (lane >= 7 && lane < 16) s.Rs[lane - 7] = s.u.R[lane - 7];
     if (lane == 0) { s.chi2 = 0.0; s.n_vis = 0; s.ctrl = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -666,7 +669,26 @@ __device__ __forceinline__ void commit_next(LdsBlockState& s, int lane) {
 // Deliberately NOT inlined: it runs only when the visible set changed (about once per pyramid level),
 // and keeping its ~70 live registers out of solver_step's allocation keeps the whole kernel inside
 // the 168-VGPR budget of a 12-wave workgroup without spills on the per-iteration path.
+// The common case first: a full-rank H goes through ldlt6_hinv_sorted (permutation known from the diagonal, no
+// transposition cascades — the same pivot order and operations in fewer instructions); everything else
+// (rank cutoff, ties, zero matrix) through the general code below.
+#ifndef SA_FAST_HINV
+#define SA_FAST_HINV 1
+#endif
+__device__ __attribute__((noinline)) void factor_hinv_general(LdsBlockState* sp, int lane);
 __device__ __attribute__((noinline)) void factor_hinv_to_lds(LdsBlockState* sp, int lane) {
+#if SA_FAST_HINV
+    typedef __attribute__((address_space(3))) double LdsF64;
+    const bool done = ldlt6_hinv_sorted((const LdsF64*)sp->Hsum, (LdsF64*)sp->Hinv, lane);
+    if (!done) factor_hinv_general(sp, lane);
+#else
+    factor_hinv_general(sp, lane);
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __attribute__((noinline)) void factor_hinv_general(LdsBlockState* sp, int lane) {
     LdsBlockState& s = *sp;
     double H[21], Fm[21], Fdinv[6];
     int tr0, tr1, tr2, tr3, tr4;
@@ -710,12 +732,21 @@ __device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, Bloc
     for (int j = 0; j < 6; ++j) hrow[j] = s.Hinv[j * 6 + li];   // lane i < 6 keeps row i of H^+ (stored by columns)
 }
 
-// Solver wave, one Gauss-Newton iteration (reference :310-343). Executed uniformly by all 64
-// lanes of the solver wave (same cost as one lane); lane 0 publishes. Returns ctrl.
+// what solver_step hands to solver_commit (wave-uniform values)
+struct SolverCarry {
+    double x[6], chi2_prev, chi2_new;
+    int level, it, cnt, n_ref, ctrl, exit_code;
+    bool fast;                  // the step was published in matrix form: the quaternion state is still to be updated
+};
+
+// Solver wave, one Gauss-Newton iteration (reference :310-343), up to the point where the patch waves can go
+// on: new R/t and the control word are in LDS when it returns (the caller publishes them), the rest of the
+// iteration follows in solver_commit. Executed uniformly by all 64 lanes of the solver wave (same cost as one
+// lane); lane 0 stores. Returns ctrl.
 template <int NP>   // NP = number of partial slots (rows or waves)
 __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int level, int it,
                                            const WavePartial* s_part, BlockState& s, int lane,
-                                           double* hrow /* lane i < 6: row i of H^+ */,
+                                           double* hrow /* lane i < 6: row i of H^+ */, SolverCarry& c,
                                            unsigned long long* tacc = nullptr /* diagnostic build only */) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
     if (tacc) ts0 = __builtin_amdgcn_s_memtime();
@@ -792,6 +823,9 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
     const bool stop = (x[0] != x[0]);                      // :321 isnan(x(0))
     const double chi2_prev = s.chi2;
     int ctrl = 0, exit_code = 0;
+    c.fast = false; c.level = level; c.it = it; c.cnt = cnt; c.n_ref = n_ref; c.chi2_prev = chi2_prev; c.chi2_new = chi2New;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c.x[i] = x[i];
     if ((it > 0 && chi2New > chi2_prev) || stop) {         // :328-332  tT_c2r = tT_c2rOld
         const SE3d To = load_se3(s.qo, s.to);
         double Rn[9];
@@ -799,47 +833,95 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
         if (lane == 0) {
             store_se3(s.u.q, s.u.t, To);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) s.u.R[i] = Rn[i];
+            for (int i = 0; i < 9; ++i) { s.u.R[i] = Rn[i]; s.Rs[i] = Rn[i]; }
             s.u.tt[0] = To.tx; s.u.tt[1] = To.ty; s.u.tt[2] = To.tz;
         }
         ctrl = 1;
         exit_code = stop ? 3 : 1;
     } else {
-        const SE3d dT = se3_exp(x);
-        __builtin_amdgcn_sched_barrier(0);
-        const SE3d Tcur = load_se3(s.u.q, s.u.t);
-        const SE3d Tn = se3_mul(Tcur, dT);                 // :335 right-multiply
-        __builtin_amdgcn_sched_barrier(0);
-        double Rn[9];
-        quat_to_matrix(Tn, Rn);
+        const double theta_sq = x[3] * x[3] + x[4] * x[4] + x[5] * x[5];
+        if (theta_sq < 0.01) {
+            // The pass only needs R and t of T_c2r * exp(x) (:335, right-multiply): in matrix form that is
+            // R_state * dR, t_state + R_state * dt — about half the dependent instructions of the quaternion
+            // route. It is published first; solver_commit then brings the Sophus-style quaternion state (what
+            // the next step composes with, what a revert restores and what Run finally returns) up to date
+            // while the patch waves are already running the next pass.
+            double dR[9], dt[3];
+            se3_exp_matrix_small(x, theta_sq, dR, dt);
+            __builtin_amdgcn_sched_barrier(0);
+            double Rn[9], tn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double r0 = s.Rs[3 * i], r1 = s.Rs[3 * i + 1], r2 = s.Rs[3 * i + 2];
+                Rn[3 * i] = r0 * dR[0] + r1 * dR[3] + r2 * dR[6];
+                Rn[3 * i + 1] = r0 * dR[1] + r1 * dR[4] + r2 * dR[7];
+                Rn[3 * i + 2] = r0 * dR[2] + r1 * dR[5] + r2 * dR[8];
+                tn[i] = s.u.t[i] + (r0 * dt[0] + r1 * dt[1] + r2 * dt[2]);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) s.u.R[i] = Rn[i];
+                s.u.tt[0] = tn[0]; s.u.tt[1] = tn[1]; s.u.tt[2] = tn[2];
+            }
+            c.fast = true;
+        } else {                                           // a large rotation step: the closed forms, state first
+            const SE3d dT = se3_exp(x);
+            const SE3d Tcur = load_se3(s.u.q, s.u.t);
+            const SE3d Tn = se3_mul(Tcur, dT);             // :335 right-multiply
+            double Rn[9];
+            quat_to_matrix(Tn, Rn);
+            if (lane == 0) {
+                store_se3(s.qo, s.to, Tcur);
+                store_se3(s.u.q, s.u.t, Tn);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { s.u.R[i] = Rn[i]; s.Rs[i] = Rn[i]; }
+                s.u.tt[0] = Tn.tx; s.u.tt[1] = Tn.ty; s.u.tt[2] = Tn.tz;
+                s.chi2 = chi2New;
+            }
+        }
         double mx = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(x[i]));
-        if (lane == 0) {
-            store_se3(s.qo, s.to, Tcur);
-            store_se3(s.u.q, s.u.t, Tn);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) s.u.R[i] = Rn[i];
-            s.u.tt[0] = Tn.tx; s.u.tt[1] = Tn.ty; s.u.tt[2] = Tn.tz;
-            s.chi2 = chi2New;
-        }
         if (mx <= 1e-8) { ctrl = 1; exit_code = 2; }        // :341
     }
     ctrl = __builtin_amdgcn_readfirstlane(ctrl);
+    c.ctrl = ctrl; c.exit_code = exit_code;
     if (tacc) { ts3 = __builtin_amdgcn_s_memtime(); tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; tacc[2] += ts3 - ts2; }
     if (lane == 0) {
         s.ctrl = ctrl;
         s.n_vis = cnt;
-        if (a.stats && (ctrl || it == a.max_iters - 1)) {
-            dsdtm_align_stats* st = a.stats + pair;
-            st->iters[level] = it + 1;
-            st->n_ref[level] = n_ref;
-            st->n_vis[level] = cnt;
-            st->exit_code[level] = exit_code;
-            st->chi2[level] = (ctrl == 1 && exit_code != 2) ? chi2_prev : chi2New;
-        }
     }
     return ctrl;
+}
+
+// Solver wave, after the new R/t/ctrl have been published: the part of the iteration nobody waits for.
+// T_c2r = T_c2r * SE3::exp(x) on the quaternion state (:335), its rotation matrix for the next step,
+// tT_c2rOld and chi2 (:313-314), and the statistics.
+__device__ __forceinline__ void solver_commit(const SAKernelArgs& a, int pair, BlockState& s, int lane, const SolverCarry& c) {
+    if (c.fast) {
+        const SE3d dT = se3_exp(c.x);
+        __builtin_amdgcn_sched_barrier(0);
+        const SE3d Tcur = load_se3(s.u.q, s.u.t);
+        const SE3d Tn = se3_mul(Tcur, dT);
+        __builtin_amdgcn_sched_barrier(0);
+        double Rn[9];
+        quat_to_matrix(Tn, Rn);
+        if (lane == 0) {
+            store_se3(s.qo, s.to, Tcur);
+            store_se3(s.u.q, s.u.t, Tn);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s.Rs[i] = Rn[i];
+            s.chi2 = c.chi2_new;
+        }
+    }
+    if (lane == 0 && a.stats && (c.ctrl || c.it == a.max_iters - 1)) {
+        dsdtm_align_stats* st = a.stats + pair;
+        st->iters[c.level] = c.it + 1;
+        st->n_ref[c.level] = c.n_ref;
+        st->n_vis[c.level] = c.cnt;
+        st->exit_code[c.level] = c.exit_code;
+        st->chi2[c.level] = (c.ctrl == 1 && c.exit_code != 2) ? c.chi2_prev : c.chi2_new;
+    }
 }
 
 // Solver wave, epilogue: tCurFrame->Set_Pose(mT_c2r * tRefFrame->Get_Pose()) (:57), return mnPts (:59)
@@ -1008,7 +1090,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     expected += NPW;
                     pair_wait_arrive(&s.arrive, expected);             // B1
                     if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
-                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hrow, STAMPS ? t_sub : nullptr);
+                    SolverCarry carry;
+                    const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hrow, carry, STAMPS ? t_sub : nullptr);
                     if (STAMPS) {
                         t2 = __builtin_amdgcn_s_memtime();
                         if (it == 0) t_first += t1 - t0; else t_wait += t1 - t0;
@@ -1016,6 +1099,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                         n_it += 1;
                     }
                     pair_publish(s, ++published, lane);                // B2
+                    solver_commit(a, pair, s, lane, carry);            // quaternion state, chi2, statistics: behind the hand-over
                     if (ctrl) break;
                     // the rest of this iteration's window (the patch waves are running their next pass)
                     if (!prepared && level < a.max_level - 1) {
@@ -1263,8 +1347,10 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
             double hrow[6];                                            // row of H^+, rebuilt when a wave reports a new visible set
             for (int it = 0; it < a.max_iters; ++it) {
                 __syncthreads();                                       // B1
-                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow);
+                SolverCarry carry;
+                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry);
                 __syncthreads();                                       // B2
+                solver_commit(a, pair, s, lane, carry);
                 if (ctrl) break;
             }
         }
@@ -1389,13 +1475,17 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
 // every tag matches. Two banks (iteration parity): a member can only overwrite the bank of iteration g at
 // iteration g + 2, which it reaches after every other member has published g + 1, i.e. has read all of g.
 constexpr int TEAM_WPD = sizeof(WavePartial) / sizeof(double);          // doubles of one (member) partial
-constexpr size_t TEAM_BYTES = 2 * 16 * TEAM_WPD * 2 * sizeof(unsigned long long);   // banks x members x words
-static_assert(TEAM_BYTES <= 16384, "team buffer");
+constexpr int TEAM_MAX_MEMBERS = 64;                                     // one solver lane per member partial
+constexpr size_t TEAM_BYTES = 2 * TEAM_MAX_MEMBERS * TEAM_WPD * 2 * sizeof(unsigned long long);   // banks x members x words
+static_assert(TEAM_BYTES <= 65536, "team buffer");
 
+// K = member capacity of the instantiation: teams of 2..16 members run the instantiation of exactly their size,
+// larger ones (up to 64 members = 16 384 features) the 64-member instantiation with `k` members at run time (the
+// absent members' partials are zero, so the solver's fixed-order sums are unchanged by them).
 template <int K, int NPW>
-__global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const SAKernelArgs a, int pairs_pad) {
+__global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const SAKernelArgs a, int pairs_pad, int k) {
     constexpr int PT = NPW * 64, WPD = TEAM_WPD;
-    static_assert(K <= 16 && WPD <= 32, "one solver lane per member partial / per double of a partial");
+    static_assert(K <= TEAM_MAX_MEMBERS && WPD <= 32, "one solver lane per member partial / per double of a partial");
     __shared__ WavePartial s_part[NPW];     // this member's wave partials
     __shared__ WavePartial s_mpart[K];      // one partial per member (its waves summed in wave order), member order
     __shared__ BlockState s;
@@ -1421,6 +1511,8 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
         SAKernelArgs am = a;
         if (member != 0) am.stats = nullptr;
         unsigned g = 0;                                                  // iterations so far, over all levels
+        if (k < K)                                                       // absent members contribute zeros
+            for (int i = lane; i < (K - k) * WPD; i += 64) ((unsigned long long*)&s_mpart[k])[i] = 0ull;
         solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
         if (member == 0 && lane == 0) stats_clear(a, pair);
         __syncthreads();                                                 // B0
@@ -1442,7 +1534,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
                     if (lane == 0) s.ctrl = 1;
                 } else {
                     const unsigned long long tag = (unsigned long long)(g + 1u) << 32;
-                    unsigned long long* const bank = twords + (size_t)(g & 1u) * 16 * WPD * 2;
+                    unsigned long long* const bank = twords + (size_t)(g & 1u) * TEAM_MAX_MEMBERS * WPD * 2;
                     // this member's partial: lane i < WPD folds double i of its wave partials in wave order
                     // (doubles 7 and 8 are the packed counters: cnt | h_changed and n_ref | pad)
                     if (lane < WPD) {
@@ -1471,7 +1563,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
                     unsigned spins = 0;
                     for (;;) {
                         bool pending = false;
-                        for (int i = lane; i < K * WPD; i += 64) {
+                        for (int i = lane; i < k * WPD; i += 64) {
                             if (i / WPD == member) continue;
                             const unsigned long long w0 = __hip_atomic_load(bank + 2 * (size_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             const unsigned long long w1 = __hip_atomic_load(bank + 2 * (size_t)i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1487,8 +1579,14 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    ctrl = solver_step<K>(am, pair, level, it, s_mpart, s, lane, hrow);
+                    SolverCarry carry;
+                    ctrl = solver_step<K>(am, pair, level, it, s_mpart, s, lane, hrow, carry);
                     if (!ok) { ctrl = 1; dead = true; if (lane == 0) s.ctrl = 1; }
+                    ++g;
+                    __syncthreads();                                     // B2
+                    solver_commit(am, pair, s, lane, carry);
+                    if (ctrl) break;
+                    continue;
                 }
                 ++g;
                 __syncthreads();                                         // B2
@@ -1558,40 +1656,49 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
 }
 
 template <int K, int NPW>
-static hipError_t launch_team(const SAKernelArgs& args, int pairs_pad, hipStream_t stream) {
-    hipLaunchKernelGGL((sparse_align_team_kernel<K, NPW>), dim3((unsigned)(pairs_pad * K)), dim3((NPW + 1) * 64), 0, stream, args, pairs_pad);
+static hipError_t launch_team(const SAKernelArgs& args, int pairs_pad, int k, hipStream_t stream) {
+    hipLaunchKernelGGL((sparse_align_team_kernel<K, NPW>), dim3((unsigned)(pairs_pad * k)), dim3((NPW + 1) * 64), 0, stream, args, pairs_pad, k);
     return hipGetLastError();
 }
 
 // Team shape (few pairs of more than 448 features): members of 4 patch waves (256 patches: every SIMD of a member's CU carries one patch wave, the
 // pass runs at its uncontended ~3 k cycles and the level start's gathers spread over more CUs; members of 7
-// waves were 15 % slower), K = ceil(N / 256) = 2..16 members (N <= 4096: one solver lane per member partial).
+// waves were 15 % slower), K = ceil(N / 256) = 2..64 members (N <= 16 384: one solver lane per member partial).
 // Returns K, or 0 when the team kernel does not apply (then: workspace kernel).
 constexpr int TEAM_NPW = 4;
+static int team_pairs_pad(int n_pairs, int k) {
+    // members of a team are workgroups b, b + P, b + 2P ..: P a multiple of 8 keeps a team on one XCD (one L2, 32
+    // CUs); teams of more than 32 members cannot fit one XCD and are spread over all of them instead (P odd)
+    static const int spread_min = getenv("DSDTM_TEAM_SPREAD_MIN") ? atoi(getenv("DSDTM_TEAM_SPREAD_MIN")) : 33;   // diagnostic override
+    if (k < spread_min) return (n_pairs + 7) / 8 * 8;
+    return n_pairs | 1;
+}
 int sparse_align_team_size(int n_pairs, int max_features, int num_cus) {
     // from 449 features a team of 2..3 CUs beats the 11 + 1 wave register kernel on one CU (N = 600: 0.113 vs
     // 0.121 ms per Run); below, one CU wins (N = 300: 0.108 vs 0.115 ms). DSDTM_TEAM_MIN overrides (diagnostic).
     static const int team_min = getenv("DSDTM_TEAM_MIN") ? atoi(getenv("DSDTM_TEAM_MIN")) : 449;
     if (max_features < team_min || n_pairs <= 0) return 0;
-    const int pairs_pad = (n_pairs + 7) / 8 * 8;
     const int k = (max_features + TEAM_NPW * 64 - 1) / (TEAM_NPW * 64);
-    if (k > 16 || pairs_pad * k > num_cus / 2) return 0;
+    // every member must be resident at once (they spin on each other): the LIVE workgroups (n_pairs * k; the
+    // padding workgroups exit at once) may take half the CUs
+    if (k > TEAM_MAX_MEMBERS || n_pairs * k > num_cus / 2) return 0;
     return k;
 }
 size_t sparse_align_team_bytes(int n_pairs) { return (size_t)n_pairs * TEAM_BYTES; }
 
 template <int K>
 static hipError_t launch_team_k(const SAKernelArgs& args, int k, int pairs_pad, hipStream_t stream) {
-    if constexpr (K > 16) return hipErrorInvalidValue;
+    if constexpr (K > 16) return launch_team<TEAM_MAX_MEMBERS, TEAM_NPW>(args, pairs_pad, k, stream);
     else {
-        if (k == K) return launch_team<K, TEAM_NPW>(args, pairs_pad, stream);
+        if (k == K) return launch_team<K, TEAM_NPW>(args, pairs_pad, k, stream);
         return launch_team_k<K + 1>(args, k, pairs_pad, stream);
     }
 }
 
 hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
-    return launch_team_k<2>(args, k, (args.n_pairs + 7) / 8 * 8, stream);
+    if (k < 2 || k > TEAM_MAX_MEMBERS) return hipErrorInvalidValue;
+    return launch_team_k<2>(args, k, team_pairs_pad(args.n_pairs, k), stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -36,7 +36,7 @@ def assert_pose_close(Tg, To, tol_rad=TOL_RAD, tol_m=TOL_M, what=""):
 
 def selftest(ctx, cases: np.ndarray) -> np.ndarray:
     cases = np.ascontiguousarray(cases, np.float64).reshape(-1, 33)
-    out = np.zeros((len(cases), 34))
+    out = np.zeros((len(cases), 120))         # selftest.hip: SELFTEST_OUT
     f = ctx.lib.dsdtm_debug_selftest
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
