@@ -1278,41 +1278,52 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
 // p = tid, tid + NPW*64, ...; the per-patch state is parked in an HBM workspace laid out
 // [slot][patch] so that the lanes of a wave read consecutive doubles (coalesced 512-B rows).
 // ---------------------------------------------------------------------------------------------
-constexpr int WS_SLOTS = 35;   // 32 grid values + X3
+// What is parked per patch is the INPUT of the grid, not the grid: the 7x7 u8 reference footprint as unpacked
+// row words (14 dwords), the feature's pixel (2 floats) and its 3-D point (3 doubles) — 88 bytes instead of the
+// 280 bytes of the 32 interpolated doubles + X. Every pass rebuilds the grid in registers with the same
+// grid_from_rows the register kernels run once per level (same inputs, same arithmetic: bit-identical values).
+// The first version parked the grid itself and was bound by exactly that traffic: 1024 pairs of 1000 patches moved
+// 8.7 GB per launch through HBM (rocprofv3 FETCH_SIZE/WRITE_SIZE, 9.7x the algorithmic bytes) at 6.2 TB/s.
+constexpr int WS_DWORDS = 22;   // rlo[7], rhi[7], px, py, X[3] as dword pairs
 __host__ __device__ inline size_t ws_doubles_per_pair(int max_features) {
     const size_t npad = ((size_t)max_features + 63) / 64 * 64;
-    return npad * WS_SLOTS;
+    return npad * WS_DWORDS / 2;
 }
 
-__device__ __forceinline__ void ws_store(double* __restrict__ ws, size_t npad, int p, const PatchRegs<double>& P) {
-    int q = 0;
+struct WsPatch {
+    uint32_t rlo[7], rhi[7];
+    FeatureRegs F;               // px, py, X; ok = the patch passed the reference-side checks of this level
+};
+
+__device__ __forceinline__ void ws_store(uint32_t* __restrict__ ws, size_t npad, int p, const WsPatch& w) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            if ((r == 0 || r == 5) && (c == 0 || c == 5)) continue;
-            ws[(size_t)q * npad + p] = P.g[r][c];
-            ++q;
-        }
+    for (int r = 0; r < 7; ++r) { ws[(size_t)r * npad + p] = w.rlo[r]; ws[(size_t)(7 + r) * npad + p] = w.rhi[r]; }
+    ws[(size_t)14 * npad + p] = __float_as_uint(w.F.px);
+    ws[(size_t)15 * npad + p] = __float_as_uint(w.F.py);
     // invalid patches are parked with a NaN depth
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        ws[(size_t)(32 + i) * npad + p] = P.valid ? P.X[i] : __longlong_as_double(0x7ff8000000000000ll);
+    for (int i = 0; i < 3; ++i) {
+        const double v = w.F.ok ? w.F.X[i] : __longlong_as_double(0x7ff8000000000000ll);
+        ws[(size_t)(16 + 2 * i) * npad + p] = (uint32_t)__double2loint(v);
+        ws[(size_t)(17 + 2 * i) * npad + p] = (uint32_t)__double2hiint(v);
+    }
 }
 
-__device__ __forceinline__ void ws_load(const double* __restrict__ ws, size_t npad, int p, PatchRegs<double>& P) {
-    int q = 0;
+__device__ __forceinline__ void ws_load(const uint32_t* __restrict__ ws, size_t npad, int p, WsPatch& w) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 7; ++r) { w.rlo[r] = ws[(size_t)r * npad + p]; w.rhi[r] = ws[(size_t)(7 + r) * npad + p]; }
+    w.F.px = __uint_as_float(ws[(size_t)14 * npad + p]);
+    w.F.py = __uint_as_float(ws[(size_t)15 * npad + p]);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            if ((r == 0 || r == 5) && (c == 0 || c == 5)) { P.g[r][c] = 0.0; continue; }
-            P.g[r][c] = ws[(size_t)q * npad + p];
-            ++q;
-        }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) P.X[i] = ws[(size_t)(32 + i) * npad + p];
-    P.valid = (P.X[2] == P.X[2]);
+    for (int i = 0; i < 3; ++i)
+        w.F.X[i] = __hiloint2double((int)ws[(size_t)(17 + 2 * i) * npad + p], (int)ws[(size_t)(16 + 2 * i) * npad + p]);
+    w.F.ok = (w.F.X[2] == w.F.X[2]);
+}
+
+// the register-resident patch state of one parked patch (what precompute_patch leaves behind in the register kernels)
+__device__ __forceinline__ void ws_patch_regs(const WsPatch& w, const LevelGeom& lg, int level, PatchRegs<double>& P) {
+    const RefGeom g = ref_geom(w.F, lg, level);          // valid == w.F.ok: the border test passed when the patch was parked
+    grid_from_rows<double>(w.F, g, w.rlo, w.rhi, P);
 }
 
 template <int NPW>
@@ -1362,7 +1373,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
     const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
     const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
     const size_t npad = ((size_t)a.max_features + 63) / 64 * 64;
-    double* __restrict__ ws = a.workspace + (size_t)pair * ws_doubles_per_pair(a.max_features);
+    uint32_t* __restrict__ ws = (uint32_t*)(a.workspace + (size_t)pair * ws_doubles_per_pair(a.max_features));
     __syncthreads();                                                   // B0
 
     for (int level = a.max_level - 1; level >= a.min_level; --level) {
@@ -1373,11 +1384,17 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
         {
             const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
             for (int p = tid; p < (int)npad; p += PT) {
-                PatchRegs<double> P;
-                const FeatureRegs F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + p, p < nf), Cref);
-                precompute_patch<double>(a, lg, level, ref_base, F, P);
-                ws_store(ws, npad, p, P);          // read back only by this same thread
-                n_valid_lane += P.valid ? 1 : 0;
+                WsPatch w;
+                w.F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + p, p < nf), Cref);
+                const RefGeom g = ref_geom(w.F, lg, level);
+                {
+                    U32x3 rows[7];
+                    ref_rows_issue(a, lg, ref_base, g, rows);
+                    ref_rows_unpack(a, lg, g, rows, w.rlo, w.rhi);
+                }
+                w.F.ok = g.valid;
+                ws_store(ws, npad, p, w);          // read back only by this same thread
+                n_valid_lane += g.valid ? 1 : 0;
             }
         }
         const int n_ref_wave = (int)wave_sum_to_lane63((double)n_valid_lane);   // valid in lane 63
@@ -1398,7 +1415,11 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
             unsigned long long vis_new = 0ull, bit = 1ull;
             for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
                 PatchRegs<double> P;
-                ws_load(ws, npad, p, P);
+                {
+                    WsPatch w;
+                    ws_load(ws, npad, p, w);
+                    ws_patch_regs(w, lg, level, P);
+                }
                 double c2, bp[6];
                 const bool vis = residual_patch<double>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp);
                 if (vis) {
@@ -1420,7 +1441,11 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
                 for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
                     if (!(vis_new & bit)) continue;
                     PatchRegs<double> P;
-                    ws_load(ws, npad, p, P);
+                    {
+                        WsPatch w;
+                        ws_load(ws, npad, p, w);
+                        ws_patch_regs(w, lg, level, P);
+                    }
                     const PatchHess ph = patch_hess_factors<double>(P, fs);
                     patch_hess_foreach<0, 0>(ph, [&](int q, double v) { H[q] += v; });
                 }

@@ -74,7 +74,10 @@ class Feature_detector:
 
     def detect(self, frame: Frame, detection_threshold: float, tFirst: bool = True):
         """void Feature_detector::detect(Frame*, const double, const bool) — :69-154. New features are
-        appended to the frame (pixel + level; bearing left to the caller as with Add_Feature(.., 0), :144)."""
+        appended to the frame (pixel + level; bearing left to the caller as with Add_Feature(.., 0), :144).
+        `frame.mDynamicMask` (optional, u8, level-0 size) is Frame::mDynamicMask, the moving-object mask
+        Set_Mask subtracts (src/Frame.cpp:294-296). Corners of EQUAL score keep their cell order here (stable
+        sort); the reference's std::sort (:110) leaves the order of ties unspecified."""
         if frame.n_features >= self.mMax_fts:                             # :71-72
             return 0
         score, cx, cy, cl = self.detect_cells(frame, detection_threshold)
@@ -85,6 +88,11 @@ class Feature_detector:
             for k in range(frame.n_features):
                 if frame.initial[k]:                                      # features that have a map point
                     fill_circle(mask, int(round(float(frame.px[k, 0]))), int(round(float(frame.px[k, 1]))), rad, 0)
+            # Set_Mask also removes the moving-object mask (src/Frame.cpp:294-296): mDynamicMask thresholded at 200,
+            # mImgMask - mDynamicMask with cv::Mat's saturating u8 subtraction => 0 wherever the object mask is set
+            dyn = getattr(frame, "mDynamicMask", None)
+            if dyn is not None:
+                mask[np.asarray(dyn, np.uint8) > 200] = 0
         new_px, new_level = [], []
         n = frame.n_features
         for k in order:                                                   # :124-150

@@ -72,6 +72,7 @@ struct Frame {                                    // include/Frame.h (what the p
     std::vector<Image8> mvImg_Pyr;
     std::vector<Feature> mvFeatures;
     SE3 mT_c2w;
+    Image8 mDynamicMask;                          // include/Frame.h mDynamicMask: moving-object mask (optional; empty = none)
     dsdtm_frame* mDev = nullptr;                  // the image pyramid, resident on the device (optional)
     const SE3& Get_Pose() const { return mT_c2w; }
     void Set_Pose(const SE3& T) { mT_c2w = T; }   // src/Frame.cpp:167-174
@@ -451,12 +452,19 @@ public:
         Corners corners;
         corners.reserve(G);
         for (size_t k = 0; k < G; ++k) corners.push_back(Corner(cx[k], cy[k], score[k], cl[k], 0.0f));
-        std::stable_sort(corners.begin(), corners.end());                                        // :110
+        std::stable_sort(corners.begin(), corners.end());                                        // :110 (std::sort there: ties unordered)
         Image8 mask(mImg_width, mImg_height);                                                    // src/Frame.cpp:64
         std::fill(mask.data.begin(), mask.data.end(), 255);
-        if (!frame->mvFeatures.empty())                                                          // :119-122, Frame::Set_Mask
+        if (!frame->mvFeatures.empty()) {                                                        // :119-122, Frame::Set_Mask
             for (const Feature& f : frame->mvFeatures)
                 if (f.mbInitial) FillCircle(mask, (int)std::lround(f.mpx_x), (int)std::lround(f.mpx_y), Config::Min_dist(), 0);
+            // src/Frame.cpp:294-296: threshold(mDynamicMask, 200) and the saturating mImgMask - mDynamicMask
+            const Image8& dyn = frame->mDynamicMask;
+            if (dyn.cols == mask.cols && dyn.rows == mask.rows)
+                for (int y = 0; y < mask.rows; ++y)
+                    for (int x = 0; x < mask.cols; ++x)
+                        if (dyn.data[(size_t)y * dyn.step + x] > 200) mask.data[(size_t)y * mask.step + x] = 0;
+        }
         for (const Corner& c : corners) {                                                        // :124-150
             if (c.score > 20) {
                 if (mask.data[(size_t)c.y * mask.step + c.x] != 255) continue;                   // :139

@@ -107,3 +107,33 @@ def test_detect_like_keyframe_creation(gpu_ctx, oracle):
     got = [(int(fr.px[60 + i, 0]), int(fr.px[60 + i, 1]), int(fr.level[60 + i])) for i in range(n_new)]
     assert got == want and 20 < n_new <= det.mMax_fts - 60
     assert fr.n_features == 60 + n_new
+
+
+def test_detect_honours_the_moving_object_mask(gpu_ctx):
+    """Frame::Set_Mask (src/Frame.cpp:286-298) subtracts the thresholded moving-object mask from the image mask
+    before detect() tests `mask != 255`: no new feature inside the masked region, the same features elsewhere
+    (Max_fts lifted so that the comparison is not cut short)."""
+    from dsdtm_amd.feature_detection import Feature_detector
+    from dsdtm_amd.frame import Frame
+    img = np.clip(np.rint(synth.make_texture(480, 640, 77)), 0, 255).astype(np.uint8)
+    pyr = synth.build_pyramid(img, 5)
+    ex = np.array([[100.0, 100.0]], np.float32)                  # one tracked feature: Set_Mask only runs with features
+    out = []
+    for masked in (False, True):
+        det = Feature_detector(640, 480, ctx=gpu_ctx)
+        det.mMax_fts = 10 ** 6
+        fr = Frame(synth.Camera.tum(640, 480), pyr)
+        fr.set_features(ex, np.zeros((1, 3)), np.zeros((1, 3)), np.ones(1, np.uint8))
+        if masked:
+            fr.mDynamicMask = np.zeros((480, 640), np.uint8)
+            fr.mDynamicMask[100:300, 200:500] = 255
+            fr.mDynamicMask[0:50, 0:50] = 150                    # below the threshold of 200: not masked
+        det.detect(fr, 5.0)
+        out.append({(int(x), int(y)) for x, y in fr.px[1:]})
+    inside = {(x, y) for x, y in out[0] if 200 <= x < 500 and 100 <= y < 300}
+    assert len(inside) > 10 and not any(200 <= x < 500 and 100 <= y < 300 for x, y in out[1])
+    # every feature outside the region is still found; the only additions are corners next to the region that a
+    # disc (radius CellSize) of a now-rejected corner used to suppress
+    assert out[0] - inside <= out[1]
+    extra = out[1] - out[0]
+    assert all(200 - 26 <= x < 500 + 26 and 100 - 26 <= y < 300 + 26 for x, y in extra) and len(extra) < 20

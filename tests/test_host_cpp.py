@@ -44,7 +44,8 @@ def dump_scene(path, sc, params, min_fts, border, patch, px0):
 
 
 def test_cpp_host_layer_builds_against_the_c_abi():
-    assert all(os.path.exists(build_example(n)) for n in ("example_align", "example_search", "example_pose_opt", "example_rgbd"))
+    assert all(os.path.exists(build_example(n)) for n in ("example_align", "example_search", "example_pose_opt", "example_rgbd",
+                                                          "example_track"))
 
 
 @pytest.mark.gpu
@@ -84,9 +85,9 @@ def test_cpp_driver_matches_oracle(tmp_path, oracle):
     assert [tuple(det[1 + 3 * i:4 + 3 * i]) for i in range(det[0])] == want_det
 
 
-def dump_world(path, cam, kfs, cur, mps, levels, cell, max_levels):
+def dump_world(path, cam, kfs, cur, mps, levels, cell, max_levels, frames=()):
     with open(path, "wb") as f:
-        f.write(struct.pack("<8i", levels, len(kfs), len(mps), cam.width, cam.height, cell, max_levels, 0))
+        f.write(struct.pack("<8i", levels, len(kfs), len(mps), cam.width, cam.height, cell, max_levels, len(frames)))
         f.write(struct.pack("<5f", cam.fx, cam.fy, cam.cx, cam.cy, cam.f))
         for fr in list(kfs) + [cur]:
             f.write(np.ascontiguousarray(fr.Get_Pose(), "<f8").tobytes())
@@ -99,6 +100,8 @@ def dump_world(path, cam, kfs, cur, mps, levels, cell, max_levels):
             f.write(np.asarray(mp.mPose, "<f8").tobytes() + struct.pack("<3i", mp.mnFound, int(mp.mbBad), len(mp.mObservations)))
             for k in sorted(mp.mObservations):
                 f.write(struct.pack("<2i", k, mp.mObservations[k]))
+        for img in frames:                                   # example_track: level-0 images of the frames to track
+            f.write(np.ascontiguousarray(img, np.uint8).tobytes())
 
 
 @pytest.mark.gpu
@@ -163,3 +166,69 @@ def test_cpp_pose_optimization_matches_the_python_mirror(tmp_path, gpu_ctx):
     assert np.array_equal(np.array([float(v) for v in out[1].split()[1:]]), fr.Get_Pose().reshape(12))
     assert [tuple(int(v) for v in l.split()) for l in out[2:2 + n]] == [(mp.mnFound, int(mp.mbBad)) for mp in mps]
     assert sum(mp.mbBad for mp in mps) > 15                      # the walk erased something
+
+
+@pytest.mark.gpu
+def test_cpp_tracked_sequence_matches_the_python_mirror(tmp_path, gpu_ctx):
+    """The tracked-frame loop (Run -> ResetGrid / ReprojectPoint / SearchLocalPoints -> PoseOptimization, every
+    frame the reference of the next; src/Tracking.cpp:199-246) through the C++ classes of dsdtm_host.hpp against
+    the same loop through the Python mirror (itself held to the oracle chain in test_tracking_sequence_gpu.py):
+    six frames, same library underneath — tracked counts, match sets, refinement summaries and every map-point
+    counter agree exactly, poses to rounding of the host-side projections."""
+    import copy
+    from dsdtm_amd import search
+    from dsdtm_amd.frame import Config, Frame
+    from dsdtm_amd.optimizer import Optimizer
+    from dsdtm_amd.sparse_align import Sprase_ImgAlign
+    from tests.test_search_gpu import make_world
+    exe = build_example("example_track")
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    n_kf, n_frames = 2, 6
+    cam, kfs, cur0, mps = make_world(33, n_points=600, n_kf=n_kf)
+    tex = synth.make_texture(cam.height, cam.width, 33)
+    rng = np.random.default_rng(5)
+    T0 = np.vstack([kfs[-1].Get_Pose(), [0, 0, 0, 1]])
+    imgs, xi = [], np.zeros(6)
+    for k in range(n_frames):
+        xi = xi + np.concatenate([rng.uniform(-0.012, 0.012, 3), rng.uniform(-0.006, 0.006, 3)])
+        imgs.append(synth.warp_plane(tex, cam, synth.se3_exp(xi) @ T0, 2.0))
+    world = tmp_path / "world.bin"
+    dump_world(world, cam, kfs, cur0, mps, 5, 25, 5, frames=imgs)
+    out = subprocess.run([exe, str(world)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == 4 * n_frames
+    # the Python mirror on the same world
+    for k, kf in enumerate(kfs):
+        mpts = [None] * kf.n_features
+        for mp in mps:
+            if k in mp.mObservations:
+                mpts[mp.mObservations[k]] = mp
+        kf.mvMapPoints = mpts
+        kf.p_world = np.array([m.mPose if m is not None else np.zeros(3) for m in mpts])
+        kf.initial = np.array([1 if m is not None else 0 for m in mpts], np.uint8)
+    al = Sprase_ImgAlign(5, 0, 8, ctx=gpu_ctx, resident_frames=True)
+    srch = search.LocalPointSearch(cam, ctx=gpu_ctx, resident_frames=True)
+    idx = {id(mp): i for i, mp in enumerate(mps)}
+    last = kfs[-1]
+    for k in range(n_frames):
+        cur = Frame(cam, synth.build_pyramid(imgs[k], 5), last.Get_Pose())
+        n = al.Run(cur, last)
+        t = out[4 * k].split()
+        assert (int(t[1]), int(t[3])) == (k, n) and n >= 40
+        assert np.allclose([float(v) for v in t[5:17]], cur.Get_Pose().reshape(12), rtol=0, atol=1e-9)
+        srch.ResetGrid()
+        for mp in mps:
+            if not mp.IsBad():
+                srch.ReprojectPoint(cur, mp)
+        got = srch.SearchLocalPoints(cur, kfs)
+        t = out[4 * k + 1].split()
+        assert int(t[1]) == len(got) and len(got) >= 50
+        cpp = [(int(t[2 + 5 * i]), int(t[3 + 5 * i]), int(t[4 + 5 * i])) for i in range(len(got))]
+        assert cpp == [(g[0], idx[id(g[1])], g[3]) for g in got]
+        cpx = np.array([[float(t[5 + 5 * i]), float(t[6 + 5 * i])] for i in range(len(got))])
+        assert np.abs(cpx - np.array([g[2] for g in got])).max() < 1e-3
+        sm = Optimizer.PoseOptimization(cur, ctx=gpu_ctx)
+        t = out[4 * k + 2].split()
+        assert (int(t[1]), int(t[2])) == (sm["iterations"], sm["termination"])
+        assert np.allclose([float(v) for v in t[4:16]], cur.Get_Pose().reshape(12), rtol=0, atol=1e-9)
+        assert out[4 * k + 3].split()[1:] == [f"{mp.mnFound}{'b' if mp.mbBad else ''}" for mp in mps]
+        last = cur

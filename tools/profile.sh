@@ -1,14 +1,32 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/*: kernel trace + stats, then one counter group per pass
-# (never --pmc together with other trace domains). Usage on the GPU box: tools/profile.sh <outdir-under-gpurun_out>
-set -e
+# rocprofv3 passes behind profiles/r02_*: kernel trace + stats, then one counter group per pass (never --pmc
+# together with other trace domains). Usage on the GPU box: tools/profile.sh <outdir-under-gpurun_out>
+# Each "case" is one bench command line; cases: main (default: 4 launch streams), solo (one stream), n1000, n2000,
+# and the secondary kernels (tools/kernels.py: pyrDown, Align2D).
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/${1:-prof}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="$REPO/bench.py --steps 200 --warmup 20 --no-cpu"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $B > "$OUT/trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $B > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $B > "$OUT/pmc_write.log" 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq" -- python3 $B > "$OUT/pmc_sq.log" 2>&1
+COMMON="--no-cpu --no-secondary"
+declare -A CASE
+CASE[main]="$REPO/bench.py --steps 200 --warmup 20 $COMMON"
+CASE[solo]="$REPO/bench.py --steps 200 --warmup 20 --streams 1 $COMMON"
+CASE[n1000]="$REPO/bench.py --patches 1000 --steps 20 --warmup 3 --streams 1 $COMMON"
+CASE[n2000]="$REPO/bench.py --width 1280 --height 960 --patches 2000 --pairs 256 --steps 20 --warmup 3 --streams 1 $COMMON"
+CASE[kernels]="$REPO/tools/kernels.py"
+for c in main solo n1000 n2000 kernels; do
+  mkdir -p "$OUT/$c"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$c/trace" -- python3 ${CASE[$c]} > "$OUT/$c/trace.log" 2>&1 || echo "trace $c failed"
+  echo "traced $c"
+done
+for c in solo n1000 n2000 kernels; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$c/pmc_fetch" -- python3 ${CASE[$c]} > "$OUT/$c/pmc_fetch.log" 2>&1 || echo "pmc fetch $c failed"
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$c/pmc_write" -- python3 ${CASE[$c]} > "$OUT/$c/pmc_write.log" 2>&1 || echo "pmc write $c failed"
+  echo "counted $c"
+done
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/solo/pmc_sq" -- python3 ${CASE[solo]} > "$OUT/solo/pmc_sq.log" 2>&1 || echo "pmc sq failed"
+# keep the merge-back small: the per-dispatch CSVs of the long runs are summarised on the box
+cd "$REPO"
+python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
+find "$OUT" -name "*_agent_info.csv" -delete
 echo profdone

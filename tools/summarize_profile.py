@@ -1,41 +1,83 @@
-"""Folds the rocprofv3 output of tools/profile.sh / tools/pose_opt_profile.sh (kernel-trace stats + one
---pmc pass per counter group) into the per-dispatch summary kept under profiles/.
-Usage: python tools/summarize_profile.py gpurun_out/<dir> <kernel name substring>[,<substring>...] profiles/<out>.json
-       "<version note>" "<command note>" [<substring>=<algorithmic bytes per launch> ...]
-For every kernel given with its algorithmic bytes an entry of "hbm_traffic_per_launch" is written (what bench.py's
-roofline.traffic reads): FETCH_SIZE and WRITE_SIZE are KiB per dispatch; FETCH_SIZE x 2 is the gfx950 correction
-of /opt/skills/guides/MI355X_MICROARCH.md (128-B requests tallied at 64 B)."""
-import collections, csv, glob, json, sys
+"""Folds the rocprofv3 output of tools/profile.sh (per case: kernel-trace stats, kernel trace, one --pmc pass per
+counter group) into the summaries kept under profiles/:
+    <out>/r02_kernel_stats.csv     per case and kernel: calls, average / min / max duration
+    <out>/r02_bench_pmc.json       per case and kernel: counters per dispatch + "hbm_traffic_per_launch" entries (what
+                                   bench.py's roofline.traffic reads): FETCH_SIZE and WRITE_SIZE are KiB per dispatch;
+                                   FETCH_SIZE x 2 is the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md
+                                   (128-B requests tallied at 64 B)
+    <out>/r02_overlap.json         case "main" (several launch streams): begin/end of every dispatch of the alignment
+                                   kernel -> launches in flight, union span per launch (= the effective time per step)
+Usage: python tools/summarize_profile.py gpurun_out/<dir>"""
+import collections, csv, glob, json, os, sys
 
-src, kerns, out, version, command = sys.argv[1:6]
-alg = dict(a.split("=") for a in sys.argv[6:])
-res = {"round": 2, "version": version, "command": command, "kernels": {}, "hbm_traffic_per_launch": []}
-for kern in kerns.split(","):
-    k = {}
-    for f in glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True):
+src = sys.argv[1]
+ALG = {   # case -> (kernel substring, algorithmic bytes per launch, dispatches per launch)
+    "solo": ("sparse_align_reg_kernel", 1024 * 833392, 1),
+    "n1000": ("sparse_align", 1024 * 873292, 1),
+    "n2000": ("sparse_align", 256 * 3378292, 1),
+    "kernels": ("pyrdown_kernel", 2048 * 504000, 3),
+}
+stats_rows, pmc = [], {"round": 2, "command": "tools/profile.sh (see the file for every command line)", "cases": {}, "hbm_traffic_per_launch": []}
+for case in sorted(os.listdir(src)):
+    d = os.path.join(src, case)
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(f"{d}/trace/**/*_kernel_stats.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if kern in r["Name"]:
-                k["kernel"] = r["Name"]
-                k["kernel_trace"] = dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), min_ns=float(r["MinNs"]), max_ns=float(r["MaxNs"]))
-    ctr = collections.defaultdict(list)
-    for f in glob.glob(f"{src}/pmc_*/**/*_counter_collection.csv", recursive=True):
+            stats_rows.append(dict(case=case, kernel=r["Name"], calls=r["Calls"], avg_ns=r["AverageNs"], min_ns=r["MinNs"],
+                                   max_ns=r["MaxNs"], total_ns=r["TotalDurationNs"], percent=r["Percentage"]))
+    ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+    launch = {}
+    for f in glob.glob(f"{d}/pmc_*/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if kern in r["Kernel_Name"]:
-                ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                k.setdefault("kernel", r["Kernel_Name"])
-                k["launch"] = dict(grid=r["Grid_Size"], workgroup=r["Workgroup_Size"], lds_bytes=r["LDS_Block_Size"],
-                                   scratch=r["Scratch_Size"], vgpr_count_field=r["VGPR_Count"])
-    k["counters"] = {c: dict(dispatches=len(v), mean_per_dispatch=sum(v) / len(v)) for c, v in sorted(ctr.items())}
-    res["kernels"][kern] = k
-    if kern in alg and "FETCH_SIZE" in k["counters"] and "WRITE_SIZE" in k["counters"]:
-        fetch = k["counters"]["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0
-        write = k["counters"]["WRITE_SIZE"]["mean_per_dispatch"] * 1024.0
-        res["hbm_traffic_per_launch"].append(dict(
-            kernel=k["kernel"], algorithmic_bytes_per_launch=int(alg[kern]), fetch_bytes_raw=fetch,
-            fetch_bytes_gfx950_corrected=2.0 * fetch, write_bytes=write,
-            traffic_over_algorithmic=(2.0 * fetch + write) / float(alg[kern])))
-json.dump(res, open(out, "w"), indent=1)
-for kern, k in res["kernels"].items():
-    print(kern, json.dumps({x: k.get(x) for x in ("kernel_trace", "launch")}))
-    print({c: round(v["mean_per_dispatch"], 1) for c, v in k["counters"].items()})
-print(json.dumps(res["hbm_traffic_per_launch"], indent=1))
+            k = r["Kernel_Name"]
+            ctr[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            launch[k] = dict(grid=r["Grid_Size"], workgroup=r["Workgroup_Size"], lds_bytes=r["LDS_Block_Size"],
+                             scratch=r["Scratch_Size"], vgpr_count_field=r["VGPR_Count"])
+    if ctr:
+        pmc["cases"][case] = {k: dict(launch=launch[k], counters={c: dict(dispatches=len(v), mean_per_dispatch=sum(v) / len(v))
+                                                                      for c, v in sorted(cs.items())}) for k, cs in ctr.items()}
+    if case in ALG:
+        sub, alg, nd = ALG[case]
+        for k, cs in ctr.items():
+            if sub in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024.0 * nd
+                write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024.0 * nd
+                pmc["hbm_traffic_per_launch"].append(dict(
+                    case=case, kernel=k, dispatches_per_launch=nd, algorithmic_bytes_per_launch=alg, fetch_bytes_raw=fetch,
+                    fetch_bytes_gfx950_corrected=2.0 * fetch, write_bytes=write,
+                    traffic_over_algorithmic=(2.0 * fetch + write) / alg))
+with open(os.path.join(src, "r02_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=["case", "kernel", "calls", "avg_ns", "min_ns", "max_ns", "total_ns", "percent"])
+    w.writeheader()
+    w.writerows(stats_rows)
+json.dump(pmc, open(os.path.join(src, "r02_bench_pmc.json"), "w"), indent=1)
+
+# overlap of consecutive launches on several streams (case main)
+ov = {}
+for f in glob.glob(f"{src}/main/trace/**/*_kernel_trace.csv", recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if "sparse_align_reg_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = rows[20:]                                  # the bench's warm-up launches
+    if len(rows) < 10:
+        continue
+    st = [int(r["Start_Timestamp"]) for r in rows]
+    en = [int(r["End_Timestamp"]) for r in rows]
+    events = sorted([(t, 1) for t in st] + [(t, -1) for t in en])
+    busy, depth, last, weighted = 0, 0, events[0][0], 0
+    for t, dlt in events:
+        if depth > 0:
+            busy += t - last
+            weighted += (t - last) * depth
+        depth += dlt
+        last = t
+    ov = dict(launches=len(rows), streams=len({r.get("Stream_Id", r.get("Queue_Id")) for r in rows}),
+              own_duration_avg_ns=sum(e - s for s, e in zip(st, en)) / len(rows),
+              union_span_ns=busy, union_span_per_launch_ns=busy / len(rows), launches_in_flight_avg=weighted / busy,
+              first_start=st[0], last_end=max(en), wall_per_launch_ns=(max(en) - st[0]) / len(rows))
+json.dump(ov, open(os.path.join(src, "r02_overlap.json"), "w"), indent=1)
+print(json.dumps(ov, indent=1))
+print(json.dumps(pmc["hbm_traffic_per_launch"], indent=1))
+for r in stats_rows:
+    if float(r["percent"]) > 1.0:
+        print(r["case"], r["kernel"][:70], r["calls"], r["avg_ns"])
