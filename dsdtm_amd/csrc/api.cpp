@@ -197,6 +197,7 @@ static int validate_params(dsdtm_ctx* ctx, const dsdtm_align_params* p, int leve
 
 static thread_local void* g_stamp_out = nullptr;   // device buffer, set only by the stamps debug entry
 static thread_local unsigned* g_timeout_out = nullptr;   // host-mapped word, set by the single-pair entry points
+static thread_local int g_team_drop_members = 0;         // set only by dsdtm_debug_sparse_align_short_team
 
 extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam,
                                                const dsdtm_align_params* prm, void* hip_stream) {
@@ -281,7 +282,8 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         uint8_t* slot = ctx->d_team + (size_t)(ctx->team_seq++ & 7u) * sparse_align_team_bytes(64);
         a.workspace = (double*)slot;
         HIP_TRY(ctx, hipMemsetAsync(slot, 0, sparse_align_team_bytes(b->n_pairs), stream));
-        HIP_TRY(ctx, sparse_align_launch_team(a, k, stream));
+        if (g_team_drop_members) a.spin_limit = 1u << 12;      // the test's waits give up after ~4 k polls
+        HIP_TRY(ctx, sparse_align_launch_team(a, k, stream, g_team_drop_members));
         if (stream != ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->team_event, stream));
         ctx->team_any = true; ctx->team_last_stream = stream;
         return DSDTM_OK;
@@ -1042,6 +1044,18 @@ extern "C" int dsdtm_debug_sparse_align_stamps(dsdtm_ctx* ctx, const dsdtm_batch
     g_stamp_out = stamps_dev;
     const int rc = dsdtm_sparse_align_batch_device(ctx, b, cam, prm, hip_stream);
     g_stamp_out = nullptr;
+    return rc;
+}
+
+// ---- debug: a team launch whose last member is missing (not in the public header) ----------------
+// The members that do run wait for a partner that never arrives: their bounded waits must run out, the pair must
+// stop without hanging the device, and dsdtm_sparse_align_check must report it (tests/test_sparse_align_gpu.py).
+extern "C" int dsdtm_debug_sparse_align_short_team(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam,
+                                                   const dsdtm_align_params* prm, void* hip_stream) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    g_team_drop_members = 1;
+    const int rc = dsdtm_sparse_align_batch_device(ctx, b, cam, prm, hip_stream);
+    g_team_drop_members = 0;
     return rc;
 }
 

@@ -29,6 +29,7 @@ struct SAKernelArgs {
     double* workspace;
     unsigned* pair_counter;     // device word, zeroed before each launch: next pair index for the persistent slots
     unsigned* timeout_out;      // optional (host-mapped) word: receives the hand-over timeout flag when a pair ends
+    unsigned spin_limit;        // team kernel: polls before a wait gives up (0 = the default, 2^24); tests shorten it
     unsigned long long pyr_pitch;
     int n_pairs, max_features;
     int max_level, min_level, max_iters, min_fts;
@@ -61,7 +62,8 @@ hipError_t sparse_align_clear_timeout_flag();
 // team kernel (one pair over K workgroups, 704 < N <= 4096, few pairs): K or 0; bytes of the zeroed team buffers
 int sparse_align_team_size(int n_pairs, int max_features, int num_cus);
 size_t sparse_align_team_bytes(int n_pairs);
-hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream);
+// drop_members > 0 (tests only): the last members of every team are not launched, so the others' waits run out
+hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream, int drop_members = 0);
 int sparse_align_occupancy(int variant);   // occupancy API answer (workgroups per CU)
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream);
 

@@ -1536,6 +1536,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
         SAKernelArgs am = a;
         if (member != 0) am.stats = nullptr;
         unsigned g = 0;                                                  // iterations so far, over all levels
+        const unsigned spin_limit = a.spin_limit ? a.spin_limit : SPIN_LIMIT;
         if (k < K)                                                       // absent members contribute zeros
             for (int i = lane; i < (K - k) * WPD; i += 64) ((unsigned long long*)&s_mpart[k])[i] = 0ull;
         solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
@@ -1596,10 +1597,10 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
                             else ((unsigned long long*)s_mpart)[i] = (w0 & 0xffffffffull) | (w1 << 32);
                         }
                         if (__ballot(pending) == 0ull) break;
-                        if (++spins >= SPIN_LIMIT) break;
+                        if (++spins >= spin_limit) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    const bool ok = spins < SPIN_LIMIT;
+                    const bool ok = spins < spin_limit;
                     if (!ok) spin_timeout();
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
@@ -1680,9 +1681,10 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
     }
 }
 
+static thread_local int g_team_drop = 0;      // tests only (sparse_align_launch_team's drop_members)
 template <int K, int NPW>
 static hipError_t launch_team(const SAKernelArgs& args, int pairs_pad, int k, hipStream_t stream) {
-    hipLaunchKernelGGL((sparse_align_team_kernel<K, NPW>), dim3((unsigned)(pairs_pad * k)), dim3((NPW + 1) * 64), 0, stream, args, pairs_pad, k);
+    hipLaunchKernelGGL((sparse_align_team_kernel<K, NPW>), dim3((unsigned)(pairs_pad * (k - g_team_drop))), dim3((NPW + 1) * 64), 0, stream, args, pairs_pad, k);
     return hipGetLastError();
 }
 
@@ -1720,10 +1722,13 @@ static hipError_t launch_team_k(const SAKernelArgs& args, int k, int pairs_pad, 
     }
 }
 
-hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream) {
+hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream, int drop_members) {
     if (args.n_pairs <= 0) return hipSuccess;
-    if (k < 2 || k > TEAM_MAX_MEMBERS) return hipErrorInvalidValue;
-    return launch_team_k<2>(args, k, team_pairs_pad(args.n_pairs, k), stream);
+    if (k < 2 || k > TEAM_MAX_MEMBERS || drop_members < 0 || drop_members >= k) return hipErrorInvalidValue;
+    g_team_drop = drop_members;
+    const hipError_t e = launch_team_k<2>(args, k, team_pairs_pad(args.n_pairs, k), stream);
+    g_team_drop = 0;
+    return e;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -685,3 +685,36 @@ def test_large_teams_have_no_feature_count_cliff(gpu_ctx, oracle, N):
         if T1 is not None:
             assert np.array_equal(T1, Tg)                          # bit-identical from launch to launch
         T1 = Tg
+
+
+def test_a_wait_that_runs_out_becomes_an_error_not_a_hang(gpu_ctx, oracle):
+    """The kernels' waits on partners are bounded: a debug entry launches teams whose last member is missing, so
+    the members that run can never complete an exchange. They must give up, stop the pair, let the kernel end,
+    and dsdtm_sparse_align_check must turn the device flag into DSDTM_ERR_HIP — once; the next, ordinary launch
+    on the same context is clean and correct again."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N = 320, 240, 3, 600
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=1300 + i, margin=12) for i in range(2)]
+    t, b = _device_batch(torch, dev, scenes, L, W, Hh)
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    f = gpu_ctx.lib.dsdtm_debug_sparse_align_short_team
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.POINTER(capi.BatchDesc), C.POINTER(capi.Camera), C.POINTER(capi.AlignParams), C.c_void_p]
+    st = torch.cuda.Stream(device=dev)
+    gpu_ctx.check(f(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+    rc = gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, st.cuda_stream)          # returns: the kernel did end
+    assert rc == capi.ERR_HIP and b"timed out" in gpu_ctx.lib.dsdtm_last_error(gpu_ctx.handle)
+    assert gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, st.cuda_stream) == capi.OK   # the flag was cleared
+    t["Tc"].copy_(torch.from_numpy(np.stack([s.T_cur_w_seed.reshape(12) for s in scenes])).to(dev))
+    torch.cuda.synchronize()
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, st.cuda_stream))
+    Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+    for i, sc in enumerate(scenes):
+        To, no, _ = oracle.sparse_align(sc, L, 0, 10)
+        H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"after the timeout, pair {i}")
+        assert ntg[i] == no
