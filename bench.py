@@ -316,9 +316,6 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
         prm = capi.AlignParams(args.levels, 0, args.iters, 15)
         d = build_batch(torch, dev, ctx, cam, n_pairs, width, height, args.levels, n_patches, seed=0xC0DE + n_patches, stream=stream)
         desc = d["desc"]
-        ws_bytes = ctx.lib.dsdtm_sparse_align_workspace_bytes(C.byref(desc))
-        if ws_bytes:
-            ctx.check(ctx.lib.dsdtm_reserve(ctx.handle, ws_bytes))
 
         def launch(s, d=d, desc=desc, cs=cs, prm=prm):
             d["T_cur_w"].copy_(d["T_seed"])
@@ -498,9 +495,6 @@ def main():
     d = build_batch(torch, dev, ctx, cam, args.pairs, args.width, args.height, args.levels, args.patches,
                     seed=shard.batch_seed(0xD5D7, rank), stream=stream)
     desc = d["desc"]
-    ws_bytes = ctx.lib.dsdtm_sparse_align_workspace_bytes(C.byref(desc))
-    if ws_bytes:
-        ctx.check(ctx.lib.dsdtm_reserve(ctx.handle, ws_bytes))
 
     # The pose argument is in/out (seed in, result out: Tracking seeds cur.pose = last.pose, src/Tracking.cpp:201).
     # Every step gets its own copy of the seed poses, resident in HBM before the timed region like the rest

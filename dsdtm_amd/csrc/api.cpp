@@ -37,7 +37,7 @@ struct dsdtm_ctx {
     //  * a launch captured into a hipGraph gets a word of its own from the graph pool, for the life of the
     //    context, and a memset node in front of it (a hipGraphExec never overlaps itself).
     unsigned* d_counter = nullptr;
-    struct StreamRing { hipStream_t stream; unsigned seq; bool used; };
+    struct StreamRing { hipStream_t stream; unsigned seq; bool used; void* d_ws; size_t ws_cap; };   // + the stream's workspace
     static constexpr int MAX_STREAMS = 16, COUNTERS_PER_STREAM = 8, GRAPH_COUNTERS = 256;
     StreamRing rings[MAX_STREAMS] = {};
     int graph_counters_used = 0;
@@ -142,6 +142,7 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    for (auto& r : ctx->rings) if (r.d_ws) (void)hipFree(r.d_ws);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->d_team) (void)hipFree(ctx->d_team);
     if (ctx->team_event) (void)hipEventDestroy(ctx->team_event);
@@ -234,6 +235,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy; a.f = cam->f;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)hip_stream;
+    int ring = -1;                                     // this stream's entry of ctx->rings (not while capturing)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     // the word the launch's persistent slots pull pair indices from (see dsdtm_ctx::d_counter)
@@ -250,12 +252,13 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
             if (ctx->rings[i].used && ctx->rings[i].stream == stream) ri = i;
         for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
-            if (!ctx->rings[i].used) { ctx->rings[i].used = true; ctx->rings[i].stream = stream; ctx->rings[i].seq = 0; ri = i; }
+            if (!ctx->rings[i].used) { ctx->rings[i] = dsdtm_ctx::StreamRing{stream, 0u, true, nullptr, 0}; ri = i; }
         if (ri < 0) {
             set_err(ctx, "more than %d streams launch through one context: use one context per group of streams", dsdtm_ctx::MAX_STREAMS);
             return DSDTM_ERR_INVALID;
         }
         a.pair_counter = ctx->d_counter + ri * dsdtm_ctx::COUNTERS_PER_STREAM + (ctx->rings[ri].seq++ % dsdtm_ctx::COUNTERS_PER_STREAM);
+        ring = ri;
     }
     a.timeout_out = g_timeout_out;
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
@@ -291,14 +294,25 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     const SAVariant v = sparse_align_pick_variant(b->max_features);
     const size_t ws = sparse_align_workspace_bytes(b->n_pairs, b->max_features);
     if (ws) {
-        if (ws > ctx->ws_cap) {
-            if (capturing) {
+        // Scratch of the workspace kernel. A live launch uses its STREAM's workspace (the stream runs its launches
+        // in order, so launches on different streams never share scratch; grown on demand, which synchronises that
+        // stream once). A captured launch cannot allocate: it uses the context's reserved workspace (dsdtm_reserve),
+        // which graph replays then share — replays of graphs captured through one context must not overlap.
+        if (capturing) {
+            if (ws > ctx->ws_cap) {
                 set_err(ctx, "workspace of %zu bytes needed: call dsdtm_reserve before capturing", ws);
                 return DSDTM_ERR_INVALID;
             }
-            if (int rc = dsdtm_reserve(ctx, ws)) return rc;
+            a.workspace = (double*)ctx->d_ws;
+        } else {
+            dsdtm_ctx::StreamRing& r = ctx->rings[ring];
+            if (ws > r.ws_cap) {
+                if (r.d_ws) { HIP_TRY(ctx, hipStreamSynchronize(stream)); (void)hipFree(r.d_ws); r.d_ws = nullptr; r.ws_cap = 0; }
+                HIP_TRY(ctx, hipMalloc(&r.d_ws, ws));
+                r.ws_cap = ws;
+            }
+            a.workspace = (double*)r.d_ws;
         }
-        a.workspace = (double*)ctx->d_ws;
     }
     HIP_TRY(ctx, sparse_align_launch(a, v, ctx->num_cus, stream));
     return DSDTM_OK;

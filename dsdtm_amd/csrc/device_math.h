@@ -562,6 +562,49 @@ __device__ __forceinline__ double row_sum16(double v) {
     return v;
 }
 
+// EIGHT values summed over the 16 lanes of each DPP row in one butterfly that halves the number of live values
+// at every step (a "transpose-reduce"): lanes pair up by lane bit 0, 1, 3 and 2 in turn; at each of the first
+// three steps a lane keeps one half of its values, sends the other half to its partner and adds what it
+// receives. 8 + 4 + 2 + 1 = 15 additions... per lane 4 + 2 + 1 + 1 = 8 instead of the 8 x 4 = 32 of eight
+// separate row_sum16 calls, and 18 DPP moves instead of 64 (FP64 has no DPP form: every exchanged double costs
+// two v_mov_dpp). Returns, in EVERY lane, the row total of value index
+//     row_reduce8_index(lane) = 4 * bit0 + 2 * bit1 + bit3        (lanes L and L ^ 4 hold the same total)
+// Fixed pairing order: deterministic, independent of timing.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_f64(double v) {      // quad_perm / row_ror: every lane has a source lane
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_xor4_f64(double v) {      // lane L <- lane L ^ 4: row_shl:4 into banks 0,2 and row_shr:4 into banks 1,3
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int l2 = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0x5, false);
+    l2 = __builtin_amdgcn_update_dpp(l2, lo, 0x114, 0xf, 0xa, false);
+    int h2 = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0x5, false);
+    h2 = __builtin_amdgcn_update_dpp(h2, hi, 0x114, 0xf, 0xa, false);
+    return __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ int row_reduce8_index(int lane) { return ((lane & 1) << 2) | (lane & 2) | ((lane >> 3) & 1); }
+__device__ __forceinline__ double row_reduce8(const double* v, int lane) {
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b3 = (lane & 8) != 0;
+    double w[4], u[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double keep = b0 ? v[4 + j] : v[j], send = b0 ? v[j] : v[4 + j];
+        w[j] = keep + dpp_perm_f64<0xB1>(send);           // quad_perm [1,0,3,2]: lane ^ 1
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double keep = b1 ? w[2 + j] : w[j], send = b1 ? w[j] : w[2 + j];
+        u[j] = keep + dpp_perm_f64<0x4E>(send);           // quad_perm [2,3,0,1]: lane ^ 2
+    }
+    const double keep = b3 ? u[1] : u[0], send = b3 ? u[0] : u[1];
+    double t = keep + dpp_perm_f64<0x128>(send);          // row_ror:8: lane ^ 8
+    t += dpp_xor4_f64(t);
+    return t;
+}
+
 // reference implementation of the same sum through the LDS crossbar (used by the self-test)
 __device__ __forceinline__ double wave_sum_shfl(double v) {
 #pragma unroll

@@ -41,7 +41,10 @@ struct PyrDownArgs {
 // ~50 instructions per output row. Threads are numbered linearly over (strip, row chunk), so waves
 // are full whatever the level width (640 px = 80 strips used to leave the second block column at 16
 // of 64 lanes).
-constexpr int PD_ROWS = 8;
+#ifndef SA_PD_ROWS
+#define SA_PD_ROWS 8
+#endif
+constexpr int PD_ROWS = SA_PD_ROWS;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u16x2 pk(uint32_t lo, uint32_t hi) {

@@ -13,7 +13,7 @@ namespace dsdtm {
 // (lane+1)*in[27], out[21] shuffle wave sum of the same, out[22..33] [R|t] of exp(xi) via from_rt(to_rt),
 // out[34..69] H^+ by columns from ldlt6_solve on the unit vectors, out[70..105] the same from ldlt6_hinv_sorted
 // (untouched where it declines), out[106] 1 where it accepted the matrix, out[107..118] dR (9) and dt (3) of
-// se3_exp_matrix_small(xi) (only for |omega|^2 < 0.01), out[119] unused
+// se3_exp_matrix_small(xi) (only for |omega|^2 < 0.01), out[119] max |row_reduce8 - row_sum16| over 8 values of all lanes
 constexpr int SELFTEST_OUT = 120;
 __global__ void selftest_kernel(const double* __restrict__ in, double* __restrict__ out, int n_cases) {
     const int c = blockIdx.x;
@@ -53,11 +53,27 @@ __global__ void selftest_kernel(const double* __restrict__ in, double* __restric
         for (int i = 0; i < 6; ++i) o[34 + lane * 6 + i] = colv[i];
     }
     if (lane < 36) o[70 + lane] = s_hinv[lane];
+    // row_reduce8 against eight row_sum16 calls on lane-dependent values
+    double rr_err;
+    {
+        double v8[8], want = 0.0;
+        const int idx = row_reduce8_index(lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v8[q] = p[q] * (double)(lane + 1) + p[21 + (q % 6)] * (double)(q + 1);
+            const double s16 = row_sum16(v8[q]);
+            want = (q == idx) ? s16 : want;
+        }
+        const double got = row_reduce8(v8, lane);
+        rr_err = fabs(got - want) / fmax(1e-300, fabs(want));
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) rr_err = fmax(rr_err, __shfl_xor(rr_err, o_, 64));
+    }
     if (lane == 63) {
         o[106] = fast_ok ? 1.0 : 0.0;
         for (int i = 0; i < 9; ++i) o[107 + i] = dRm[i];
         for (int i = 0; i < 3; ++i) o[116 + i] = dtm[i];
-        o[119] = 0.0;
+        o[119] = rr_err;
         for (int i = 0; i < 6; ++i) o[i] = x[i];
         o[6] = E.qw; o[7] = E.qx; o[8] = E.qy; o[9] = E.qz; o[10] = E.tx; o[11] = E.ty; o[12] = E.tz;
         o[13] = E2.qw; o[14] = E2.qx; o[15] = E2.qy; o[16] = E2.qz; o[17] = E2.tx; o[18] = E2.ty; o[19] = E2.tz;

@@ -108,6 +108,14 @@ struct BlockState {
 // counters instead. All waves of a workgroup are co-resident, every wait has its producer in
 // flight, and every spin is bounded (a broken protocol ends the kernel instead of hanging the GPU).
 constexpr unsigned SPIN_LIMIT = 1u << 24;
+// Row partials of the register kernel by packed butterflies (row_reduce8: 54 instead of 96 instructions per eight
+// values) instead of one DPP rotation chain per value. Measured (same-box A/B, stamps): no difference — pass 3989 vs
+// 4016 cycles, level-start H block 17 844 vs 17 835 per pair, kernel 0.2350 vs 0.2340 ms: a patch wave issues one
+// instruction per ~8.5 cycles because of FP64 dependency latency, and the seven independent rotation chains fill
+// those gaps for free. Kept as an experiment switch, off by default.
+#ifndef SA_PACKED_REDUCE
+#define SA_PACKED_REDUCE 0
+#endif
 #ifndef SA_SLEEP_ARRIVE
 #define SA_SLEEP_ARRIVE 1   // solver waiting for the patch waves (and for acknowledgements)
 #endif
@@ -391,6 +399,37 @@ __device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs<GT>& P, 
     h.A[0] = A5[0]; h.A[1] = 0.0;   h.A[2] = A5[1]; h.A[3] = A5[2]; h.A[4] = A5[3]; h.A[5] = A5[4];
     h.B[0] = 0.0;   h.B[1] = B5[0]; h.B[2] = B5[1]; h.B[3] = B5[2]; h.B[4] = B5[3]; h.B[5] = B5[4];
     return h;
+}
+
+// entry q (row-major upper triangle, 0..20) by compile-time index; 0 beyond
+template <int Q>
+__device__ __forceinline__ double patch_hess_entry_q(const PatchHess& h) {
+    if constexpr (Q >= 21) return 0.0;
+    else {
+        constexpr int I = Q < 6 ? 0 : Q < 11 ? 1 : Q < 15 ? 2 : Q < 18 ? 3 : Q < 20 ? 4 : 5;
+        constexpr int J = I + (Q - (I * 6 - (I * (I - 1)) / 2));
+        return h.entry<I, J>();
+    }
+}
+// The 21 entries of the per-patch matrix summed over each 16-lane DPP row, three packed butterflies of eight
+// values (row_reduce8): a lane ends up with the row totals of entries 8 g + row_reduce8_index(lane), g = 0..2, and
+// the lanes with bit 2 clear store them.
+template <int G>
+__device__ __forceinline__ void patch_hess_rows_group(const PatchHess& ph, bool use, int lane, double* Hout) {
+    double v[8];
+    v[0] = use ? patch_hess_entry_q<8 * G + 0>(ph) : 0.0; v[1] = use ? patch_hess_entry_q<8 * G + 1>(ph) : 0.0;
+    v[2] = use ? patch_hess_entry_q<8 * G + 2>(ph) : 0.0; v[3] = use ? patch_hess_entry_q<8 * G + 3>(ph) : 0.0;
+    v[4] = use ? patch_hess_entry_q<8 * G + 4>(ph) : 0.0; v[5] = use ? patch_hess_entry_q<8 * G + 5>(ph) : 0.0;
+    v[6] = use ? patch_hess_entry_q<8 * G + 6>(ph) : 0.0; v[7] = use ? patch_hess_entry_q<8 * G + 7>(ph) : 0.0;
+    const double t = row_reduce8(v, lane);
+    const int q = 8 * G + row_reduce8_index(lane);
+    if (!(lane & 4) && q < 21) Hout[q] = t;
+    __builtin_amdgcn_sched_barrier(0);       // one group of eight live at a time
+}
+__device__ __forceinline__ void patch_hess_rows(const PatchHess& ph, bool use, int lane, double* Hout) {
+    patch_hess_rows_group<0>(ph, use, lane, Hout);
+    patch_hess_rows_group<1>(ph, use, lane, Hout);
+    patch_hess_rows_group<2>(ph, use, lane, Hout);
 }
 
 // calls f(q, value) for the 21 upper-triangular entries in row-major order
@@ -1184,12 +1223,16 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 unsigned long long th0 = 0;
                 if (STAMPS) th0 = __builtin_amdgcn_s_memtime();
                 const PatchHess ph = patch_hess_factors<GT>(P, fs);
+#if SA_PACKED_REDUCE
+                patch_hess_rows(ph, P.valid, lane, my_part.H);
+#else
                 double* Hout = my_part.H;
                 patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
                     const double hs = row_sum16(P.valid ? v : 0.0);
                     if (row_writer) Hout[q] = hs;
                     __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
                 });
+#endif
                 pair_signal_arrive(&s.arrive_h, lane);                 // BH
                 if (STAMPS) st_h += __builtin_amdgcn_s_memtime() - th0;
             }
@@ -1206,8 +1249,22 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 const bool vis = residual_patch<GT, NPW * 64>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b,
                                                                               win, &worg);
                 const unsigned long long vmask = __ballot(vis);
-                // reduce to the 16-lane DPP rows only (4 steps instead of 6); the solver's lane-parallel
-                // summation folds the 4*NPW row partials
+                // reduce to the 16-lane DPP rows only; the solver's lane-parallel summation folds the 4*NPW row
+                // partials
+#if SA_PACKED_REDUCE
+                {
+                    // b[0..5] and chi2 in ONE packed butterfly (row_reduce8): the lane holds the row total of value
+                    // row_reduce8_index(lane); doubles 0..6 of a WavePartial are b[0..5], chi2
+                    const double v8[8] = {b[0], b[1], b[2], b[3], b[4], b[5], chi2, 0.0};
+                    const double t = row_reduce8(v8, lane);
+                    const int q = row_reduce8_index(lane);
+                    if (!(lane & 4) && q < 7) ((double*)&my_part)[q] = t;
+                }
+                if (row_writer) {
+                    my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
+                    my_part.n_ref = n_ref_row;
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < 6; ++i) b[i] = row_sum16(b[i]);
                 chi2 = row_sum16(chi2);
@@ -1218,6 +1275,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
                     my_part.n_ref = n_ref_row;
                 }
+#endif
                 if (STAMPS) {
                     tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0;
 #pragma unroll
@@ -1226,12 +1284,16 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 const bool h_changed = (vmask != cached_mask);        // wave-uniform, rare
                 if (h_changed) {
                     const PatchHess ph = patch_hess_factors<GT>(P, fs);
+#if SA_PACKED_REDUCE
+                    patch_hess_rows(ph, vis, lane, my_part.H);
+#else
                     double* Hout = my_part.H;
                     patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
                         const double hs = row_sum16(vis ? v : 0.0);
                         if (row_writer) Hout[q] = hs;
                         __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
                     });
+#endif
                     cached_mask = vmask;
                 }
                 if (row_writer) my_part.h_changed = h_changed ? 1 : 0;

@@ -3,6 +3,8 @@
 //  Test/test_Feature_alignment.cpp:47-86: Align2DGaussNewton on one patch), reading a scene dumped by
 // tests/test_host_cpp.py and printing machine-readable results.
 //   usage: example_align <scene.bin>
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,5 +82,18 @@ int main(int argc, char** argv) {
     std::printf("detected %zu", cur->mvFeatures.size());
     for (const Feature& ft : cur->mvFeatures) std::printf(" %d %d %d", (int)ft.mpx_x, (int)ft.mpx_y, ft.mlevel);
     std::printf("\n");
+    // wall time of Feature_detector::detect through the C++ layer on the resident frame (library call + the
+    // sort / mask / cap bookkeeping of src/Feature_detection.cpp:110-150), median of 21 calls
+    {
+        std::vector<double> ms;
+        for (int rep = 0; rep < 21; ++rep) {
+            cur->mvFeatures.clear();
+            const auto t0 = std::chrono::steady_clock::now();
+            detector.detect(cur.get(), 5.0);
+            ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        std::sort(ms.begin(), ms.end());
+        std::printf("detect_ms %.4f features %zu\n", ms[ms.size() / 2], cur->mvFeatures.size());
+    }
     return 0;
 }

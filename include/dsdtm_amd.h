@@ -310,14 +310,12 @@ int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream);
  * several compute units (few pairs of more than 448 features) are ordered against each other across streams by
  * the library and are not used inside a capture (the single-CU kernels run instead). */
 
-/* Bytes of scratch HBM the batch call needs for `batch` (0 when the register-resident
- * kernel applies: max_features <= 704). The context grows its own workspace on demand OUTSIDE
- * stream capture; call dsdtm_reserve first when the launch is to be captured into a hipGraph.
- * The workspace belongs to the context: launches that use it (max_features > 704) must not be in
- * flight on two streams of one context at the same time — use one context per stream for those.
- * Few pairs of 449..4096 features (n_pairs <= 64 and roughly n_pairs * ceil(max_features / 256) <= 128) need
- * no workspace: each is spread over several compute units that exchange their partial sums through
- * context-owned buffers; this function does not know the device and may over-estimate for those shapes. */
+/* Bytes of scratch HBM the batch call needs for `batch` (0 when a register-resident kernel applies:
+ * max_features <= 704, or few pairs of up to 16 384 features, which are spread over several compute units —
+ * this function does not know the device and may over-estimate for those shapes). A live launch takes the
+ * scratch from its stream's own workspace, which the context grows on demand (launches on different streams
+ * never share scratch). A launch that is being captured into a hipGraph cannot allocate: call dsdtm_reserve
+ * first; captured launches of one context share that reserved workspace, so their replays must not overlap. */
 size_t dsdtm_sparse_align_workspace_bytes(const dsdtm_batch_desc* batch);
 int dsdtm_reserve(dsdtm_ctx* ctx, size_t workspace_bytes);
 

@@ -66,6 +66,7 @@ def test_device_building_blocks(gpu_ctx, oracle):
             assert np.allclose(o[70:106].reshape(6, 6).T @ Hm, np.eye(6), atol=1e-8)
         else:
             assert (o[70:106] == -12345.0).all()
+        assert o[119] < 1e-13                                     # packed row reduction == eight separate row sums (to rounding)
         # the step in matrix form (what the solver publishes first) is the same group element as SE3::exp
         if np.dot(c[30:33], c[30:33]) < 0.01:
             assert np.allclose(o[107:116].reshape(3, 3), T.reshape(3, 4)[:, :3], atol=1e-15)
@@ -718,3 +719,36 @@ def test_a_wait_that_runs_out_becomes_an_error_not_a_hang(gpu_ctx, oracle):
         To, no, _ = oracle.sparse_align(sc, L, 0, 10)
         H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"after the timeout, pair {i}")
         assert ntg[i] == no
+
+
+def test_workspace_launches_in_flight_on_two_streams(gpu_ctx, oracle):
+    """Many pairs of more than 704 features run the workspace kernel, whose scratch belongs to the launch's
+    STREAM: two such launches in flight on two streams of one context do not share it (round 1 had one
+    workspace per context and forbade this)."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N, P = 320, 240, 3, 720, 70
+    base = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=1500 + i, margin=12) for i in range(4)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in base]
+    groups = [[base[(i + g) % 4] for i in range(P)] for g in range(2)]
+    packed = [_device_batch(torch, dev, g, L, W, Hh) for g in groups]
+    cam = capi.camera_struct(base[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    streams = [torch.cuda.Stream(device=dev) for _ in groups]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for (t, b), scs in zip(packed, groups):
+            t["Tc"].copy_(torch.from_numpy(np.stack([s_.T_cur_w_seed.reshape(12) for s_ in scs])).to(dev))
+        torch.cuda.synchronize()
+        for (t, b), st in zip(packed, streams):
+            gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+        for st in streams:
+            gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, st.cuda_stream))
+        for g, (t, b) in enumerate(packed):
+            Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+            for i in range(P):
+                To, no, _ = want[(i + g) % 4]
+                H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"rep {rep} stream {g} pair {i}")
+                assert ntg[i] == no
