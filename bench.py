@@ -417,8 +417,8 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSDTM_BENCH_STREAMS", "4")),
-                    help="HIP streams the steps are issued on in turn (default 4 = HIP's hardware queues): the workgroups "
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSDTM_BENCH_STREAMS", "8")),
+                    help="HIP streams the steps are issued on in turn (default 8 = two per HIP hardware queue): the workgroups "
                          "of step k+1 take the compute units the tail of step k leaves idle (same launches, same "
                          "results); 1 = strictly one launch at a time, with HIP events around every launch")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs timed on the CPU oracle (rank 0, N=1)")

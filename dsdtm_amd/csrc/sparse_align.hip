@@ -1468,12 +1468,8 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
         const bool maskable = npad <= (size_t)PT * 64;                 // one bit per patch of this lane
         for (int it = 0; it < a.max_iters; ++it) {
             double b[6] = {0, 0, 0, 0, 0, 0};
-            double H[21];
-#pragma unroll
-            for (int i = 0; i < 21; ++i) H[i] = 0.0;
             double chi2 = 0.0;
             int cnt = 0;
-            const bool sum_h = (it == 0) || !maskable;
             unsigned long long vis_new = 0ull, bit = 1ull;
             for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
                 PatchRegs<double> P;
@@ -1490,44 +1486,47 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
                     chi2 += c2;
                     cnt += 1;
                     vis_new |= bit;
-                    if (sum_h) {
-                        const PatchHess ph = patch_hess_factors<double>(P, fs);
-                        patch_hess_foreach<0, 0>(ph, [&](int q, double v) { H[q] += v; });
-                    }
                 }
             }
-            bool h_new = sum_h;
-            if (!sum_h && __ballot(vis_new != vis_old) != 0ull) {      // rare: this wave's visible set changed
-                h_new = true;
+            // H is summed in a loop of its own (over the patches the pass found visible), so that its 21
+            // accumulators are not live in the residual loop above: with them there the kernel spilled
+            const bool h_new = (it == 0) || !maskable || __ballot(vis_new != vis_old) != 0ull;
+            vis_old = vis_new;
+            if (h_new) {
+                double H[21];
+#pragma unroll
+                for (int i = 0; i < 21; ++i) H[i] = 0.0;
                 bit = 1ull;
                 for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
-                    if (!(vis_new & bit)) continue;
                     PatchRegs<double> P;
-                    {
+                    if (maskable) {
+                        if (!(vis_new & bit)) continue;
                         WsPatch w;
                         ws_load(ws, npad, p, w);
                         ws_patch_regs(w, lg, level, P);
+                    } else {                                           // more patches per lane than mask bits: project again
+                        WsPatch w;
+                        ws_load(ws, npad, p, w);
+                        ws_patch_regs(w, lg, level, P);
+                        double u, v;
+                        if (!P.valid || !project_patch(a, lg, scale, P.X, s.u.R, s.u.tt, u, v)) continue;
                     }
                     const PatchHess ph = patch_hess_factors<double>(P, fs);
                     patch_hess_foreach<0, 0>(ph, [&](int q, double v) { H[q] += v; });
                 }
+#pragma unroll
+                for (int i = 0; i < 21; ++i) {
+                    const double hs = wave_sum_to_lane63(H[i]);
+                    if (lane == 63) s_part[wave].H[i] = hs;
+                }
             }
-            vis_old = vis_new;
 #pragma unroll
             for (int i = 0; i < 6; ++i) b[i] = wave_sum_to_lane63(b[i]);
-            if (h_new) {
-#pragma unroll
-                for (int i = 0; i < 21; ++i) H[i] = wave_sum_to_lane63(H[i]);
-            }
             chi2 = wave_sum_to_lane63(chi2);
             const double cntd = wave_sum_to_lane63((double)cnt);
             if (lane == 63) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) s_part[wave].b[i] = b[i];
-                if (h_new) {
-#pragma unroll
-                    for (int i = 0; i < 21; ++i) s_part[wave].H[i] = H[i];
-                }
                 s_part[wave].chi2 = chi2;
                 s_part[wave].cnt = (int)cntd;
                 s_part[wave].n_ref = n_ref_wave;
