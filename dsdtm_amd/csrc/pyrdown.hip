@@ -51,14 +51,16 @@ __device__ __forceinline__ u16x2 pk(uint32_t lo, uint32_t hi) {
     u16x2 v; v.x = (unsigned short)lo; v.y = (unsigned short)hi; return v;
 }
 
-// horizontal [1 4 6 4 1] of input row `row` for the 4 output columns x4..x4+3 (aligned fast path):
-// hA = (h0, h1), hB = (h2, h3)
-__device__ __forceinline__ void pd_hrow(const uint8_t* __restrict__ src, int sstride, int row, int base, bool left,
-                                        bool right, u16x2& hA, u16x2& hB) {
+// one 16-byte load of an input row at `base` (a multiple of 4). The 4th dword of the right-border strip starts at
+// the row end: it lies inside the pyramid (a source level is never the last level) and is not used.
+__device__ __forceinline__ uint4 pd_load(const uint8_t* __restrict__ src, int sstride, int row, int base) {
     const uint32_t* __restrict__ p32 = (const uint32_t*)(src + (size_t)row * sstride + base);
-    // 16 bytes from `base` (a multiple of 4). The 4th dword of the right-border strip starts at the
-    // row end: it lies inside the pyramid (a source level is never the last level) and is not used.
-    const uint32_t d0 = p32[0], d1 = p32[1], d2 = p32[2], d3 = p32[3];
+    return make_uint4(p32[0], p32[1], p32[2], p32[3]);
+}
+// horizontal [1 4 6 4 1] of a loaded input row for the 4 output columns x4..x4+3 (aligned fast path):
+// hA = (h0, h1), hB = (h2, h3)
+__device__ __forceinline__ void pd_filter(const uint4 d, bool left, bool right, u16x2& hA, u16x2& hB) {
+    const uint32_t d0 = d.x, d1 = d.y, d2 = d.z, d3 = d.w;
     // e0..e3 = columns xs-2 .. xs+13 with xs = 2*x4 - 2; interior strips load exactly that
     // (base = xs-2); the left-border strip (xs = -2) loads columns 0..15 and mirrors -4..-1 -> 4..1
     const uint32_t e0 = left ? __builtin_amdgcn_perm(d1, d0, 0x01020304u) : d0;   // bytes [col4, col3, col2, col1]
@@ -80,6 +82,10 @@ __device__ __forceinline__ void pd_hrow(const uint8_t* __restrict__ src, int sst
     hA = pk(h0, h1);
     hB = pk(h2, h3);
 }
+__device__ __forceinline__ void pd_hrow(const uint8_t* __restrict__ src, int sstride, int row, int base, bool left,
+                                        bool right, u16x2& hA, u16x2& hB) {
+    pd_filter(pd_load(src, sstride, row, base), left, right, hA, hB);
+}
 
 // vertical [1 4 6 4 1] + rounding of one packed pair: ((r0 + r4) + 4 (r1 + r3) + 6 r2 + 128) >> 8
 __device__ __forceinline__ u16x2 pd_vert(u16x2 r0, u16x2 r1, u16x2 r2, u16x2 r3, u16x2 r4) {
@@ -89,10 +95,34 @@ __device__ __forceinline__ u16x2 pd_vert(u16x2 r0, u16x2 r1, u16x2 r2, u16x2 r3,
     return (v + half) >> eight;
 }
 
+// XCD-aware block numbering. Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own
+// L2: with the plain numbering the blocks of ONE image — whose row chunks share 3 halo rows with their
+// neighbours — are spread over all eight L2s and every halo row is fetched from HBM by two of them. The
+// remapped id gives each XCD a contiguous range of (image, block) pairs, so an image's blocks meet in one L2.
+// SA_PD_XCD=0 restores the plain numbering (A/B).
+// all input rows of a thread's chunk loaded before the filtering starts (see the fast path)
+#ifndef SA_PD_PREFETCH
+#define SA_PD_PREFETCH 1
+#endif
+#ifndef SA_PD_XCD
+#define SA_PD_XCD 1
+#endif
+__device__ __forceinline__ void pd_block(int& img, int& bx) {
+    const unsigned nb = gridDim.x, total = gridDim.x * gridDim.z;
+    unsigned lb = blockIdx.z * nb + blockIdx.x;
+#if SA_PD_XCD
+    const unsigned q = total / 8u;
+    if (lb < q * 8u) lb = (lb % 8u) * q + lb / 8u;
+#endif
+    img = (int)(lb / nb);
+    bx = (int)(lb % nb);
+}
+
 __global__ __launch_bounds__(256) void pyrdown_kernel(const PyrDownArgs a, int tx, int ty) {
-    const int img = blockIdx.z;
+    int img, bx;
+    pd_block(img, bx);
     // linear numbering over (strip, row chunk): consecutive lanes = consecutive strips of a row chunk
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = bx * blockDim.x + threadIdx.x;
     if (gid >= tx * ty) return;
     const int y0 = (gid / tx) * PD_ROWS;                                // first output row of this thread
     const int x4 = (gid % tx) * 4;                                      // first of 4 output columns
@@ -112,6 +142,30 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const PyrDownArgs a, int t
     if (fast) {
         const int base = left ? 0 : (xs - 2);         // multiple of 4
         u16x2 wA[5], wB[5];                           // horizontally filtered rows 2y-2 .. 2y+2
+#if SA_PD_PREFETCH
+        // all 2*PD_ROWS + 3 input rows of the chunk in flight before the first one is filtered: the sliding-window
+        // loop below otherwise waits for two rows per output row, and ~2 loads per wave in flight at 7 waves per
+        // SIMD is short of what keeps HBM busy (Little: ~47 KB per CU at 6 TB/s and 2 us)
+        uint4 raw[2 * PD_ROWS + 3];
+#pragma unroll
+        for (int k = 0; k < 2 * PD_ROWS + 3; ++k)
+            raw[k] = pd_load(src, a.sstride, reflect101(min(2 * y0 - 2 + k, 2 * a.dh), a.sh), base);
+        pd_filter(raw[0], left, right, wA[0], wB[0]);
+        pd_filter(raw[1], left, right, wA[1], wB[1]);
+        pd_filter(raw[2], left, right, wA[2], wB[2]);
+#pragma unroll
+        for (int r = 0; r < PD_ROWS; ++r) {
+            const int y = y0 + r;
+            if (y >= a.dh) break;
+            pd_filter(raw[2 * r + 3], left, right, wA[(2 * r + 3) % 5], wB[(2 * r + 3) % 5]);
+            pd_filter(raw[2 * r + 4], left, right, wA[(2 * r + 4) % 5], wB[(2 * r + 4) % 5]);
+            const u16x2 oA = pd_vert(wA[(2 * r) % 5], wA[(2 * r + 1) % 5], wA[(2 * r + 2) % 5], wA[(2 * r + 3) % 5], wA[(2 * r + 4) % 5]);
+            const u16x2 oB = pd_vert(wB[(2 * r) % 5], wB[(2 * r + 1) % 5], wB[(2 * r + 2) % 5], wB[(2 * r + 3) % 5], wB[(2 * r + 4) % 5]);
+            const uint32_t packed = (uint32_t)oA.x | ((uint32_t)oA.y << 8) | ((uint32_t)oB.x << 16) | ((uint32_t)oB.y << 24);
+            *(uint32_t*)(dst + (size_t)y * a.dstride + x4) = packed;
+        }
+        return;
+#endif
         pd_hrow(src, a.sstride, reflect101(2 * y0 - 2, a.sh), base, left, right, wA[0], wB[0]);
         pd_hrow(src, a.sstride, reflect101(2 * y0 - 1, a.sh), base, left, right, wA[1], wB[1]);
         pd_hrow(src, a.sstride, reflect101(2 * y0, a.sh), base, left, right, wA[2], wB[2]);
@@ -152,6 +206,12 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const PyrDownArgs a, int t
     }
 }
 
+// (Round 2 also built a "streaming" variant: every lane loads exactly its own 16 input bytes per row — lanes 16
+// bytes apart, the wide coalesced pattern — produces 8 outputs per row and takes the 3 halo bytes of the horizontal
+// filter from the neighbouring lanes with two DPP wave shifts instead of from overlapping loads. Bit-exact, and
+// 5–8 % SLOWER than the kernel above on the same box (0.252–0.265 vs 0.243–0.246 ms for 2048 pyramids): the
+// overlapping bytes are L1 hits and were never the limit. Removed.)
+
 hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, int sh, int sstride,
                           size_t soff, int dstride, size_t doff, hipStream_t stream) {
     if (n_images <= 0) return hipSuccess;
@@ -159,8 +219,8 @@ hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, 
     a.pyr = pyr; a.pyr_pitch = pyr_pitch; a.n_images = n_images;
     a.sw = sw; a.sh = sh; a.sstride = sstride; a.soff = soff;
     a.dw = (sw + 1) / 2; a.dh = (sh + 1) / 2; a.dstride = dstride; a.doff = doff;
-    const int tx = (a.dw + 3) / 4;                          // strips of 4 output columns
     const int ty = (a.dh + PD_ROWS - 1) / PD_ROWS;          // row chunks of PD_ROWS output rows per thread
+    const int tx = (a.dw + 3) / 4;                          // strips of 4 output columns
     // gridDim.z is limited to 65535 images per launch
     for (int i0 = 0; i0 < n_images; i0 += 65535) {
         const int nz = (n_images - i0 < 65535) ? n_images - i0 : 65535;
