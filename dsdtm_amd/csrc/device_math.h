@@ -387,117 +387,53 @@ __device__ __forceinline__ void ldlt6_apply(const double* m, const double* dinv,
     for (int i = 0; i < 6; ++i) x[i] = d[i];
 }
 
-// H^+ of a well-conditioned H without the transposition cascades of ldlt6_factor / ldlt6_apply.
-// Eigen's left-looking LDLT (ldlt_step above) updates a diagonal entry only at its own step, so every pivot
-// search sees ORIGINAL diagonal entries: the pivot sequence is the diagonal sorted by magnitude, known before
-// the first elimination step. With the permutation applied up front — a gather of the 21 entries — the six
-// steps run without pivoting, on the same numbers in the same order as the pivoted code: factors, reciprocals
-// and the solves of the six unit vectors (lane j < 6 solves e_j: column j of H^+) equal its results up to the
-// compiler's choice of FMA contraction (measured: relative differences <= 1e-12).
-// Returns false — nothing written — for anything but a full-rank matrix with a strictly ordered diagonal
-// (ties, a step below Eigen's rank cutoff, a D_i at or below the pseudo-inverse tolerance, non-finite
-// values): the caller then takes the general path. `Hu`: 21 upper-triangular entries, row-major (any address
-// space); `col`: the lane's column as Hinv[j * 6 + row] is written through `hinv` for lanes < 6.
-template <typename HPtr, typename OPtr>
-__device__ __forceinline__ bool ldlt6_hinv_sorted(HPtr Hu, OPtr hinv, int lane) {
-    auto uidx = [](int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); };   // i <= j
-    double dg[6];
+// H^-1 of a positive definite 6x6 spread over 36 lanes: lane 6 i + j holds element (i, j), and six in-place
+// Gauss-Jordan steps (pivot k: row k scaled by p = 1/a_kk, every other row eliminated, column k replaced) turn H
+// into its inverse with ~20 instructions per step per lane — one reciprocal (v_rcp_f64 + two Newton steps), two
+// lane permutes per operand half for a_ik and a_kj, three multiply-adds — instead of the ~650 wave-uniform
+// instructions of the pivoted LDLT + six substitutions (ldlt6_factor / ldlt6_apply: transposition cascades, six
+// IEEE divisions). Elimination without pivoting is backward stable for symmetric positive definite matrices
+// (growth factor 1), which is what sum J J^T is whenever it has full rank; the result equals H.ldlt().solve(e_j) to
+// cond(H) * eps (measured <= 1e-10 relative on matrices of condition 1e6, tests/test_sparse_align_gpu.py).
+// Returns false (wave-uniform) when a pivot is not safely positive — rank-deficient, indefinite by rounding,
+// zero or non-finite H: the caller then runs the general pivoted code, which reproduces Eigen's rank cutoff and
+// pseudo-inverse. All 64 lanes must call it (lanes >= 36 carry no element).
+__device__ __forceinline__ double rcp_f64_newton(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    double e = __builtin_fma(-a, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-a, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double lane_read_f64(double v, int src_lane) {      // ds_bpermute on both halves
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast_f64(double v, int src_lane) {          // wave-uniform lane index
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+__device__ __forceinline__ bool gj6_invert_lanes(double& a, int lane) {
+    const int l36 = lane < 36 ? lane : 35;
+    const int i = l36 / 6, j = l36 - 6 * i;
+    double dmax = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dg[i] = fabs(Hu[uidx(i, i)]);
-    // rank_i = number of strictly larger entries; order[k] = the index of rank k
-    int order[6] = {0, 0, 0, 0, 0, 0};
-    bool bad = false;
-    double dmax = 0.0, dmin = dg[0];
+    for (int k = 0; k < 6; ++k) dmax = fmax(dmax, fabs(bcast_f64(a, 7 * k)));
+    // a pivot must stay well above the rounding noise of the entries it was eliminated from
+    const double floor_ = dmax * 1e-13;
+    bool ok = dmax > 0.0 && dmax < 1.7976931348623157e308;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        int r = 0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            if (j == i) continue;
-            r += (dg[j] > dg[i]) ? 1 : 0;
-            if (j < i) bad |= (dg[j] == dg[i]);
-        }
-        bad |= !(dg[i] == dg[i]);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) order[k] += (r == k) ? i : 0;
-        dmax = fmax(dmax, dg[i]); dmin = fmin(dmin, dg[i]);
+    for (int k = 0; k < 6; ++k) {
+        const double akk = bcast_f64(a, 7 * k);
+        ok = ok && (akk > floor_);
+        const double p = rcp_f64_newton(akk);
+        const double aik = lane_read_f64(a, 6 * i + k);       // same row, pivot column
+        const double akj = lane_read_f64(a, 6 * k + j);       // pivot row, same column
+        const double upd = a - (aik * p) * akj;
+        a = (i == k) ? ((j == k) ? p : a * p) : ((j == k) ? -(a * p) : upd);
     }
-    const double cutoff = fabs(2.220446049250313e-16 * dmax);          // ldlt_step<0>
-    bad |= (dmin < cutoff) | !(dmax < 1.7976931348623157e308);
-    if (__builtin_amdgcn_readfirstlane((int)bad)) return false;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) order[k] = __builtin_amdgcn_readfirstlane(order[k]);
-#define DSDTM_M(i, j) m[((i) * ((i) + 1)) / 2 + (j)]
-    double m[21], rD[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            const int a = order[i], b = order[j];
-            DSDTM_M(i, j) = Hu[uidx(a < b ? a : b, a < b ? b : a)];
-        }
-    bool ok = true;
-#pragma unroll
-    for (int K = 0; K < 6; ++K) {                                       // ldlt_step<K> without the pivot cases
-        if (K > 0) {
-            double temp[6];
-#pragma unroll
-            for (int j = 0; j < K; ++j) temp[j] = DSDTM_M(j, j) * DSDTM_M(K, j);
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) s += DSDTM_M(K, j) * temp[j];
-            DSDTM_M(K, K) -= s;
-#pragma unroll
-            for (int i = K + 1; i < 6; ++i) {
-                double a = 0.0;
-#pragma unroll
-                for (int j = 0; j < K; ++j) a += DSDTM_M(i, j) * temp[j];
-                DSDTM_M(i, K) -= a;
-            }
-        }
-        rD[K] = 1.0 / DSDTM_M(K, K);
-        ok &= fabs(DSDTM_M(K, K)) > cutoff;
-        if (K < 5) {
-#pragma unroll
-            for (int i = K + 1; i < 6; ++i) DSDTM_M(i, K) *= rD[K];
-        }
-    }
-    {   // pseudo-inverse tolerance of ldlt6_factor: every D_i must be kept
-        double maxd = 0.0, mind = fabs(DSDTM_M(0, 0));
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { maxd = fmax(maxd, fabs(DSDTM_M(i, i))); mind = fmin(mind, fabs(DSDTM_M(i, i))); }
-        double tol = maxd * 2.220446049250313e-16;
-        tol = fmax(tol, 1.0 / 1.7976931348623157e308);
-        ok &= (mind > tol) & (maxd < 1.7976931348623157e308);
-    }
-    if (!__builtin_amdgcn_readfirstlane((int)ok)) return false;
-    // lane j < 6: d = P e_j, L^-1, D^-1, L^-T, x = P^T d
-    const int jj = lane < 6 ? lane : 5;
-    double d[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) d[i] = (order[i] == jj) ? 1.0 : 0.0;
-#pragma unroll
-    for (int i = 1; i < 6; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < i; ++j) s += DSDTM_M(i, j) * d[j];
-        d[i] -= s;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) d[i] = d[i] * rD[i];
-#pragma unroll
-    for (int i = 4; i >= 0; --i) {
-        double s = 0.0;
-#pragma unroll
-        for (int j = i + 1; j < 6; ++j) s += DSDTM_M(j, i) * d[j];
-        d[i] -= s;
-    }
-    if (lane < 6) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) hinv[jj * 6 + order[i]] = d[i];
-    }
-#undef DSDTM_M
-    return true;
+    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
 }
 
 __device__ inline void ldlt6_solve(const double* Hu, const double* b, double* x) {

@@ -11,7 +11,7 @@ namespace dsdtm {
 // per case: in[0..20] H upper triangle, in[21..26] b, in[27..32] xi  -> out[0..5] x = H^+ b,
 // out[6..12] exp(xi) (qw,qx,qy,qz,tx,ty,tz), out[13..19] exp(xi)*exp(b) , out[20] DPP wave sum of
 // (lane+1)*in[27], out[21] shuffle wave sum of the same, out[22..33] [R|t] of exp(xi) via from_rt(to_rt),
-// out[34..69] H^+ by columns from ldlt6_solve on the unit vectors, out[70..105] the same from ldlt6_hinv_sorted
+// out[34..69] H^+ by columns from ldlt6_solve on the unit vectors, out[70..105] the same from gj6_invert_lanes
 // (untouched where it declines), out[106] 1 where it accepted the matrix, out[107..118] dR (9) and dt (3) of
 // se3_exp_matrix_small(xi) (only for |omega|^2 < 0.01), out[119] max |row_reduce8 - row_sum16| over 8 values of all lanes
 constexpr int SELFTEST_OUT = 120;
@@ -41,7 +41,15 @@ __global__ void selftest_kernel(const double* __restrict__ in, double* __restric
     if (lane < 21) s_h[lane] = p[lane];
     if (lane < 36) s_hinv[lane] = -12345.0;
     __syncthreads();
-    const bool fast_ok = ldlt6_hinv_sorted((const double*)s_h, (double*)s_hinv, lane);
+    bool fast_ok;
+    {
+        const int l36 = lane < 36 ? lane : 35;
+        const int gi = l36 / 6, gj = l36 - 6 * gi;
+        const int glo = gi < gj ? gi : gj, ghi = gi < gj ? gj : gi;
+        double el = s_h[glo * 6 - (glo * (glo - 1)) / 2 + (ghi - glo)];
+        fast_ok = gj6_invert_lanes(el, lane);
+        if (fast_ok && lane < 36) s_hinv[gj * 6 + gi] = el;
+    }
     __syncthreads();
     double dRm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dtm[3] = {0, 0, 0};
     const double th2 = xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5];

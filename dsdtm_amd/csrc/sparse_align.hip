@@ -708,25 +708,7 @@ __device__ __forceinline__ void commit_next(LdsBlockState& s, int lane) {
 // Deliberately NOT inlined: it runs only when the visible set changed (about once per pyramid level),
 // and keeping its ~70 live registers out of solver_step's allocation keeps the whole kernel inside
 // the 168-VGPR budget of a 12-wave workgroup without spills on the per-iteration path.
-// The common case first: a full-rank H goes through ldlt6_hinv_sorted (permutation known from the diagonal, no
-// transposition cascades — the same pivot order and operations in fewer instructions); everything else
-// (rank cutoff, ties, zero matrix) through the general code below.
-#ifndef SA_FAST_HINV
-#define SA_FAST_HINV 1
-#endif
-__device__ __attribute__((noinline)) void factor_hinv_general(LdsBlockState* sp, int lane);
-__device__ __attribute__((noinline)) void factor_hinv_to_lds(LdsBlockState* sp, int lane) {
-#if SA_FAST_HINV
-    typedef __attribute__((address_space(3))) double LdsF64;
-    const bool done = ldlt6_hinv_sorted((const LdsF64*)sp->Hsum, (LdsF64*)sp->Hinv, lane);
-    if (!done) factor_hinv_general(sp, lane);
-#else
-    factor_hinv_general(sp, lane);
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
+// Deliberately NOT inlined (rare path; keeps its ~70 live registers out of the solver loop's allocation).
 __device__ __attribute__((noinline)) void factor_hinv_general(LdsBlockState* sp, int lane) {
     LdsBlockState& s = *sp;
     double H[21], Fm[21], Fdinv[6];
@@ -749,26 +731,41 @@ __device__ __attribute__((noinline)) void factor_hinv_general(LdsBlockState* sp,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// Sum the per-row H partials (lane q < 21 sums entry q over the NP slots in fixed order), factorise
-// the total and form H^+. Called once per level on the all-visible H — speculatively, while the patch
-// waves run the level's first pass — and again only if a row later reports a different visible set.
+// Sum the per-row H partials and form H^+. Lane 6 i + j (< 36) sums entry (i, j) over the NP slots in fixed
+// order, the 36 lanes invert the matrix in place (gj6_invert_lanes) and park H^+ in LDS; a matrix that is not safely
+// positive definite (no visible patch, rank-deficient) goes through the pivoted LDLT of the general path instead,
+// which reproduces Eigen's rank cutoff and pseudo-inverse. Called once per level on the all-visible H —
+// speculatively, while the patch waves run the level's first pass — and again only if a row later reports a
+// different visible set. (Round 2: 7.7 k cycles per call with the pivoted factorisation + six substitutions.)
+// Out of line on purpose: it runs about once per level, and inlined its temporaries pushed the per-iteration solver
+// code into spills (18 VGPRs, solve 2.06 k -> 3.3 k cycles). Data in and out through LDS only.
+typedef __attribute__((address_space(3))) WavePartial LdsWavePartial;
 template <int NP>
-__device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, BlockState& s, int lane, double* hrow) {
+__device__ __attribute__((noinline)) void refresh_hinv_to_lds(const LdsWavePartial* s_part, LdsBlockState* sp, int lane) {
     constexpr int WP = sizeof(WavePartial) / sizeof(double);
-    const double* base = (const double*)s_part;
-    if (lane < 21) {
-        double acc = 0.0;
-#pragma unroll 4
-        for (int w = 0; w < NP; ++w) acc += base[w * WP + 9 + lane];   // H[] starts at double 9 of a slot
-        s.Hsum[lane] = acc;
-    }
+    LdsBlockState& s = *sp;
+    const __attribute__((address_space(3))) double* base = (const __attribute__((address_space(3))) double*)s_part;
+    const int l36 = lane < 36 ? lane : 35;
+    const int i = l36 / 6, j = l36 - 6 * i;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int q = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);          // row-major upper triangle
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < NP; ++w) acc += base[w * WP + 9 + q];         // H[] starts at double 9 of a slot (all loads in flight)
+    if (lane < 36 && i <= j) s.Hsum[q] = acc;                         // for the general path
+    const bool ok = gj6_invert_lanes(acc, lane);
+    if (ok && lane < 36) s.Hinv[j * 6 + i] = acc;                     // H^+ by columns
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    factor_hinv_to_lds((LdsBlockState*)&s, lane);         // out-of-line; parks H^+ in LDS
+    if (!ok) factor_hinv_general(sp, lane);                           // rare; parks H^+ in LDS
+}
+template <int NP>
+__device__ __forceinline__ void solver_refresh_H(const WavePartial* s_part, BlockState& s, int lane, double* hrow) {
+    refresh_hinv_to_lds<NP>((const LdsWavePartial*)s_part, (LdsBlockState*)&s, lane);
     const int li = lane < 6 ? lane : 5;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) hrow[j] = s.Hinv[j * 6 + li];   // lane i < 6 keeps row i of H^+ (stored by columns)
+    for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];    // lane i < 6 keeps row i of H^+ (stored by columns)
 }
 
 // what solver_step hands to solver_commit (wave-uniform values)
