@@ -445,10 +445,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.stub:
+        # The data path has no collective; the process group only carries the contract's barrier and the
+        # max-over-ranks reduction. RCCL ("nccl") when every rank has its own GPU; gloo for the CPU stub and for
+        # DSDTM_BENCH_SHARE_GPU=1 (rehearsal of the multi-process path on a one-GPU box: all ranks use cuda:0,
+        # RCCL refuses two ranks on one device).
+        share_gpu = os.environ.get("DSDTM_BENCH_SHARE_GPU") == "1"
+        if args.stub or share_gpu:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            local_rank = 0
 
     def barrier():
         if world > 1:
@@ -544,7 +551,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        elapsed = shard.max_over_ranks(elapsed, dist, dev)
+        elapsed = shard.max_over_ranks(elapsed, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
     ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, stream.cuda_stream))   # no hand-over wait timed out in any launch
     d["T_cur_w"] = d["T_steps"][n_slots - 1]          # the last step's results are the ones checked below
     if per_kernel:
@@ -576,7 +583,8 @@ def main():
                                    f"levels, {args.patches} patches, cap {args.iters} GN iterations, one launch per step",
                        "pairs_per_gpu": args.pairs, "patches": args.patches, "levels": args.levels,
                        "max_iters": args.iters, "launch_streams": n_streams,
-                       "parallelism": f"independent pairs x{world} (no collective)"},
+                       "parallelism": f"independent pairs x{world} (no collective)",
+                       **({"barrier_backend": dist.get_backend()} if world > 1 else {})},
             "roofline": roofline_block("sparse_align_reg_kernel", args.pairs * b_alg, k_avg, k_min, args.pairs, b_alg, "alignment",
                                        {"kernel_time_basis": k_basis}),
             "executed_iterations_per_level_mean": [float(x) for x in iters.mean(axis=0)],
