@@ -1343,6 +1343,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
 // grid_from_rows the register kernels run once per level (same inputs, same arithmetic: bit-identical values).
 // The first version parked the grid itself and was bound by exactly that traffic: 1024 pairs of 1000 patches moved
 // 8.7 GB per launch through HBM (rocprofv3 FETCH_SIZE/WRITE_SIZE, 9.7x the algorithmic bytes) at 6.2 TB/s.
+// patch waves of the workspace kernel (7 + 1 solver = 2 waves per SIMD at up to 256 VGPRs; 11 + 1 = 3 per SIMD at 168)
+#ifndef SA_WS_NPW
+#define SA_WS_NPW 7
+#endif
 constexpr int WS_DWORDS = 22;   // rlo[7], rhi[7], px, py, X[3] as dword pairs
 __host__ __device__ inline size_t ws_doubles_per_pair(int max_features) {
     const size_t npad = ((size_t)max_features + 63) / 64 * 64;
@@ -1826,7 +1830,7 @@ int sparse_align_occupancy(int variant) {
     int nb = -1;
     if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, false>, SA_PPW * 6 * 64, 0);
     else if (variant == SA_REG448) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<7, SA_GRID_T, 1, false>, 8 * 64, 0);
-    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<7>, 8 * 64, 0);
+    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<SA_WS_NPW>, (SA_WS_NPW + 1) * 64, 0);
     return nb;
 }
 
@@ -1859,7 +1863,7 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
         case SA_REG448: return launch_reg<7, 1, false>(args, num_cus, stream);
         case SA_REG704: return launch_reg<11, 1, false>(args, num_cus, stream);
         case SA_WS:
-            hipLaunchKernelGGL((sparse_align_ws_kernel<7>), dim3((unsigned)args.n_pairs), dim3(8 * 64), 0, stream, args);
+            hipLaunchKernelGGL((sparse_align_ws_kernel<SA_WS_NPW>), dim3((unsigned)args.n_pairs), dim3((SA_WS_NPW + 1) * 64), 0, stream, args);
             break;
     }
     return hipGetLastError();

@@ -1,0 +1,35 @@
+"""bench.py's bookkeeping that needs no GPU: the algorithmic byte counts of SURVEY.md §8(d), the lookup of the
+committed rocprofv3 PMC summary behind roofline.traffic, and the host-thread census behind cpu_baseline_all_cores."""
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_algorithmic_bytes_are_the_surveys_figures():
+    # C2 833 392 B, C3 873 292 B, C5 3 378 292 B per alignment
+    assert bench.algorithmic_bytes(640, 480, 4, 300) == 833392
+    assert bench.algorithmic_bytes(640, 480, 4, 1000) == 873292
+    assert bench.algorithmic_bytes(1280, 960, 4, 2000) == 3378292
+
+
+def test_traffic_lookup_reads_the_committed_pmc_summary():
+    path = os.path.join(ROOT, bench.PMC_SUMMARY)
+    assert os.path.exists(path), "profiles/ must carry the PMC summary bench.py quotes"
+    with open(path) as f:
+        d = json.load(f)
+    rows = {(t["case"], int(t["algorithmic_bytes_per_launch"])): t for t in d["hbm_traffic_per_launch"]}
+    main = rows[("solo", 1024 * 833392)]
+    t = bench.pmc_traffic("sparse_align_reg_kernel", 1024 * 833392)
+    assert t == main["fetch_bytes_gfx950_corrected"] + main["write_bytes"]
+    assert main["fetch_bytes_gfx950_corrected"] == 2.0 * main["fetch_bytes_raw"]          # the guide's gfx950 correction
+    assert 0.3 < t / (1024 * 833392) < 1.5                                                 # no wasted re-reads on the main kernel
+    assert bench.pmc_traffic("sparse_align_reg_kernel", 12345) is None                     # another launch size: no number
+    assert bench.pmc_traffic("pyrdown", 2048 * 504000) is not None
+
+
+def test_usable_cpus_is_positive_and_bounded_by_the_machine():
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
