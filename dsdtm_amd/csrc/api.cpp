@@ -37,7 +37,8 @@ struct dsdtm_ctx {
     //  * a launch captured into a hipGraph gets a word of its own from the graph pool, for the life of the
     //    context, and a memset node in front of it (a hipGraphExec never overlaps itself).
     unsigned* d_counter = nullptr;
-    struct StreamRing { hipStream_t stream; unsigned seq; bool used; void* d_ws; size_t ws_cap; };   // + the stream's workspace
+    struct StreamRing { hipStream_t stream; unsigned seq; bool used; void* d_ws; size_t ws_cap; unsigned long long last_use; };   // + the stream's workspace
+    unsigned long long ring_tick = 0;
     static constexpr int MAX_STREAMS = 16, COUNTERS_PER_STREAM = 8, GRAPH_COUNTERS = 256;
     StreamRing rings[MAX_STREAMS] = {};
     int graph_counters_used = 0;
@@ -252,11 +253,19 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
             if (ctx->rings[i].used && ctx->rings[i].stream == stream) ri = i;
         for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
-            if (!ctx->rings[i].used) { ctx->rings[i] = dsdtm_ctx::StreamRing{stream, 0u, true, nullptr, 0}; ri = i; }
+            if (!ctx->rings[i].used) { ctx->rings[i] = dsdtm_ctx::StreamRing{stream, 0u, true, nullptr, 0, 0ull}; ri = i; }
         if (ri < 0) {
-            set_err(ctx, "more than %d streams launch through one context: use one context per group of streams", dsdtm_ctx::MAX_STREAMS);
-            return DSDTM_ERR_INVALID;
+            // A 17th stream (applications that keep creating streams): the entry that has been idle longest is handed
+            // over. Its old stream may be gone, so it cannot be waited for; the whole device is — once per eviction —
+            // after which nothing can still be using the entry's counters or workspace.
+            ri = 0;
+            for (int i = 1; i < dsdtm_ctx::MAX_STREAMS; ++i)
+                if (ctx->rings[i].last_use < ctx->rings[ri].last_use) ri = i;
+            HIP_TRY(ctx, hipDeviceSynchronize());
+            ctx->rings[ri].stream = stream;
+            ctx->rings[ri].seq = 0;
         }
+        ctx->rings[ri].last_use = ++ctx->ring_tick;
         a.pair_counter = ctx->d_counter + ri * dsdtm_ctx::COUNTERS_PER_STREAM + (ctx->rings[ri].seq++ % dsdtm_ctx::COUNTERS_PER_STREAM);
         ring = ri;
     }

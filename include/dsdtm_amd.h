@@ -304,7 +304,8 @@ int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* batc
  * single-pair host entry points above perform this check themselves. */
 int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream);
 
-/* Streams and hipGraphs. Launches of one context may be in flight on up to 16 different streams at once; a
+/* Streams and hipGraphs. Launches of one context may be in flight on up to 16 different streams at once (a 17th
+ * stream takes over the bookkeeping of the one idle longest, after one device synchronisation); a
  * launch captured into a hipGraph owns a pair-counter word of the context for good (256 per context) and is
  * preceded by a memset node, so graph replays need nothing from the host. Shapes that spread one pair over
  * several compute units (few pairs of more than 448 features) are ordered against each other across streams by

@@ -752,3 +752,32 @@ def test_workspace_launches_in_flight_on_two_streams(gpu_ctx, oracle):
                 To, no, _ = want[(i + g) % 4]
                 H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"rep {rep} stream {g} pair {i}")
                 assert ntg[i] == no
+
+
+def test_more_streams_than_a_context_tracks(gpu_ctx, oracle):
+    """A context keeps pair counters (and workspaces) per stream for 16 streams; applications that keep creating
+    streams get the least recently used entry handed over (one device synchronisation) — launches on 40 different
+    streams, two in flight at any time, all give the oracle's results."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L = 320, 240, 3
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=150, seed=1700 + i, margin=12) for i in range(9)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in scenes]
+    packed = [_device_batch(torch, dev, scenes, L, W, Hh) for _ in range(2)]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    seed = torch.from_numpy(np.stack([s_.T_cur_w_seed.reshape(12) for s_ in scenes])).to(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(40)]
+    for k in range(0, 40, 2):
+        for (t, b), st in zip(packed, streams[k:k + 2]):
+            with torch.cuda.stream(st):
+                t["Tc"].copy_(seed, non_blocking=True)
+            gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+        for (t, b), st in zip(packed, streams[k:k + 2]):
+            gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, st.cuda_stream))
+            Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+            for i, (To, no, _) in enumerate(want):
+                H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"stream {k} pair {i}")
+                assert ntg[i] == no
