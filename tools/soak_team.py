@@ -12,7 +12,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 ctx = capi.default_context(0)
 Config.Set("Camera.Min_fts", 15)
 cases = []
-for n in (705, 1000, 1537, 2000, 3000, 4096):
+for n in (705, 1000, 1537, 2000, 3000, 4096, 5000, 9000):
     sc = synth.make_scene(n_patches=n, seed=5)
     al = Sprase_ImgAlign(4, 0, 10, ctx=ctx, resident_frames=True)
     cur, ref = frames_from_scene(sc)
