@@ -108,13 +108,27 @@ struct BlockState {
 // counters instead. All waves of a workgroup are co-resident, every wait has its producer in
 // flight, and every spin is bounded (a broken protocol ends the kernel instead of hanging the GPU).
 constexpr unsigned SPIN_LIMIT = 1u << 24;
+// current-image windows parked byte-aligned to their first column (window_commit / residual_patch); needs 5-row windows
+#ifndef SA_WIN_ALIGNED
+#define SA_WIN_ALIGNED (SA_WIN_ROWS == 5)
+#endif
+#ifndef SA_HESS_LEAN
+#define SA_HESS_LEAN 1
+#endif
+#ifndef SA_HBLOCK_GROUP
+#define SA_HBLOCK_GROUP 1
+#endif
+// SA_PASS_LEAN: instruction diet of the residual pass (see project_patch / residual_patch); 0 restores round 1's code
+#ifndef SA_PASS_LEAN
+#define SA_PASS_LEAN 1
+#endif
 // Row partials of the register kernel by packed butterflies (row_reduce8: 54 instead of 96 instructions per eight
-// values) instead of one DPP rotation chain per value. Measured (same-box A/B, stamps): no difference — pass 3989 vs
-// 4016 cycles, level-start H block 17 844 vs 17 835 per pair, kernel 0.2350 vs 0.2340 ms: a patch wave issues one
-// instruction per ~8.5 cycles because of FP64 dependency latency, and the seven independent rotation chains fill
-// those gaps for free. Kept as an experiment switch, off by default.
+// values, and none of the s_nops that a chain of dependent DPP steps needs) instead of one DPP rotation chain per
+// value, for the pass's seven sums and the 21 entries of the H block. First measured as "no difference" (a build
+// that still spilled in the solver); on the final kernel: 0.2196 -> 0.2107 ms, +4 % (passes and level starts are
+// bound by VALU issue on the SIMDs that carry three patch waves).
 #ifndef SA_PACKED_REDUCE
-#define SA_PACKED_REDUCE 0
+#define SA_PACKED_REDUCE 1
 #endif
 #ifndef SA_SLEEP_ARRIVE
 #define SA_SLEEP_ARRIVE 1   // solver waiting for the patch waves (and for acknowledgements)
@@ -375,9 +389,22 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
 struct PatchHess {
     double sxx, sxy, syy;
     double A[6], B[6];
+    // A = [a0, 0, A2..A5], B = [0, b0, B2..B5] (GetJocabianBA's zeros): with P_j = sxx A_j + sxy B_j and
+    // Q_j = sxy A_j + syy B_j the entry (i, j) is A_i P_j + B_i Q_j — two operations instead of six, and nothing is
+    // multiplied by the structural zeros (SA_HESS_LEAN; the level start is bound by VALU issue like the pass)
+    double Pj[6], Qj[6];
     template <int I, int J>
     __device__ __forceinline__ double entry() const {
+#if SA_HESS_LEAN
+        if constexpr (I == 0 && J == 0) return A[0] * Pj[0];
+        else if constexpr (I == 0 && J == 1) return A[0] * Pj[1];
+        else if constexpr (I == 0) return A[0] * Pj[J];
+        else if constexpr (I == 1 && J == 1) return B[1] * Qj[1];
+        else if constexpr (I == 1) return B[1] * Qj[J];
+        else return A[I] * Pj[J] + B[I] * Qj[J];
+#else
         return sxx * (A[I] * A[J]) + sxy * (A[I] * B[J] + B[I] * A[J]) + syy * (B[I] * B[J]);
+#endif
     }
 };
 
@@ -389,15 +416,33 @@ __device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs<GT>& P, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+#if SA_HESS_LEAN
+            // the 0.5 of the central differences as ONE exact scaling of the three sums (power of two)
+            const double dx = (double)P.g[i + 1][k + 2] - (double)P.g[i + 1][k];
+            const double dy = (double)P.g[i + 2][k + 1] - (double)P.g[i][k + 1];
+#else
             const double dx = 0.5 * ((double)P.g[i + 1][k + 2] - (double)P.g[i + 1][k]);
             const double dy = 0.5 * ((double)P.g[i + 2][k + 1] - (double)P.g[i][k + 1]);
+#endif
             sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
         }
+#if SA_HESS_LEAN
+    sxx *= 0.25; sxy *= 0.25; syy *= 0.25;
+#endif
     h.sxx = sxx; h.sxy = sxy; h.syy = syy;
     double A5[5], B5[5];
     patch_AB(fs, P.X, A5, B5);
     h.A[0] = A5[0]; h.A[1] = 0.0;   h.A[2] = A5[1]; h.A[3] = A5[2]; h.A[4] = A5[3]; h.A[5] = A5[4];
     h.B[0] = 0.0;   h.B[1] = B5[0]; h.B[2] = B5[1]; h.B[3] = B5[2]; h.B[4] = B5[3]; h.B[5] = B5[4];
+#if SA_HESS_LEAN
+    h.Pj[0] = sxx * h.A[0]; h.Qj[0] = sxy * h.A[0];               // B_0 = 0
+    h.Pj[1] = sxy * h.B[1]; h.Qj[1] = syy * h.B[1];               // A_1 = 0
+#pragma unroll
+    for (int j = 2; j < 6; ++j) {
+        h.Pj[j] = sxx * h.A[j] + sxy * h.B[j];
+        h.Qj[j] = sxy * h.A[j] + syy * h.B[j];
+    }
+#endif
     return h;
 }
 
@@ -464,10 +509,13 @@ __device__ __forceinline__ bool project_patch(const SAKernelArgs& a, const Level
     const double pzc = sR[6] * X[0] + sR[7] * X[1] + sR[8] + st[2] * X[2];
     // Camera2Pixel (src/Camera.cpp:167-171), * tScale (:255)
     // one reciprocal for both coordinates (the reference divides twice; <= 1 ulp on u,v)
-    const double izc = 1.0 / pzc;
+    const double izc = SA_PASS_LEAN ? rcp_f64_newton(pzc) : 1.0 / pzc;
     u = ((double)a.fx * pxc * izc + (double)a.cx) * scale;
     v = ((double)a.fy * pyc * izc + (double)a.cy) * scale;
-    // :262 with mnboarder = 3 on floored ints: floor(u) >= 3 && floor(u)+3 < cols (NaN fails)
+    // :262 with mnboarder = 3 on floored ints: floor(u) >= 3 && floor(u)+3 < cols (NaN fails). Evaluated without
+    // short-circuits: the pass is bound by VALU issue, and nested early-outs made the compiler re-zero the seven
+    // result registers on every arm (21 moves on the visible path)
+    if (SA_PASS_LEAN) return (u >= 3.0) & (u < (double)(lg.w - 3)) & (v >= 3.0) & (v < (double)(lg.h - 3));
     return u >= 3.0 && u < (double)(lg.w - 3) && v >= 3.0 && v < (double)(lg.h - 3);
 }
 
@@ -500,9 +548,20 @@ __device__ __forceinline__ void window_commit(const SAKernelArgs& a, const Level
     for (int r = 0; r < WIN_ROWS; ++r) {
         const uint32_t o = lg.off + (uint32_t)(f.v_i - HR + r) * (uint32_t)lg.stride + (uint32_t)(f.u_i - 3);
         const bool in = min(o >> 2, last_dw - 2u) == (o >> 2);
-        win[(r * 3 + 0) * WIN_NL] = in ? f.w[r].a : f.w[r].b;
-        win[(r * 3 + 1) * WIN_NL] = in ? f.w[r].b : f.w[r].c;
-        win[(r * 3 + 2) * WIN_NL] = in ? f.w[r].c : 0u;
+        const uint32_t d0 = in ? f.w[r].a : f.w[r].b, d1 = in ? f.w[r].b : f.w[r].c, d2 = in ? f.w[r].c : 0u;
+#if SA_WIN_ALIGNED
+        // parked with column u_i - 3 in byte 0 of the row's first dword (9..12 valid bytes): a pass then needs the same
+        // dword offset and byte shift for all five rows and no per-row address arithmetic (the pass is bound by VALU
+        // issue; this is done once per fill)
+        const uint32_t sh = (o & 3u) * 8u;
+        win[(r * 3 + 0) * WIN_NL] = __builtin_amdgcn_alignbit(d1, d0, sh);
+        win[(r * 3 + 1) * WIN_NL] = __builtin_amdgcn_alignbit(d2, d1, sh);
+        win[(r * 3 + 2) * WIN_NL] = d2 >> sh;
+#else
+        win[(r * 3 + 0) * WIN_NL] = d0;
+        win[(r * 3 + 1) * WIN_NL] = d1;
+        win[(r * 3 + 2) * WIN_NL] = d2;
+#endif
     }
     worg = (uint32_t)f.u_i | ((uint32_t)f.v_i << 16);
 }
@@ -517,9 +576,13 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
     chi2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = 0.0;
-    if (!P.valid) return false;
     double u, v;
+#if SA_PASS_LEAN
+    if (!(project_patch(a, lg, scale, P.X, sR, st, u, v) & P.valid)) return false;    // ONE exit for lanes without a visible patch
+#else
+    if (!P.valid) return false;
     if (!project_patch(a, lg, scale, P.X, sR, st, u, v)) return false;
+#endif
     const double fu_d = floor(u), fv_d = floor(v);
     const int u_i = (int)fu_d, v_i = (int)fv_d;
     const double su = u - fu_d, sv = v - fv_d;
@@ -540,6 +603,20 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
             window_commit<WIN_NL>(a, lg, f, win, *worg);
             u0 = u_i; v0 = v_i;
         }
+#if SA_WIN_ALIGNED
+        static_assert(WIN_ROWS == 5, "aligned windows: the window's rows are the pass's rows");
+        {
+            const uint32_t p = (uint32_t)(u_i - u0 + 1);          // byte of column u_i - 2 in the parked rows: 0..4
+            const LdsU32* wc = win + (p >> 2) * (uint32_t)WIN_NL; // dword 0 or 1 of every row
+            const uint32_t sh = (p & 3u) * 8u;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const uint32_t lo = wc[(r * 3) * WIN_NL], hi = wc[(r * 3 + 1) * WIN_NL];
+                wlo[r] = __builtin_amdgcn_alignbit(hi, lo, sh);     // bytes 0..3 of the row
+                whi[r] = hi >> sh;                                  // byte 4 in bits 0..7
+            }
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
             const uint32_t rowb = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride;
@@ -551,6 +628,7 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
             wlo[r] = __builtin_amdgcn_alignbit(hi, lo, sh);     // bytes 0..3 of the row
             whi[r] = hi >> sh;                                  // byte 4 in bits 0..7
         }
+#endif
     } else {
         U32x2 wr[5];
 #pragma unroll
@@ -1227,7 +1305,9 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
                     const double hs = row_sum16(P.valid ? v : 0.0);
                     if (row_writer) Hout[q] = hs;
-                    __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
+                    // SA_HBLOCK_GROUP entries in flight: with one (round 1, to keep few values live) every DPP step
+                    // waits out its read-after-write hazard in s_nops (87 of them in the level-start code)
+                    if ((q % SA_HBLOCK_GROUP) == SA_HBLOCK_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                 });
 #endif
                 pair_signal_arrive(&s.arrive_h, lane);                 // BH
