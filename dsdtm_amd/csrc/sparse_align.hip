@@ -345,7 +345,9 @@ __device__ __forceinline__ void ref_rows_unpack(const SAKernelArgs& a, const Lev
 template <typename GT>
 __device__ __forceinline__ void grid_from_rows(const FeatureRegs& F, const RefGeom& g, const uint32_t* rlo, const uint32_t* rhi,
                                                PatchRegs<GT>& P) {
-    P.X[0] = F.X[0]; P.X[1] = F.X[1]; P.X[2] = F.X[2];
+    // lanes without a valid patch get a harmless point: their A, B (patch_AB) stay finite, so that zeroing the three
+    // gradient sums is enough to keep them out of the H block (patch_hess_factors)
+    P.X[0] = g.valid ? F.X[0] : 0.0; P.X[1] = g.valid ? F.X[1] : 0.0; P.X[2] = g.valid ? F.X[2] : 1.0;
     P.valid = g.valid;
     const double omx = 1.0 - g.su, omy = 1.0 - g.sv;
     const double w00 = omx * omy, w01 = g.su * omy, w10 = omx * g.sv, w11 = g.su * g.sv;
@@ -408,8 +410,9 @@ struct PatchHess {
     }
 };
 
+// `use` = the patch contributes (valid / visible): otherwise its three sums, hence all 21 entries, are zero
 template <typename GT>
-__device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs<GT>& P, double fs) {
+__device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs<GT>& P, double fs, bool use = true) {
     PatchHess h;
     double sxx = 0.0, sxy = 0.0, syy = 0.0;
 #pragma unroll
@@ -427,7 +430,7 @@ __device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs<GT>& P, 
             sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
         }
 #if SA_HESS_LEAN
-    sxx *= 0.25; sxy *= 0.25; syy *= 0.25;
+    sxx = use ? sxx * 0.25 : 0.0; sxy = use ? sxy * 0.25 : 0.0; syy = use ? syy * 0.25 : 0.0;
 #endif
     h.sxx = sxx; h.sxy = sxy; h.syy = syy;
     double A5[5], B5[5];
@@ -462,10 +465,18 @@ __device__ __forceinline__ double patch_hess_entry_q(const PatchHess& h) {
 template <int G>
 __device__ __forceinline__ void patch_hess_rows_group(const PatchHess& ph, bool use, int lane, double* Hout) {
     double v[8];
+#if SA_HESS_LEAN
+    (void)use;       // the factors were built with `use`: a patch that does not contribute has zero sums
+    v[0] = patch_hess_entry_q<8 * G + 0>(ph); v[1] = patch_hess_entry_q<8 * G + 1>(ph);
+    v[2] = patch_hess_entry_q<8 * G + 2>(ph); v[3] = patch_hess_entry_q<8 * G + 3>(ph);
+    v[4] = patch_hess_entry_q<8 * G + 4>(ph); v[5] = patch_hess_entry_q<8 * G + 5>(ph);
+    v[6] = patch_hess_entry_q<8 * G + 6>(ph); v[7] = patch_hess_entry_q<8 * G + 7>(ph);
+#else
     v[0] = use ? patch_hess_entry_q<8 * G + 0>(ph) : 0.0; v[1] = use ? patch_hess_entry_q<8 * G + 1>(ph) : 0.0;
     v[2] = use ? patch_hess_entry_q<8 * G + 2>(ph) : 0.0; v[3] = use ? patch_hess_entry_q<8 * G + 3>(ph) : 0.0;
     v[4] = use ? patch_hess_entry_q<8 * G + 4>(ph) : 0.0; v[5] = use ? patch_hess_entry_q<8 * G + 5>(ph) : 0.0;
     v[6] = use ? patch_hess_entry_q<8 * G + 6>(ph) : 0.0; v[7] = use ? patch_hess_entry_q<8 * G + 7>(ph) : 0.0;
+#endif
     const double t = row_reduce8(v, lane);
     const int q = 8 * G + row_reduce8_index(lane);
     if (!(lane & 4) && q < 21) Hout[q] = t;
@@ -1297,7 +1308,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             {
                 unsigned long long th0 = 0;
                 if (STAMPS) th0 = __builtin_amdgcn_s_memtime();
-                const PatchHess ph = patch_hess_factors<GT>(P, fs);
+                const PatchHess ph = patch_hess_factors<GT>(P, fs, P.valid);
 #if SA_PACKED_REDUCE
                 patch_hess_rows(ph, P.valid, lane, my_part.H);
 #else
@@ -1360,7 +1371,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 }
                 const bool h_changed = (vmask != cached_mask);        // wave-uniform, rare
                 if (h_changed) {
-                    const PatchHess ph = patch_hess_factors<GT>(P, fs);
+                    const PatchHess ph = patch_hess_factors<GT>(P, fs, vis);
 #if SA_PACKED_REDUCE
                     patch_hess_rows(ph, vis, lane, my_part.H);
 #else
