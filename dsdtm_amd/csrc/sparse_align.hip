@@ -680,6 +680,22 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
         __builtin_amdgcn_sched_barrier(0);
     }
     chi2 = c2a + c2b;
+#if SA_PASS_LEAN
+    // JRes += J*res (:291) with J = dx*A + dy*B, written out in the normalised point (patch_AB's entries) so that the
+    // ten products A_i, B_i are never formed: with gX = fs/2 * sum(2dx res), gY likewise and s = xn gX + yn gY
+    //   b = [-zi gX, -zi gY, zi s, yn s + gY, -(xn s + gX), yn gX - xn gY]          (11 instead of 24 instructions)
+    // (the 0.5 of the central differences is folded into fs: exact, a power of two)
+    const double fsh = 0.5 * fs;
+    const double gX = (gxa + gxb) * fsh, gY = (gya + gyb) * fsh;
+    const double xn = P.X[0], yn = P.X[1], zi = P.X[2];
+    const double sxy = xn * gX + yn * gY;
+    b[0] = -(zi * gX);
+    b[1] = -(zi * gY);
+    b[2] = zi * sxy;
+    b[3] = yn * sxy + gY;
+    b[4] = -(xn * sxy + gX);
+    b[5] = yn * gX - xn * gY;
+#else
     // the 0.5 of the central difference commutes exactly with every rounding in the sums
     const double gx = 0.5 * (gxa + gxb);
     const double gy = 0.5 * (gya + gyb);
@@ -691,6 +707,7 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
     b[3] = A[2] * gx + B[2] * gy;
     b[4] = A[3] * gx + B[3] * gy;
     b[5] = A[4] * gx + B[4] * gy;
+#endif
     return true;
 }
 
