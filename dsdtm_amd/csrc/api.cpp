@@ -766,6 +766,20 @@ extern "C" int dsdtm_pyrdown_batch_device(dsdtm_ctx* ctx, uint8_t* pyr, size_t p
         }
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // Few images (the live tracker's new frame): ONE launch builds every level, intermediate levels in LDS — the call is
+    // bound by launch latency and dependent round trips, 0.0145 -> 0.0079 ms for a 640x480x4 pyramid. Large batches are
+    // bound by HBM and run one launch per level (the fused kernel's LDS stages issue no loads: 2..30 % slower from 64
+    // images on, `tools/pyr_ab.py`). DSDTM_PYR_FUSED=0 / 2: never / whenever the shape allows (A/B, tests);
+    // DSDTM_PYR_BAND: rows of the coarsest level per workgroup.
+    const char* env_fused = getenv("DSDTM_PYR_FUSED");            // read per call (tests toggle it)
+    const char* env_band = getenv("DSDTM_PYR_BAND");
+    const int fused_mode = env_fused ? atoi(env_fused) : 1;
+    if (fused_mode == 2 || (fused_mode == 1 && n_images <= 32)) {
+        bool launched = false;
+        HIP_TRY(ctx, pyrdown_fused_launch(pyr, pyr_pitch, n_images, levels, width, height, stride, level_offset,
+                                          env_band ? atoi(env_band) : 0, (hipStream_t)hip_stream, &launched));
+        if (launched) return DSDTM_OK;
+    }
     for (int l = 1; l < levels; ++l)
         HIP_TRY(ctx, pyrdown_launch(pyr, pyr_pitch, n_images, width[l - 1], height[l - 1], stride[l - 1],
                                     level_offset[l - 1], stride[l], level_offset[l], (hipStream_t)hip_stream));

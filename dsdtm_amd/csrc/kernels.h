@@ -97,6 +97,11 @@ hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream);
 // pyrDown: one launch per level over n_images packed pyramids.
 hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, int sh, int sstride,
                           size_t soff, int dstride, size_t doff, hipStream_t stream);
+// pyrDown: all levels of n_images packed pyramids in ONE launch (band buffers of the intermediate levels in LDS).
+// *launched == false: the shape is not eligible (odd or narrow levels, unaligned buffers) and nothing was enqueued —
+// the caller falls back to one pyrdown_launch per level. band <= 0: chosen from the batch size.
+hipError_t pyrdown_fused_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int levels, const int* w, const int* h,
+                                const int* stride, const size_t* off, int band, hipStream_t stream, bool* launched);
 
 // Warp prelude: one 128-thread group per candidate (100 sample lanes).
 struct WarpKernelArgs {

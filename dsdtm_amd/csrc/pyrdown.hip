@@ -51,22 +51,28 @@ __device__ __forceinline__ u16x2 pk(uint32_t lo, uint32_t hi) {
     u16x2 v; v.x = (unsigned short)lo; v.y = (unsigned short)hi; return v;
 }
 
-// one 16-byte load of an input row at `base` (a multiple of 4). The 4th dword of the right-border strip starts at
-// the row end: it lies inside the pyramid (a source level is never the last level) and is not used.
-__device__ __forceinline__ uint4 pd_load(const uint8_t* __restrict__ src, int sstride, int row, int base) {
-    const uint32_t* __restrict__ p32 = (const uint32_t*)(src + (size_t)row * sstride + base);
-    return make_uint4(p32[0], p32[1], p32[2], p32[3]);
-}
 // horizontal [1 4 6 4 1] of a loaded input row for the 4 output columns x4..x4+3 (aligned fast path):
-// hA = (h0, h1), hB = (h2, h3)
+// hA = (h0, h1), hB = (h2, h3).
+// e0..e3 = columns xs-2 .. xs+13 with xs = 2*x4 - 2. Interior strips load exactly that (base = xs-2). The left-border
+// strip (xs = -2) needs columns -4..-1 mirrored to 4..1:
+//   SHIFTED = false: it loaded columns 0..15 (base 0) and every word moves up by one (4 selects + 1 perm per row);
+//   SHIFTED = true:  it loaded from base -4 like everybody else — the four bytes before the row start are the end of
+//                    the previous row, valid memory wherever the caller uses this form — and only e0 is replaced
+//                    (1 select + 1 perm). The kernel is bound by instruction issue as much as by HBM; this is the
+//                    form of every task that does not touch the top or bottom border.
+template <bool SHIFTED>
 __device__ __forceinline__ void pd_filter(const uint4 d, bool left, bool right, u16x2& hA, u16x2& hB) {
     const uint32_t d0 = d.x, d1 = d.y, d2 = d.z, d3 = d.w;
-    // e0..e3 = columns xs-2 .. xs+13 with xs = 2*x4 - 2; interior strips load exactly that
-    // (base = xs-2); the left-border strip (xs = -2) loads columns 0..15 and mirrors -4..-1 -> 4..1
-    const uint32_t e0 = left ? __builtin_amdgcn_perm(d1, d0, 0x01020304u) : d0;   // bytes [col4, col3, col2, col1]
-    const uint32_t e1 = left ? d0 : d1;
-    const uint32_t e2 = left ? d1 : d2;
-    const uint32_t e3 = left ? d2 : d3;
+    uint32_t e0, e1, e2, e3;
+    if constexpr (SHIFTED) {
+        e0 = left ? __builtin_amdgcn_perm(d2, d1, 0x01020304u) : d0;                 // bytes [col4, col3, col2, col1]
+        e1 = d1; e2 = d2; e3 = d3;
+    } else {
+        e0 = left ? __builtin_amdgcn_perm(d1, d0, 0x01020304u) : d0;
+        e1 = left ? d0 : d1;
+        e2 = left ? d1 : d2;
+        e3 = left ? d2 : d3;
+    }
     // output o: taps at bytes 2+2o .. 6+2o of (e0..e3)
     const uint32_t k = 0x04060401u;                                   // weights of taps 0..3; tap 4 has weight 1
     const uint32_t w0 = __builtin_amdgcn_alignbyte(e1, e0, 2);        // bytes 2..5
@@ -82,11 +88,6 @@ __device__ __forceinline__ void pd_filter(const uint4 d, bool left, bool right, 
     hA = pk(h0, h1);
     hB = pk(h2, h3);
 }
-__device__ __forceinline__ void pd_hrow(const uint8_t* __restrict__ src, int sstride, int row, int base, bool left,
-                                        bool right, u16x2& hA, u16x2& hB) {
-    pd_filter(pd_load(src, sstride, row, base), left, right, hA, hB);
-}
-
 // vertical [1 4 6 4 1] + rounding of one packed pair: ((r0 + r4) + 4 (r1 + r3) + 6 r2 + 128) >> 8
 __device__ __forceinline__ u16x2 pd_vert(u16x2 r0, u16x2 r1, u16x2 r2, u16x2 r3, u16x2 r4) {
     const u16x2 four = {4, 4}, six = {6, 6}, half = {128, 128}, eight = {8, 8};
@@ -94,16 +95,98 @@ __device__ __forceinline__ u16x2 pd_vert(u16x2 r0, u16x2 r1, u16x2 r2, u16x2 r3,
     v = r2 * six + v;
     return (v + half) >> eight;
 }
+// the four output bytes of a strip from the two packed pairs: ONE v_perm (bytes 0 and 2 of each pair)
+__device__ __forceinline__ uint32_t pd_pack(u16x2 oA, u16x2 oB) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, oB), __builtin_bit_cast(uint32_t, oA), 0x06040200u);
+}
+
+// 16 bytes of a source row: from HBM as one global_load_dwordx4 (4-byte aligned), from LDS as two ds_read_b64 (strip
+// bases are multiples of 8). The 4th dword of the right-border strip starts at the row end: in HBM it lies inside
+// the pyramid (a source level is never the last level), in LDS inside the band buffer's padding; it is not used.
+template <bool SRC_LDS>
+__device__ __forceinline__ uint4 pd_load16(const uint8_t* __restrict__ p) {
+    if constexpr (SRC_LDS) {
+        const uint2* __restrict__ q = (const uint2*)p;
+        const uint2 a = q[0], b = q[1];
+        return make_uint4(a.x, a.y, b.x, b.y);
+    } else {
+        const uint32_t* __restrict__ p32 = (const uint32_t*)p;
+        return make_uint4(p32[0], p32[1], p32[2], p32[3]);
+    }
+}
+
+// filter + store of one task whose 2*ROWS + 3 source rows are in `raw`. No control flow around the arithmetic — rows
+// behind d_hi (a ragged last chunk; never in the interior form) are computed from valid rows and not stored: with an
+// early exit per row the compiler sinks the row loads into the conditional blocks, and the point of `raw` is that
+// all of them are in flight at once.
+template <bool SHIFTED, bool FULL, bool DST_LDS, int ROWS>
+__device__ __forceinline__ void pd_rows(const uint4* raw, bool left, bool right, int y0, int x4, int d_lo, int d_hi,
+                                        uint8_t* __restrict__ ldst, int lstride, uint8_t* __restrict__ gp, int gstride,
+                                        int own_lo, int own_hi) {
+    u16x2 wA[5], wB[5];                              // horizontally filtered rows 2y-2 .. 2y+2
+    pd_filter<SHIFTED>(raw[0], left, right, wA[0], wB[0]);
+    pd_filter<SHIFTED>(raw[1], left, right, wA[1], wB[1]);
+    pd_filter<SHIFTED>(raw[2], left, right, wA[2], wB[2]);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = y0 + r;
+        // window slot of input row 2y+k-2 is (2r + k) % 5
+        pd_filter<SHIFTED>(raw[2 * r + 3], left, right, wA[(2 * r + 3) % 5], wB[(2 * r + 3) % 5]);
+        pd_filter<SHIFTED>(raw[2 * r + 4], left, right, wA[(2 * r + 4) % 5], wB[(2 * r + 4) % 5]);
+        const u16x2 oA = pd_vert(wA[(2 * r) % 5], wA[(2 * r + 1) % 5], wA[(2 * r + 2) % 5], wA[(2 * r + 3) % 5], wA[(2 * r + 4) % 5]);
+        const u16x2 oB = pd_vert(wB[(2 * r) % 5], wB[(2 * r + 1) % 5], wB[(2 * r + 2) % 5], wB[(2 * r + 3) % 5], wB[(2 * r + 4) % 5]);
+        const uint32_t packed = pd_pack(oA, oB);
+        if constexpr (DST_LDS) { if (FULL || y < d_hi) *(uint32_t*)(ldst + (ptrdiff_t)(y - d_lo) * lstride + x4) = packed; }
+        if (y >= own_lo && y < own_hi) *(uint32_t*)(gp + (ptrdiff_t)r * gstride) = packed;      // own_hi <= d_hi
+    }
+}
+
+// One strip task of the aligned fast path: output rows y0 .. y0+ROWS-1 (below d_hi) x output columns x4 .. x4+3.
+// All 2*ROWS + 3 source rows are in flight before the first one is filtered (the sliding-window loop otherwise waits
+// for two rows per output row, and ~2 loads per wave in flight is short of what keeps HBM busy). Row addressing:
+// away from the top and bottom of the level the rows of a task are consecutive — one address and compile-time
+// multiples of the stride; only tasks that touch a border reflect (BORDER_REFLECT_101, one reflection: sh >= 4).
+// (The first version called a general reflect101() with its while loop for every row: 19 divergent loops per task,
+// a quarter of the kernel's instructions.) `src` points at row s_row0 of the source level; `last` is the last source
+// row index (before reflection) the caller's row range needs.
+template <bool SRC_LDS, bool DST_LDS, int ROWS>
+__device__ __forceinline__ void pd_task(const uint8_t* __restrict__ src, int sstride, int s_row0, int sw, int sh, int y0, int x4,
+                                        int d_lo, int d_hi, int last, uint8_t* __restrict__ ldst, int lstride,
+                                        uint8_t* __restrict__ gdst, int gstride, int own_lo, int own_hi) {
+    const int xs = 2 * x4 - 2;                       // first input column needed (x4 is a multiple of 4)
+    // Interior strips read columns (xs-2)..(xs+13) and use bytes 2..12; the left-border strip (xs = -2) reads columns
+    // 0..15 and mirrors; the right-border strip of an even-width level needs column sw -> sw-2. Keeping the border
+    // lanes on this path matters: one lane on a byte-wise path stalls its whole wave.
+    const bool left = (x4 == 0);
+    const bool right = (xs + 10 >= sw);
+    const int base = left ? 0 : (xs - 2);            // multiple of 4 (of 8 from the second strip on)
+    const int t0 = 2 * y0 - 2;
+    uint4 raw[2 * ROWS + 3];
+    uint8_t* __restrict__ gp = gdst + (ptrdiff_t)y0 * gstride + x4;
+    if (t0 >= (SRC_LDS ? 0 : 1) && t0 + 2 * ROWS + 2 <= min(last, sh - 1)) {
+        // (HBM source: the shifted form of the left strip reads 4 bytes before its rows, hence not row 0)
+        constexpr bool SH = !SRC_LDS;
+        const uint8_t* __restrict__ p = src + (ptrdiff_t)(t0 - s_row0) * sstride + (SH ? xs - 2 : base);
+#pragma unroll
+        for (int k = 0; k < 2 * ROWS + 3; ++k) raw[k] = pd_load16<SRC_LDS>(p + (ptrdiff_t)k * sstride);
+        pd_rows<SH, true, DST_LDS, ROWS>(raw, left, right, y0, x4, d_lo, d_hi, ldst, lstride, gp, gstride, own_lo, own_hi);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2 * ROWS + 3; ++k) {
+            int r = min(t0 + k, last);               // rows behind the caller's range: any valid row (their outputs are not stored)
+            r = r < 0 ? -r : r;
+            r = r >= sh ? 2 * sh - 2 - r : r;
+            raw[k] = pd_load16<SRC_LDS>(src + (ptrdiff_t)(r - s_row0) * sstride + base);
+        }
+        pd_rows<false, false, DST_LDS, ROWS>(raw, left, right, y0, x4, d_lo, d_hi, ldst, lstride, gp, gstride, own_lo, own_hi);
+    }
+}
 
 // XCD-aware block numbering. Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own
 // L2: with the plain numbering the blocks of ONE image — whose row chunks share 3 halo rows with their
 // neighbours — are spread over all eight L2s and every halo row is fetched from HBM by two of them. The
 // remapped id gives each XCD a contiguous range of (image, block) pairs, so an image's blocks meet in one L2.
 // SA_PD_XCD=0 restores the plain numbering (A/B).
-// all input rows of a thread's chunk loaded before the filtering starts (see the fast path)
-#ifndef SA_PD_PREFETCH
-#define SA_PD_PREFETCH 1
-#endif
 #ifndef SA_PD_XCD
 #define SA_PD_XCD 1
 #endif
@@ -130,57 +213,12 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const PyrDownArgs a, int t
     uint8_t* __restrict__ dst = a.pyr + (size_t)img * a.pyr_pitch + a.doff;
     const int xs = 2 * x4 - 2;                       // first input column needed (x4 is a multiple of 4)
 
-    // Fast path: the 11 input columns xs..xs+10 of a row come from ONE 16-byte load. Interior threads
-    // read columns (xs-2)..(xs+13) and use bytes 2..12; the left-border thread (xs = -2) reads
-    // columns 0..15 and mirrors; the right-border thread of an even-width image needs column
-    // sw -> sw-2. Keeping the border lanes on this path matters: one lane on the byte-wise path
-    // stalls its whole wave.
-    const bool left = (x4 == 0);
+    // Fast path (pd_task): the 11 input columns xs..xs+10 of a row come from ONE 16-byte load.
     const bool right = (xs + 10 >= a.sw);             // only column xs+10 == sw can be outside
-    const bool fast = ((a.sstride & 3) == 0) && ((((size_t)src) & 3) == 0) && ((a.sw & 1) == 0) && a.sw >= 16 &&
+    const bool fast = ((a.sstride & 3) == 0) && ((((size_t)src) & 3) == 0) && ((a.sw & 1) == 0) && a.sw >= 16 && a.sh >= 4 &&
                       (x4 + 3 < a.dw) && (!right || xs + 10 == a.sw) && (((size_t)(dst + x4)) & 3) == 0 && (a.dstride & 3) == 0;
     if (fast) {
-        const int base = left ? 0 : (xs - 2);         // multiple of 4
-        u16x2 wA[5], wB[5];                           // horizontally filtered rows 2y-2 .. 2y+2
-#if SA_PD_PREFETCH
-        // all 2*PD_ROWS + 3 input rows of the chunk in flight before the first one is filtered: the sliding-window
-        // loop below otherwise waits for two rows per output row, and ~2 loads per wave in flight at 7 waves per
-        // SIMD is short of what keeps HBM busy (Little: ~47 KB per CU at 6 TB/s and 2 us)
-        uint4 raw[2 * PD_ROWS + 3];
-#pragma unroll
-        for (int k = 0; k < 2 * PD_ROWS + 3; ++k)
-            raw[k] = pd_load(src, a.sstride, reflect101(min(2 * y0 - 2 + k, 2 * a.dh), a.sh), base);
-        pd_filter(raw[0], left, right, wA[0], wB[0]);
-        pd_filter(raw[1], left, right, wA[1], wB[1]);
-        pd_filter(raw[2], left, right, wA[2], wB[2]);
-#pragma unroll
-        for (int r = 0; r < PD_ROWS; ++r) {
-            const int y = y0 + r;
-            if (y >= a.dh) break;
-            pd_filter(raw[2 * r + 3], left, right, wA[(2 * r + 3) % 5], wB[(2 * r + 3) % 5]);
-            pd_filter(raw[2 * r + 4], left, right, wA[(2 * r + 4) % 5], wB[(2 * r + 4) % 5]);
-            const u16x2 oA = pd_vert(wA[(2 * r) % 5], wA[(2 * r + 1) % 5], wA[(2 * r + 2) % 5], wA[(2 * r + 3) % 5], wA[(2 * r + 4) % 5]);
-            const u16x2 oB = pd_vert(wB[(2 * r) % 5], wB[(2 * r + 1) % 5], wB[(2 * r + 2) % 5], wB[(2 * r + 3) % 5], wB[(2 * r + 4) % 5]);
-            const uint32_t packed = (uint32_t)oA.x | ((uint32_t)oA.y << 8) | ((uint32_t)oB.x << 16) | ((uint32_t)oB.y << 24);
-            *(uint32_t*)(dst + (size_t)y * a.dstride + x4) = packed;
-        }
-        return;
-#endif
-        pd_hrow(src, a.sstride, reflect101(2 * y0 - 2, a.sh), base, left, right, wA[0], wB[0]);
-        pd_hrow(src, a.sstride, reflect101(2 * y0 - 1, a.sh), base, left, right, wA[1], wB[1]);
-        pd_hrow(src, a.sstride, reflect101(2 * y0, a.sh), base, left, right, wA[2], wB[2]);
-#pragma unroll
-        for (int r = 0; r < PD_ROWS; ++r) {
-            const int y = y0 + r;
-            if (y >= a.dh) break;
-            // window slot of input row 2y+k-2 is (2r + k) % 5
-            pd_hrow(src, a.sstride, reflect101(2 * y + 1, a.sh), base, left, right, wA[(2 * r + 3) % 5], wB[(2 * r + 3) % 5]);
-            pd_hrow(src, a.sstride, reflect101(2 * y + 2, a.sh), base, left, right, wA[(2 * r + 4) % 5], wB[(2 * r + 4) % 5]);
-            const u16x2 oA = pd_vert(wA[(2 * r) % 5], wA[(2 * r + 1) % 5], wA[(2 * r + 2) % 5], wA[(2 * r + 3) % 5], wA[(2 * r + 4) % 5]);
-            const u16x2 oB = pd_vert(wB[(2 * r) % 5], wB[(2 * r + 1) % 5], wB[(2 * r + 2) % 5], wB[(2 * r + 3) % 5], wB[(2 * r + 4) % 5]);
-            const uint32_t packed = (uint32_t)oA.x | ((uint32_t)oA.y << 8) | ((uint32_t)oB.x << 16) | ((uint32_t)oB.y << 24);
-            *(uint32_t*)(dst + (size_t)y * a.dstride + x4) = packed;
-        }
+        pd_task<false, false, PD_ROWS>(src, a.sstride, 0, a.sw, a.sh, y0, x4, 0, a.dh, 2 * a.dh, nullptr, 0, dst, a.dstride, 0, a.dh);
         return;
     }
     // generic path (odd widths, unaligned buffers, ragged right edge): byte-wise BORDER_REFLECT_101
@@ -211,6 +249,145 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const PyrDownArgs a, int t
 // filter from the neighbouring lanes with two DPP wave shifts instead of from overlapping loads. Bit-exact, and
 // 5–8 % SLOWER than the kernel above on the same box (0.252–0.265 vs 0.243–0.246 ms for 2048 pyramids): the
 // overlapping bytes are L1 hits and were never the limit. Removed.)
+
+// ---------------------------------------------------------------------------------------------
+// One launch per pyramid: every level from level 0 in ONE kernel (Frame::ComputeImagePyramid, src/Frame.cpp:74-81).
+//
+// A workgroup owns a BAND of rows of the coarsest level (full width) and everything above it: it reads the level-0
+// rows the band depends on from HBM, filters them into level 1 (kept in LDS, owned rows also written out), level 1
+// into level 2 from LDS, and so on — levels 1.. are never read back from HBM, so a 4-level 640x480 pyramid moves
+// 307 200 + 100 800 bytes instead of the 504 000 of three separate launches, and there is one launch instead of three.
+// Rows a band needs beyond its own (the [1 4 6 4 1] halo, 2 rows per side and level) are recomputed: a band of b rows
+// of level K needs 2^K b + 3 (2^K - 1) rows of level 0 (141 for b = 15, K = 3: 1.175x, and the neighbouring band's
+// rows are L2 hits with the XCD-aware block numbering). Every stage is the per-level kernel's strip code (4 output
+// columns x PD_ROWS output rows per thread, dot4 + packed u16), so the bytes are the same bytes.
+struct PyrFusedArgs {
+    uint8_t* pyr;
+    size_t pyr_pitch;
+    int band, n_bands;                      // rows of the coarsest level per workgroup
+    int w[DSDTM_MAX_LEVELS], h[DSDTM_MAX_LEVELS], stride[DSDTM_MAX_LEVELS];
+    unsigned long long off[DSDTM_MAX_LEVELS];
+    int lds_off[DSDTM_MAX_LEVELS];          // band buffer of level l (1 <= l <= K-1) in dynamic LDS: byte offset
+    int lds_stride[DSDTM_MAX_LEVELS];       //   and row stride
+};
+
+// rows [d_lo, d_hi) of a level from rows of the level below. `src` points at row s_row0 of the source level.
+// ROWS = output rows per thread: 8 for the level-0 stage (every input row loaded and filtered once per 2..3 outputs,
+// as in the per-level kernel), fewer for the stages that read LDS — those are short, and what matters is that a
+// workgroup gets through them quickly (more, shorter tasks), because it issues no HBM loads meanwhile.
+#ifndef SA_PF_ROWS_G
+#define SA_PF_ROWS_G 8
+#endif
+#ifndef SA_PF_ROWS_L
+#define SA_PF_ROWS_L 2
+#endif
+template <bool SRC_LDS, bool DST_LDS, int ROWS>
+__device__ __forceinline__ void pf_stage(const uint8_t* __restrict__ src, int sstride, int s_row0, int sw, int sh,
+                                         int d_lo, int d_hi, int dw, uint8_t* __restrict__ ldst, int lstride,
+                                         uint8_t* __restrict__ gdst, int gstride, int own_lo, int own_hi) {
+    const int tx = dw >> 2;
+    const int chunks = (d_hi - d_lo + ROWS - 1) / ROWS;
+    for (int task = threadIdx.x; task < tx * chunks; task += blockDim.x) {
+        const int ch = task / tx;
+        pd_task<SRC_LDS, DST_LDS, ROWS>(src, sstride, s_row0, sw, sh, d_lo + ch * ROWS, (task - ch * tx) * 4, d_lo, d_hi, 2 * d_hi,
+                                        ldst, lstride, gdst, gstride, own_lo, own_hi);
+    }
+}
+
+template <int K>     // K = number of downsampling steps (levels - 1), 2..4
+__global__ __launch_bounds__(256) void pyrdown_fused_kernel(const PyrFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pf_lds[];
+    int img, band;
+    pd_block(img, band);
+    // row ranges per level: [lo, hi) computed by this workgroup, [olo, ohi) written to HBM by it
+    int lo[K + 1], hi[K + 1], olo[K + 1], ohi[K + 1];
+    lo[K] = band * a.band; hi[K] = min(a.h[K], lo[K] + a.band);
+    olo[K] = lo[K]; ohi[K] = hi[K];
+#pragma unroll
+    for (int l = K - 1; l >= 0; --l) {
+        lo[l] = max(0, 2 * lo[l + 1] - 2); hi[l] = min(a.h[l], 2 * hi[l + 1] + 1);
+        olo[l] = 2 * olo[l + 1]; ohi[l] = (band == a.n_bands - 1) ? a.h[l] : min(a.h[l], 2 * ohi[l + 1]);
+    }
+    uint8_t* __restrict__ base = a.pyr + (size_t)img * a.pyr_pitch;
+    // level 0 (HBM) -> level 1 (LDS + owned rows)
+    pf_stage<false, true, SA_PF_ROWS_G>(base + a.off[0], a.stride[0], 0, a.w[0], a.h[0], lo[1], hi[1], a.w[1],
+                          pf_lds + a.lds_off[1], a.lds_stride[1], base + a.off[1], a.stride[1], olo[1], ohi[1]);
+    __syncthreads();
+#pragma unroll
+    for (int l = 2; l < K; ++l) {
+        pf_stage<true, true, SA_PF_ROWS_L>(pf_lds + a.lds_off[l - 1], a.lds_stride[l - 1], lo[l - 1], a.w[l - 1], a.h[l - 1], lo[l], hi[l], a.w[l],
+                             pf_lds + a.lds_off[l], a.lds_stride[l], base + a.off[l], a.stride[l], olo[l], ohi[l]);
+        __syncthreads();
+    }
+    pf_stage<true, false, SA_PF_ROWS_L>(pf_lds + a.lds_off[K - 1], a.lds_stride[K - 1], lo[K - 1], a.w[K - 1], a.h[K - 1], lo[K], hi[K], a.w[K],
+                          nullptr, 0, base + a.off[K], a.stride[K], olo[K], ohi[K]);
+}
+
+// Can the whole pyramid go through the fused kernel? (every source level on the aligned fast path of the strip code)
+static bool pyrdown_fused_ok(const uint8_t* pyr, size_t pyr_pitch, int levels, const int* w, const int* h, const int* stride,
+                             const size_t* off) {
+    if (levels < 3 || levels > 5) return false;
+    if (((size_t)pyr & 3) || (pyr_pitch & 3)) return false;
+    for (int l = 0; l < levels; ++l) {
+        if ((stride[l] & 3) || (off[l] & 3)) return false;
+        if (l < levels - 1 && ((w[l] & 7) || w[l] < 16)) return false;      // even width, whole strips of 4 outputs
+        if (h[l] < (l < levels - 1 ? 4 : 1)) return false;                  // one reflection at the top and bottom
+    }
+    return true;
+}
+
+hipError_t pyrdown_fused_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int levels, const int* w, const int* h,
+                                const int* stride, const size_t* off, int band, hipStream_t stream, bool* launched) {
+    *launched = false;
+    if (n_images <= 0) { *launched = true; return hipSuccess; }
+    if (!pyrdown_fused_ok(pyr, pyr_pitch, levels, w, h, stride, off)) return hipSuccess;
+    const int K = levels - 1;
+    PyrFusedArgs a;
+    a.pyr = pyr; a.pyr_pitch = pyr_pitch;
+    for (int l = 0; l < DSDTM_MAX_LEVELS; ++l) { a.w[l] = a.h[l] = a.stride[l] = 0; a.off[l] = 0; a.lds_off[l] = 0; a.lds_stride[l] = 0; }
+    for (int l = 0; l < levels; ++l) { a.w[l] = w[l]; a.h[l] = h[l]; a.stride[l] = stride[l]; a.off[l] = off[l]; }
+    // band height: few bands per image for batches (little halo), many for a single frame (parallelism)
+    if (band <= 0) {
+        const int want_groups = 2048;
+        int nb = (want_groups + n_images - 1) / n_images;
+        nb = nb < 4 ? 4 : nb;
+        band = (h[K] + nb - 1) / nb;
+        if (band < 2) band = 2;
+    }
+    if (band > h[K]) band = h[K];
+    size_t lds = 0;
+    for (;;) {
+        a.band = band; a.n_bands = (h[K] + band - 1) / band;
+        lds = 0;
+        for (int l = 1; l < K; ++l) {
+            int rows = 0;
+            for (int b = 0; b < a.n_bands; ++b) {                       // widest band of this level
+                int lo = b * band, hi = lo + band < h[K] ? lo + band : h[K];
+                for (int m = K - 1; m >= l; --m) {
+                    lo = 2 * lo - 2 > 0 ? 2 * lo - 2 : 0;
+                    hi = 2 * hi + 1 < h[m] ? 2 * hi + 1 : h[m];
+                }
+                rows = hi - lo > rows ? hi - lo : rows;
+            }
+            a.lds_off[l] = (int)lds; a.lds_stride[l] = w[l];
+            lds += ((size_t)rows * w[l] + 16 + 15) / 16 * 16;           // + the right-border strip's unused fourth dword
+        }
+        if (lds <= 64 * 1024 || band <= 2) break;
+        band = (band + 1) / 2;                                          // smaller bands until the band buffers fit
+    }
+    if (lds > 64 * 1024) return hipSuccess;
+    for (int i0 = 0; i0 < n_images; i0 += 65535) {
+        const int nz = (n_images - i0 < 65535) ? n_images - i0 : 65535;
+        PyrFusedArgs b = a;
+        b.pyr = pyr + (size_t)i0 * pyr_pitch;
+        const dim3 grid((unsigned)a.n_bands, 1u, (unsigned)nz);
+        if (K == 2) hipLaunchKernelGGL(pyrdown_fused_kernel<2>, grid, dim3(256), lds, stream, b);
+        else if (K == 3) hipLaunchKernelGGL(pyrdown_fused_kernel<3>, grid, dim3(256), lds, stream, b);
+        else hipLaunchKernelGGL(pyrdown_fused_kernel<4>, grid, dim3(256), lds, stream, b);
+    }
+    *launched = true;
+    return hipGetLastError();
+}
 
 hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, int sh, int sstride,
                           size_t soff, int dstride, size_t doff, hipStream_t stream) {
