@@ -44,6 +44,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dsdtm_amd.h"
 #include "device_math.h"
@@ -129,6 +130,9 @@ constexpr unsigned SPIN_LIMIT = 1u << 24;
 // bound by VALU issue on the SIMDs that carry three patch waves).
 #ifndef SA_PACKED_REDUCE
 #define SA_PACKED_REDUCE 1
+#endif
+#ifndef SA_VIS_BALLOT
+#define SA_VIS_BALLOT 1
 #endif
 #ifndef SA_SLEEP_ARRIVE
 #define SA_SLEEP_ARRIVE 1   // solver waiting for the patch waves (and for acknowledgements)
@@ -526,6 +530,15 @@ __device__ __forceinline__ bool project_patch(const SAKernelArgs& a, const Level
     // :262 with mnboarder = 3 on floored ints: floor(u) >= 3 && floor(u)+3 < cols (NaN fails). Evaluated without
     // short-circuits: the pass is bound by VALU issue, and nested early-outs made the compiler re-zero the seven
     // result registers on every arm (21 moves on the visible path)
+#if SA_VIS_BALLOT
+    // four v_cmp into SGPR pairs + three s_and (scalar unit) + the combined mask as the lane condition; written with `&`
+    // on the bools, the vectoriser packs the four bits into an i4 and the backend spends ~15 VALU instructions on it
+    {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(u >= 3.0) & __builtin_amdgcn_ballot_w64(u < (double)(lg.w - 3)) &
+                                     __builtin_amdgcn_ballot_w64(v >= 3.0) & __builtin_amdgcn_ballot_w64(v < (double)(lg.h - 3));
+        return __builtin_amdgcn_inverse_ballot_w64(m);
+    }
+#endif
     if (SA_PASS_LEAN) return (u >= 3.0) & (u < (double)(lg.w - 3)) & (v >= 3.0) & (v < (double)(lg.h - 3));
     return u >= 3.0 && u < (double)(lg.w - 3) && v >= 3.0 && v < (double)(lg.h - 3);
 }
@@ -1455,6 +1468,9 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
 #ifndef SA_WS_NPW
 #define SA_WS_NPW 7
 #endif
+#ifndef SA_WS_WINDOWS
+#define SA_WS_WINDOWS 1
+#endif
 constexpr int WS_DWORDS = 22;   // rlo[7], rhi[7], px, py, X[3] as dword pairs
 __host__ __device__ inline size_t ws_doubles_per_pair(int max_features) {
     const size_t npad = ((size_t)max_features + 63) / 64 * 64;
@@ -1497,11 +1513,17 @@ __device__ __forceinline__ void ws_patch_regs(const WsPatch& w, const LevelGeom&
     grid_from_rows<double>(w.F, g, w.rlo, w.rhi, P);
 }
 
-template <int NPW>
+// WCAP > 0: current-image footprint windows in LDS as in the register kernels (residual_patch, WIN_NL = WCAP): one
+// column of 15 dwords + the window's origin per PATCH (not per lane; a thread always handles the same patches), in
+// dynamic LDS — 64 KB for up to 1024 patches, 128 KB for up to 2048. Without them every pass gathers its five
+// footprint rows per patch through the CU's texture-address path again (the round-2 kernel: 1024 pairs of 1000
+// patches 1.03 ms per launch).
+template <int NPW, int WCAP>
 __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const SAKernelArgs a) {
     constexpr int PT = NPW * 64;   // patch threads
     __shared__ WavePartial s_part[NPW];
     __shared__ BlockState s;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ws_win[];   // [16][WCAP]: 15 window planes + origins
 
     const int pair = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1555,6 +1577,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
         {
             const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
             for (int p = tid; p < (int)npad; p += PT) {
+                if constexpr (WCAP > 0) ws_win[15 * WCAP + p] = WIN_EMPTY;      // the level's windows are filled by its first pass
                 WsPatch w;
                 w.F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + p, p < nf), Cref);
                 const RefGeom g = ref_geom(w.F, lg, level);
@@ -1588,7 +1611,15 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
                     ws_patch_regs(w, lg, level, P);
                 }
                 double c2, bp[6];
-                const bool vis = residual_patch<double>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp);
+                bool vis;
+                if constexpr (WCAP > 0) {
+                    uint32_t worg = ws_win[15 * WCAP + p];
+                    const uint32_t worg0 = worg;
+                    vis = residual_patch<double, WCAP>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp, (LdsU32*)&ws_win[p], &worg);
+                    if (worg != worg0) ws_win[15 * WCAP + p] = worg;
+                } else {
+                    vis = residual_patch<double>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp);
+                }
                 if (vis) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) b[i] += bp[i];
@@ -1938,7 +1969,7 @@ int sparse_align_occupancy(int variant) {
     int nb = -1;
     if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, false>, SA_PPW * 6 * 64, 0);
     else if (variant == SA_REG448) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<7, SA_GRID_T, 1, false>, 8 * 64, 0);
-    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<SA_WS_NPW>, (SA_WS_NPW + 1) * 64, 0);
+    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<SA_WS_NPW, 0>, (SA_WS_NPW + 1) * 64, 0);
     return nb;
 }
 
@@ -1970,9 +2001,23 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
         case SA_REG320: return launch_reg<5, SA_PPW, false>(args, num_cus, stream);
         case SA_REG448: return launch_reg<7, 1, false>(args, num_cus, stream);
         case SA_REG704: return launch_reg<11, 1, false>(args, num_cus, stream);
-        case SA_WS:
-            hipLaunchKernelGGL((sparse_align_ws_kernel<SA_WS_NPW>), dim3((unsigned)args.n_pairs), dim3((SA_WS_NPW + 1) * 64), 0, stream, args);
+        case SA_WS: {
+            const int npad = (args.max_features + 63) / 64 * 64;
+            static const bool ws_windows = SA_WS_WINDOWS && getenv("DSDTM_WS_NO_WINDOWS") == nullptr;
+            if (ws_windows && npad <= 1024) {
+                hipLaunchKernelGGL((sparse_align_ws_kernel<SA_WS_NPW, 1024>), dim3((unsigned)args.n_pairs), dim3((SA_WS_NPW + 1) * 64),
+                                   16 * 1024 * sizeof(uint32_t), stream, args);
+            } else if (ws_windows && npad <= 2048) {
+                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<SA_WS_NPW, 2048>,
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * sizeof(uint32_t));
+                if (attr != hipSuccess) return attr;
+                hipLaunchKernelGGL((sparse_align_ws_kernel<SA_WS_NPW, 2048>), dim3((unsigned)args.n_pairs), dim3((SA_WS_NPW + 1) * 64),
+                                   16 * 2048 * sizeof(uint32_t), stream, args);
+            } else {
+                hipLaunchKernelGGL((sparse_align_ws_kernel<SA_WS_NPW, 0>), dim3((unsigned)args.n_pairs), dim3((SA_WS_NPW + 1) * 64), 0, stream, args);
+            }
             break;
+        }
     }
     return hipGetLastError();
 }
