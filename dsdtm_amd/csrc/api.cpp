@@ -1041,12 +1041,24 @@ extern "C" int dsdtm_pose_optimization(dsdtm_ctx* ctx, const double* bearing, co
         memcpy(h + o_l, level, N * 4);
         memcpy(h + o_u, use, N);
     }
-    HIP_TRY(ctx, hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, ctx->stream));
+    // Up to 512 features the kernel keeps a lane's features in registers (pose_opt.hip, CACHED): every input is read once,
+    // so it reads them straight from the pinned block and writes pose, summary and norms there — no copy operations
+    // around the launch (DSDTM_NO_ZERO_COPY=1 restores them). Larger frames re-read their columns at every evaluation
+    // and are copied to the device first.
+    static const bool zero_copy_enabled = getenv("DSDTM_NO_ZERO_COPY") == nullptr;
+    const bool zero_copy = zero_copy_enabled && n_features > 64 && n_features <= 512 && getenv("DSDTM_PO_NO_CACHE") == nullptr;
+    if (zero_copy) {
+        void* hd = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&hd, ctx->h_pinned, 0));
+        d = (uint8_t*)hd;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (int rc = dsdtm_pose_optimization_batch_device(ctx, 1, n_features, nullptr, (const double*)(d + o_b),
                                                       (const double*)(d + o_p), (const int32_t*)(d + o_l), d + o_u,
                                                       (double*)(d + o_T), params, (double*)(d + o_rn),
                                                       (dsdtm_pose_opt_summary*)(d + o_sm), ctx->stream)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(h, d, out_end, hipMemcpyDeviceToHost, ctx->stream));
+    if (!zero_copy) HIP_TRY(ctx, hipMemcpyAsync(h, d, out_end, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(T_cur_w, h + o_T, 96);
     memcpy(summary, h + o_sm, sizeof(*summary));

@@ -19,6 +19,7 @@
 // evaluation); throughput comes from problems in flight, not from bandwidth.
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stdlib.h>
 
 #include "device_math.h"
 #include "kernels.h"
@@ -31,6 +32,8 @@ namespace {
 // iteration loop, their ~60 polynomial coefficients are hoisted out of it as loop invariants and held in
 // registers for the whole kernel (296 VGPRs, one wave per SIMD); out of line the kernel needs 2/3 of that.
 // Scalar in, scalar out: arguments and results travel in registers, nothing goes through the stack.
+// (The few-frames instantiation — one frame of the live tracker, one wave per SIMD — has the whole register file
+// to itself: there LAT = true inlines them, which saves the call sequences on the iteration's dependent chain.)
 __device__ __attribute__((noinline)) double log_out_of_line(double v) { return log(v); }
 __device__ __attribute__((noinline)) double atan_out_of_line(double v) { return atan(v); }
 struct SinCos { double s, c; };
@@ -39,8 +42,14 @@ __device__ __attribute__((noinline)) SinCos sincos_out_of_line(double v) {
     sincos(v, &r.s, &r.c);
     return r;
 }
+template <bool LAT> __device__ __forceinline__ double po_log(double v) { if constexpr (LAT) return log(v); else return log_out_of_line(v); }
+template <bool LAT> __device__ __forceinline__ double po_atan(double v) { if constexpr (LAT) return atan(v); else return atan_out_of_line(v); }
+template <bool LAT> __device__ __forceinline__ SinCos po_sincos(double v) {
+    if constexpr (LAT) { SinCos r; sincos(v, &r.s, &r.c); return r; } else return sincos_out_of_line(v);
+}
 // x = [t, w] -> SE3(SO3::exp(w), t) (include/Optimizer.h:147). The quaternion part of se3_exp
 // (device_math.h) on its own: same series / closed forms, same normalisation, no V matrix.
+template <bool LAT>
 __device__ __forceinline__ SE3d pose_of(const double* x) {
     const double wx = x[3], wy = x[4], wz = x[5];
     const double theta_sq = wx * wx + wy * wy + wz * wz;
@@ -57,7 +66,7 @@ __device__ __forceinline__ SE3d pose_of(const double* x) {
         }
     } else {
         const double theta = sqrt(theta_sq);
-        const SinCos sc = sincos_out_of_line(0.5 * theta);
+        const SinCos sc = po_sincos<LAT>(0.5 * theta);
         ch = sc.c;
         imag_factor = sc.s * (1.0 / theta);
     }
@@ -69,21 +78,23 @@ __device__ __forceinline__ SE3d pose_of(const double* x) {
 }
 
 // Sophus SO3::log (atan form) of a unit quaternion
+template <bool LAT>
 __device__ __forceinline__ void so3_log(const SE3d& q, double* w) {
     const double n = sqrt(q.qx * q.qx + q.qy * q.qy + q.qz * q.qz);
     const double qw = q.qw;
     double f;
     if (n < 1e-10) f = 2. / qw - 2. * (n * n) / (qw * (qw * qw));
-    else f = 2 * atan_out_of_line(n / qw) / n;
+    else f = 2 * po_atan<LAT>(n / qw) / n;
     w[0] = f * q.qx; w[1] = f * q.qy; w[2] = f * q.qz;
 }
 
 // PoseLocalParameterization::Plus (include/Optimizer.h:222-236)
+template <bool LAT>
 __device__ __forceinline__ void pose_plus(const SE3d& To /* pose_of(x) */, const double* d, double* out) {
-    const SE3d Td = pose_of(d);
+    const SE3d Td = pose_of<LAT>(d);
     const SE3d Tn = se3_mul(Td, To);
     out[0] = Tn.tx; out[1] = Tn.ty; out[2] = Tn.tz;
-    so3_log(Tn, out + 3);
+    so3_log<LAT>(Tn, out + 3);
 }
 
 
@@ -117,6 +128,36 @@ __device__ __forceinline__ bool block_residual(const Frame& f, int i, const SE3d
     return true;
 }
 
+// A lane's feature held in registers (few-frames instantiation with at most one feature per lane): the columns are
+// read from memory ONCE — so the host entry point can hand them over in pinned host memory, no copy — and the two
+// quotients that do not depend on the pose are formed once (the same IEEE divisions, the same bits).
+struct FeatRegs {
+    bool use;
+    double bx, by;          // b0 / b2, b1 / b2
+    double X, Y, Z;
+    double inv_scale;
+};
+__device__ __forceinline__ FeatRegs load_feature(const Frame& f, int i) {
+    FeatRegs r;
+    r.use = i < f.n && f.use[i];
+    r.bx = r.by = r.X = r.Y = r.Z = 0.0; r.inv_scale = 1.0;
+    if (r.use) {
+        const double b0 = f.bearing[3 * (size_t)i], b1 = f.bearing[3 * (size_t)i + 1], b2 = f.bearing[3 * (size_t)i + 2];
+        r.bx = b0 / b2; r.by = b1 / b2;
+        r.X = f.pw[3 * (size_t)i]; r.Y = f.pw[3 * (size_t)i + 1]; r.Z = f.pw[3 * (size_t)i + 2];
+        r.inv_scale = __hiloint2double((1023 - (f.level[i] & 31)) << 20, 0);
+    }
+    return r;
+}
+__device__ __forceinline__ void block_residual_regs(const FeatRegs& c, const SE3d& T, double& r0, double& r1,
+                                                    double& px, double& py, double& pz) {
+    double rx, ry, rz;
+    quat_rotate(T, c.X, c.Y, c.Z, rx, ry, rz);
+    px = rx + T.tx; py = ry + T.ty; pz = rz + T.tz;
+    r0 = (c.bx - px / pz) * c.inv_scale;
+    r1 = (c.by - py / pz) * c.inv_scale;
+}
+
 // Program evaluation at pose T: cost = sum 1/2 rho(|r|^2) (wave-uniform); H = J^T J (upper triangle,
 // row-major) and g = J^T r of the loss-corrected blocks go to hg[0..20], hg[21..26] in LDS (the solver part
 // reads what it needs, when it needs it; the 27 totals are not live in registers across the next
@@ -125,9 +166,11 @@ __device__ __forceinline__ bool block_residual(const Frame& f, int i, const SE3d
 // NW waves per frame: one for batches (the wave-uniform solver part is executed once per frame), four for a
 // few frames (the live tracker's single frame: the features spread over 256 lanes, every wave repeats the
 // solver part on the same totals and so takes the same decisions — no broadcast).
-template <int NW>
-__device__ void evaluate(const Frame& f, int tid, const SE3d& T /* pose_of(x) */, double& cost, double* hg, double* part,
-                         double* red, bool& ok) {
+template <int NW, int FPL>      // FPL: features per lane held in registers (0: read from memory at every evaluation)
+__device__ void evaluate(const Frame& f, const FeatRegs* fr, int tid, const SE3d& T /* pose_of(x) */, double& cost, double* hg,
+                         double* part, double* red, bool& ok) {
+    constexpr bool LAT = NW > 1;
+    constexpr bool CACHED = FPL > 0;
     const int lane = tid & 63, wave = tid >> 6;
     double c = 0.0, h[21], gg[6];
     bool bad = false;
@@ -135,9 +178,15 @@ __device__ void evaluate(const Frame& f, int tid, const SE3d& T /* pose_of(x) */
     for (int k = 0; k < 21; ++k) h[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) gg[k] = 0.0;
-    for (int i = tid; i < f.n; i += NW * 64) {
+#pragma unroll
+    for (int i = tid, j = 0; CACHED ? j < FPL : i < f.n; i += NW * 64, ++j) {
         double r0, r1, px, py, pz;
-        if (!block_residual(f, i, T, r0, r1, px, py, pz)) continue;
+        if constexpr (CACHED) {
+            if (!fr[j].use) continue;
+            block_residual_regs(fr[j], T, r0, r1, px, py, pz);
+        } else {
+            if (!block_residual(f, i, T, r0, r1, px, py, pz)) continue;
+        }
         const double z_inv = 1.0 / pz;
         const double z_inv2 = z_inv * z_inv;
         double J0[6], J1[6];
@@ -147,7 +196,7 @@ __device__ void evaluate(const Frame& f, int tid, const SE3d& T /* pose_of(x) */
         const double s = r0 * r0 + r1 * r1;
         const double sum = 1.0 + s;                         // CauchyLoss(1.0): b = c = 1
         const double inv = 1.0 / sum;
-        c += 0.5 * log_out_of_line(sum);
+        c += 0.5 * po_log<LAT>(sum);
         const double sq = sqrt(fmax(inv, DBL_MIN));         // Corrector, alpha = 0 (rho'' < 0)
 #pragma unroll
         for (int k = 0; k < 6; ++k) { J0[k] *= sq; J1[k] *= sq; }
@@ -250,11 +299,22 @@ __device__ __forceinline__ double norm6(const double* v) {
     return sqrt(s);
 }
 
+// max |x - Plus(x, -g)|, used by exactly one test: gmax <= 1e-10. To first order x - Plus(x, -g) is g itself (the
+// rotation part through a left Jacobian whose singular values stay within [1/2, 2] for |w| < pi), so a gradient with
+// an entry above 1e-6 cannot pass that test and the exact value is not needed: the few-frames instantiation then
+// returns the gradient's own max norm and saves one Plus (exp, product, log with its atan) per accepted step.
+template <bool LAT>
 __device__ __forceinline__ double gradient_max_norm(const SE3d& Tx, const double* x, const double* hg) {
     double ng[6], xp[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ng[k] = -hg[21 + k];
-    pose_plus(Tx, ng, xp);
+    if constexpr (LAT) {
+        double m = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m = fmax(m, fabs(ng[k]));
+        if (m > 1e-6) return m;
+    }
+    pose_plus<LAT>(Tx, ng, xp);
     double m = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) m = fmax(m, fabs(x[k] - xp[k]));
@@ -266,9 +326,11 @@ __device__ __forceinline__ double gradient_max_norm(const SE3d& Tx, const double
 #ifndef PO_WAVES_PER_EU
 #define PO_WAVES_PER_EU 2
 #endif
-template <int NW>
+template <int NW, int FPL>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? PO_WAVES_PER_EU : 1, NW == 1 ? PO_WAVES_PER_EU : 2)))
 void pose_opt_kernel(PoseOptArgs a) {
+    constexpr bool LAT = NW > 1;
+    constexpr bool CACHED = FPL > 0;
     const int frame = blockIdx.x;
     if (frame >= a.n_frames) return;
     const int tid = threadIdx.x;
@@ -285,28 +347,45 @@ void pose_opt_kernel(PoseOptArgs a) {
 
     // residual blocks (src/Optimizer.cpp:45-65)
     int n_blocks = 0;
-    for (int b0 = 0; b0 < f.n; b0 += 64) {
-        const int i = b0 + lane;
-        n_blocks += __popcll(__ballot(i < f.n && f.use[i]));
+    if constexpr (!CACHED) {
+        for (int b0 = 0; b0 < f.n; b0 += 64) {
+            const int i = b0 + lane;
+            n_blocks += __popcll(__ballot(i < f.n && f.use[i]));
+        }
     }
 
     // parameter block (src/Optimizer.cpp:35-37)
     const SE3d T0 = se3_from_rt(Tio);
     double x[6] = {T0.tx, T0.ty, T0.tz, 0.0, 0.0, 0.0};
-    so3_log(T0, x + 3);
-    SE3d Tx = pose_of(x);              // the pose every evaluation of x uses; recomputed from x only when x changes
+    so3_log<LAT>(T0, x + 3);
+    SE3d Tx = pose_of<LAT>(x);
+    FeatRegs fr[CACHED ? FPL : 1];     // CACHED: this lane's features tid, tid + NW*64, .. (the launcher guarantees n <= FPL * NW * 64)
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) fr[j] = load_feature(f, tid + j * NW * 64);
+    } else fr[0].use = false;              // the pose every evaluation of x uses; recomputed from x only when x changes
 
     int termination = DSDTM_PO_MAX_ITERATIONS, iterations = 0, successful = 0;
     double x_cost = 0.0, initial_cost = 0.0;
     __shared__ double s_hg[2][28];     // H (21), g (6), cost of the accepted point [cur] and of the candidate [cur ^ 1]
     __shared__ double s_part[NW * 64 * PO_PART_STRIDE];   // per-lane partials of one evaluation
     __shared__ double s_red[(2 * NW + 1) * 32];           // half-wave sums, then the waves' not-finite flags
+    if constexpr (CACHED) {                                // residual blocks = used features over the NW waves
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) mine += __popcll(__ballot(fr[j].use));
+        if (lane == 0) s_red[tid >> 6] = (double)mine;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) n_blocks += (int)s_red[w];
+        __syncthreads();
+    }
     int cur = 0;
     bool ok;
     if (n_blocks == 0) {
         termination = DSDTM_PO_NO_RESIDUALS;
     } else {
-        evaluate<NW>(f, tid, Tx, x_cost, s_hg[0], s_part, s_red, ok);
+        evaluate<NW, FPL>(f, fr, tid, Tx, x_cost, s_hg[0], s_part, s_red, ok);
         if (!ok) {
             termination = DSDTM_PO_EVALUATION_FAILED;
             x_cost = 0.0;
@@ -316,7 +395,7 @@ void pose_opt_kernel(PoseOptArgs a) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) scale[k] = 1.0 / (1.0 + sqrt(s_hg[0][PO_U(k, k)]));   // Jacobi scaling, fixed
             double x_norm = norm6(x);
-            double gmax = gradient_max_norm(Tx, x, s_hg[0]);
+            double gmax = gradient_max_norm<LAT>(Tx, x, s_hg[0]);
             double radius = 1e4, decrease_factor = 2.0;
             bool reuse_diagonal = false;
             int invalid_steps = 0, it = 0;
@@ -371,10 +450,10 @@ void pose_opt_kernel(PoseOptArgs a) {
                 double delta[6], cand[6], cand_cost;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) delta[k] = step[k] * scale[k];
-                pose_plus(Tx, delta, cand);
+                pose_plus<LAT>(Tx, delta, cand);
                 bool cand_ok = finite6(cand);
-                const SE3d Tc = pose_of(cand);
-                if (cand_ok) evaluate<NW>(f, tid, Tc, cand_cost, s_hg[cur ^ 1], s_part, s_red, cand_ok);
+                const SE3d Tc = pose_of<LAT>(cand);
+                if (cand_ok) evaluate<NW, FPL>(f, fr, tid, Tc, cand_cost, s_hg[cur ^ 1], s_part, s_red, cand_ok);
                 if (!cand_ok) cand_cost = DBL_MAX;
                 double diff[6];
 #pragma unroll
@@ -390,7 +469,7 @@ void pose_opt_kernel(PoseOptArgs a) {
                     x_cost = cand_cost;
                     x_norm = norm6(x);
                     Tx = Tc;
-                    gmax = gradient_max_norm(Tx, x, s_hg[cur]);
+                    gmax = gradient_max_norm<LAT>(Tx, x, s_hg[cur]);
                     ++successful;
                     const double t = 2.0 * relative_decrease - 1.0;
                     radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
@@ -411,6 +490,29 @@ void pose_opt_kernel(PoseOptArgs a) {
     const SE3d Tf = Tx;
     double R[9];
     quat_to_matrix(Tf, R);
+    if constexpr (CACHED) {
+        // GetReprojectReidual (src/Optimizer.cpp:297-317) from the features in registers, in residual-block order
+        // (= feature order): round j holds features j*NW*64 + tid; a wave's lanes write behind the blocks of the
+        // rounds and waves before them
+        const int wave = tid >> 6;
+        unsigned long long m[FPL];
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            m[j] = __ballot(fr[j].use);
+            if (lane == 0) s_red[j * NW + wave] = (double)__popcll(m[j]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FPL; ++j) {
+            int before = 0;
+            for (int k = 0; k < j * NW + wave; ++k) before += (int)s_red[k];
+            if (fr[j].use) {
+                double r0, r1, px, py, pz;
+                block_residual_regs(fr[j], Tf, r0, r1, px, py, pz);
+                (a.residual_norm + base)[before + __popcll(m[j] & ((1ull << lane) - 1ull))] = sqrt(r0 * r0 + r1 * r1);
+            }
+        }
+    }
     if (tid >= 64) return;                                  // results: the first wave (all waves hold the same state)
     if (lane == 0) {
         Tio[0] = R[0]; Tio[1] = R[1]; Tio[2] = R[2];  Tio[3] = Tf.tx;
@@ -426,16 +528,18 @@ void pose_opt_kernel(PoseOptArgs a) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) sm.x[k] = x[k];
     }
-    // GetReprojectReidual (src/Optimizer.cpp:297-317): raw residual norms, in residual-block order
-    double* rn = a.residual_norm + base;
-    int done = 0;
-    for (int b0 = 0; b0 < f.n; b0 += 64) {
-        const int i = b0 + lane;
-        double r0 = 0.0, r1 = 0.0, px, py, pz;
-        const bool u = block_residual(f, i, Tf, r0, r1, px, py, pz);
-        const unsigned long long m = __ballot(u);
-        if (u) rn[done + __popcll(m & ((1ull << lane) - 1ull))] = sqrt(r0 * r0 + r1 * r1);
-        done += __popcll(m);
+    if constexpr (!CACHED) {
+        // GetReprojectReidual (src/Optimizer.cpp:297-317): raw residual norms, in residual-block order
+        double* rn = a.residual_norm + base;
+        int done = 0;
+        for (int b0 = 0; b0 < f.n; b0 += 64) {
+            const int i = b0 + lane;
+            double r0 = 0.0, r1 = 0.0, px, py, pz;
+            const bool u = block_residual(f, i, Tf, r0, r1, px, py, pz);
+            const unsigned long long m = __ballot(u);
+            if (u) rn[done + __popcll(m & ((1ull << lane) - 1ull))] = sqrt(r0 * r0 + r1 * r1);
+            done += __popcll(m);
+        }
     }
 }
 
@@ -443,10 +547,15 @@ hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream) {
     if (args.n_frames <= 0) return hipSuccess;
     // a few frames (the live tracker refines one): latency counts, four waves share a frame's features;
     // batches: one wave per frame, the solver part is not repeated
-    if (args.n_frames <= 32 && args.max_features > 64)
-        hipLaunchKernelGGL(pose_opt_kernel<4>, dim3((unsigned)args.n_frames), dim3(256), 0, stream, args);
+    static const bool no_cache = getenv("DSDTM_PO_NO_CACHE") != nullptr;       // diagnostic (A/B)
+    if (args.n_frames <= 32 && args.max_features > 64 && args.max_features <= 256 && !no_cache)
+        hipLaunchKernelGGL((pose_opt_kernel<4, 1>), dim3((unsigned)args.n_frames), dim3(256), 0, stream, args);
+    else if (args.n_frames <= 32 && args.max_features > 256 && args.max_features <= 512 && !no_cache)
+        hipLaunchKernelGGL((pose_opt_kernel<4, 2>), dim3((unsigned)args.n_frames), dim3(256), 0, stream, args);
+    else if (args.n_frames <= 32 && args.max_features > 64)
+        hipLaunchKernelGGL((pose_opt_kernel<4, 0>), dim3((unsigned)args.n_frames), dim3(256), 0, stream, args);
     else
-        hipLaunchKernelGGL(pose_opt_kernel<1>, dim3((unsigned)args.n_frames), dim3(64), 0, stream, args);
+        hipLaunchKernelGGL((pose_opt_kernel<1, 0>), dim3((unsigned)args.n_frames), dim3(64), 0, stream, args);
     return hipGetLastError();
 }
 
