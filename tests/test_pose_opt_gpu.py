@@ -35,7 +35,10 @@ def assert_same(gpu, cpu, what=""):
 
 CASES = [dict(seed=1, n=200, max_level=3), dict(seed=2, n=200, max_level=0), dict(seed=3, n=500, max_level=4, outlier_frac=0.2),
          dict(seed=4, n=30, max_level=2), dict(seed=5, n=150, max_level=3, seed_t=0.12, seed_w=0.1), dict(seed=6, n=7, max_level=1, unused_frac=0.0),
-         dict(seed=7, n=2000, max_level=3), dict(seed=8, n=64, max_level=2), dict(seed=9, n=65, max_level=2), dict(seed=10, n=700, max_level=4, noise_px=1.5)]
+         dict(seed=7, n=2000, max_level=3), dict(seed=8, n=64, max_level=2), dict(seed=9, n=65, max_level=2), dict(seed=10, n=700, max_level=4, noise_px=1.5),
+         # the few-frames kernel keeps one / two features per lane in registers up to 256 / 512 features
+         dict(seed=11, n=256, max_level=3, unused_frac=0.3), dict(seed=12, n=257, max_level=3, unused_frac=0.3),
+         dict(seed=13, n=512, max_level=2, outlier_frac=0.1), dict(seed=14, n=513, max_level=2, outlier_frac=0.1)]
 
 
 @pytest.mark.parametrize("kw", CASES)

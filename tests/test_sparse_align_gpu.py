@@ -754,6 +754,36 @@ def test_workspace_launches_in_flight_on_two_streams(gpu_ctx, oracle):
                 assert ntg[i] == no
 
 
+@pytest.mark.parametrize("N,scale", [(1000, 1.0), (1100, 2.5), (2040, 1.0), (2100, 1.0)])
+def test_workspace_kernel_window_shapes(gpu_ctx, oracle, N, scale):
+    """The workspace kernel keeps the current-image windows of up to 1024 / 2048 patches in dynamic LDS (64 / 128 KB)
+    and gathers from the pyramid beyond that: every shape against the oracle, one of them with multi-pixel motion
+    (windows are refilled when a patch leaves them)."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, P = 320, 240, 3, 66
+    kw = dict(width=W, height=Hh, levels=L, n_patches=N, margin=12)
+    if scale != 1.0:
+        kw["xi"] = tuple(scale * v for v in (0.01, -0.006, 0.004, 0.004, -0.003, 0.005))
+    base = [cached_scene(seed=1700 + i, **kw) for i in range(3)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in base]
+    scs = [base[i % 3] for i in range(P)]
+    t, b = _device_batch(torch, dev, scs, L, W, Hh)
+    cam = capi.camera_struct(base[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, st.cuda_stream))
+    Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+    for i in range(P):
+        To, no, _ = want[i % 3]
+        H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"N {N} pair {i}")
+        assert ntg[i] == no
+
+
 def test_more_streams_than_a_context_tracks(gpu_ctx, oracle):
     """A context keeps pair counters (and workspaces) per stream for 16 streams; applications that keep creating
     streams get the least recently used entry handed over (one device synchronisation) — launches on 40 different
