@@ -1471,6 +1471,15 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
 #ifndef SA_WS_WINDOWS
 #define SA_WS_WINDOWS 1
 #endif
+#ifndef SA_WS_FROM
+#define SA_WS_FROM 704      // feature counts above this run the workspace kernel in batches
+#endif
+#ifndef SA_WS_SHARED
+#define SA_WS_SHARED 1      // 8 patch waves, the last one also solves (0: SA_WS_NPW patch waves + a solver wave)
+#endif
+constexpr bool WS_SH = SA_WS_SHARED != 0;
+constexpr int WS_NPW = WS_SH ? 8 : SA_WS_NPW;
+constexpr int WS_THREADS = (WS_SH ? WS_NPW : WS_NPW + 1) * 64;
 constexpr int WS_DWORDS = 22;   // rlo[7], rhi[7], px, py, X[3] as dword pairs
 __host__ __device__ inline size_t ws_doubles_per_pair(int max_features) {
     const size_t npad = ((size_t)max_features + 63) / 64 * 64;
@@ -1518,9 +1527,16 @@ __device__ __forceinline__ void ws_patch_regs(const WsPatch& w, const LevelGeom&
 // dynamic LDS — 64 KB for up to 1024 patches, 128 KB for up to 2048. Without them every pass gathers its five
 // footprint rows per patch through the CU's texture-address path again (the round-2 kernel: 1024 pairs of 1000
 // patches 1.03 ms per launch).
-template <int NPW, int WCAP>
-__global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const SAKernelArgs a) {
+// SH (shared solver): no solver wave — the workgroup is NPW patch waves and the last of them runs the solve between
+// the two barriers of an iteration. This kernel's patch state does not live in registers across passes (the grid is
+// rebuilt from the parked inputs every pass), so one wave can be both; at ~205 VGPRs a CU holds 8 waves, and 8 patch
+// waves instead of 7 + 1 turn the 1000 patches of BASELINE config 3 from three rounds of 448 lanes (the third 23 %
+// full) into two rounds of 512, and 2000 patches from five rounds into four.
+template <int NPW, int WCAP, bool SH>
+__global__ __launch_bounds__((SH ? NPW : NPW + 1) * 64) __attribute__((amdgpu_waves_per_eu(SH && NPW <= 4 ? 2 : 1, 2)))
+void sparse_align_ws_kernel(const SAKernelArgs a) {
     constexpr int PT = NPW * 64;   // patch threads
+    constexpr int SW = NPW - 1;    // SH: the wave that also solves
     __shared__ WavePartial s_part[NPW];
     __shared__ BlockState s;
     extern __shared__ __attribute__((aligned(16))) uint32_t ws_win[];   // [16][WCAP]: 15 window planes + origins
@@ -1536,7 +1552,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
         return;
     }
 
-    if (wave == NPW) {
+    if (!SH && wave == NPW) {
         solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
         if (lane == 0) stats_clear(a, pair);
         __syncthreads();                                               // B0
@@ -1562,6 +1578,11 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
         report_timeout(a, lane);
         return;
     }
+    const bool solves = SH && wave == SW;
+    if (solves) {
+        solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
+        if (lane == 0) stats_clear(a, pair);
+    }
 
     const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
     const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
@@ -1574,6 +1595,13 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
         const double scale = (double)(1.0f / (float)(1 << level));
         const double fs = (double)a.f * scale;
         int n_valid_lane = 0;
+        if (solves && lane == 0) {                                     // GaussNewtonSolver entry (:304-308)
+            s.chi2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.qo[i] = s.u.q[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s.to[i] = s.u.t[i];
+        }
         {
             const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
             for (int p = tid; p < (int)npad; p += PT) {
@@ -1673,9 +1701,28 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_ws_kernel(const S
                 s_part[wave].h_changed = h_new ? 1 : 0;
             }
             __syncthreads();                                           // B1
-            __syncthreads();                                           // B2
+            if constexpr (SH) {
+                SolverCarry carry;
+                if (solves) {
+                    // row of H^+ from LDS at every step (refresh_hinv_to_lds parks it there): nothing of the solver
+                    // is live in registers across the pass
+                    double hrow[6];
+                    const int li = lane < 6 ? lane : 5;
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];
+                    (void)solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry);
+                }
+                __syncthreads();                                       // B2
+                if (solves) solver_commit(a, pair, s, lane, carry);
+            } else {
+                __syncthreads();                                       // B2
+            }
             if (s.ctrl) break;
         }
+    }
+    if (solves) {
+        solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
+        report_timeout(a, lane);
     }
 }
 
@@ -1940,6 +1987,8 @@ hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t
 //   <= 128 features: 2+1 waves x 4 slots     <= 192: 3+1 x 3     <= 256: 4+1 x 2
 //   <= 320 features: 5+1 x 2 (BASELINE shape) <= 448: 7+1 x 1     <= 704: 11+1 x 1
 SAVariant sparse_align_pick_variant(int max_features) {
+    static const int ws_from = getenv("DSDTM_WS_FROM") ? atoi(getenv("DSDTM_WS_FROM")) : SA_WS_FROM;   // diagnostic (A/B)
+    if (max_features > ws_from) return SA_WS;
     if (max_features <= 128) return SA_REG128;
     if (max_features <= 192) return SA_REG192;
     if (max_features <= 256) return SA_REG256;
@@ -1969,7 +2018,7 @@ int sparse_align_occupancy(int variant) {
     int nb = -1;
     if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, false>, SA_PPW * 6 * 64, 0);
     else if (variant == SA_REG448) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<7, SA_GRID_T, 1, false>, 8 * 64, 0);
-    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<SA_WS_NPW, 0>, (SA_WS_NPW + 1) * 64, 0);
+    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<WS_NPW, 0, WS_SH>, WS_THREADS, 0);
     return nb;
 }
 
@@ -2004,17 +2053,23 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
         case SA_WS: {
             const int npad = (args.max_features + 63) / 64 * 64;
             static const bool ws_windows = SA_WS_WINDOWS && getenv("DSDTM_WS_NO_WINDOWS") == nullptr;
-            if (ws_windows && npad <= 1024) {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<SA_WS_NPW, 1024>), dim3((unsigned)args.n_pairs), dim3((SA_WS_NPW + 1) * 64),
-                                   16 * 1024 * sizeof(uint32_t), stream, args);
-            } else if (ws_windows && npad <= 2048) {
-                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<SA_WS_NPW, 2048>,
+            // Two workgroups of four waves per CU (two pairs in flight: one's gathers overlap the other's arithmetic,
+            // as the two slots of the register kernel do) when their windows fit side by side, else one of eight.
+            static const int ws_waves = getenv("DSDTM_WS_WAVES") ? atoi(getenv("DSDTM_WS_WAVES")) : 0;
+            const dim3 grid((unsigned)args.n_pairs);
+            if (WS_SH && ws_windows && npad <= 1024 && ws_waves != 8) {
+                hipLaunchKernelGGL((sparse_align_ws_kernel<4, 1024, true>), grid, dim3(256), 16 * 1024 * sizeof(uint32_t), stream, args);
+            } else if (ws_windows && npad <= 1024) {
+                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024, WS_SH>), grid, dim3(WS_THREADS), 16 * 1024 * sizeof(uint32_t), stream, args);
+            } else if (ws_windows && npad <= 2048 && ws_waves != 4) {
+                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 2048, WS_SH>,
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * sizeof(uint32_t));
                 if (attr != hipSuccess) return attr;
-                hipLaunchKernelGGL((sparse_align_ws_kernel<SA_WS_NPW, 2048>), dim3((unsigned)args.n_pairs), dim3((SA_WS_NPW + 1) * 64),
-                                   16 * 2048 * sizeof(uint32_t), stream, args);
+                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 2048, WS_SH>), grid, dim3(WS_THREADS), 16 * 2048 * sizeof(uint32_t), stream, args);
+            } else if (WS_SH && ws_waves == 4) {
+                hipLaunchKernelGGL((sparse_align_ws_kernel<4, 0, true>), grid, dim3(256), 0, stream, args);
             } else {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<SA_WS_NPW, 0>), dim3((unsigned)args.n_pairs), dim3((SA_WS_NPW + 1) * 64), 0, stream, args);
+                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 0, WS_SH>), grid, dim3(WS_THREADS), 0, stream, args);
             }
             break;
         }
