@@ -10,7 +10,7 @@ python bench.py --streams 1 --no-secondary > $O/r02_bench_one_stream.json.log 2>
 tools/streams_sweep.sh $(basename $O)/sweep > $O/r02_streams_sweep.txt 2>&1
 python tools/stamps.py > $O/r02_stamps.txt 2>/dev/null
 python tools/latency_by_count.py > $O/r02_latency_by_count.txt 2>/dev/null
-( python tools/kernels.py; python tools/latency.py; ) > $O/r02_secondary_kernels.txt 2>/dev/null
+( python tools/kernels.py; python tools/latency.py; python tools/cpp_detect.py ) 2>/dev/null | grep -v amdgpu > $O/r02_secondary_kernels.txt
 python tools/track_step.py > $O/r02_track_step.txt 2>/dev/null
 ( PYR_SMALL=1 PYR_ALL=1 python tools/pyr_ab.py ) 2>/dev/null | grep -v amdgpu > $O/r02_pyramid_ab.txt
 ( python tools/pose_opt_bench.py 1 200 nolatency; python tools/pose_opt_bench.py 64 200; python tools/pose_opt_bench.py 4096 200 nolatency ) 2>/dev/null | grep -v amdgpu > $O/r02_pose_opt.txt
