@@ -186,21 +186,25 @@ def test_golden_fixtures(gpu_ctx, name):
     assert sg["n_ref"] == list(g.d["out_nref"]) and sg["n_vis"] == list(g.d["out_nvis"])
 
 
-def test_batch_device_api_with_ragged_feature_counts(gpu_ctx, oracle):
+@pytest.mark.parametrize("NMAX,base_counts,reps", [(300, [300, 257, 64, 15, 14, 0, 129], 1),
+                                                   (1000, [1000, 705, 257, 64, 15, 14, 0, 999, 449], 8)])
+def test_batch_device_api_with_ragged_feature_counts(gpu_ctx, oracle, NMAX, base_counts, reps):
     """dsdtm_sparse_align_batch_device: several pairs in one launch, per-pair feature counts
-    (including one below Camera.Min_fts and one empty), stats array, in/out pose buffer."""
+    (including one below Camera.Min_fts and one empty), stats array, in/out pose buffer. Register kernel
+    (300 features at most) and, with 72 pairs of up to 1000, the workspace kernel with its per-patch windows."""
     import ctypes as C
     import torch
     from dsdtm_amd import capi
     dev = torch.device("cuda", 0)
-    W, Hh, L, NMAX = 320, 240, 3, 300
-    counts = [300, 257, 64, 15, 14, 0, 129]          # odd pair count: the last workgroup has one empty pair slot
-    scenes = []
-    for i, n in enumerate(counts):
+    W, Hh, L = 320, 240, 3
+    counts = base_counts * reps                      # (first case) odd pair count: the last workgroup has one empty pair slot
+    base_scenes = []
+    for i, n in enumerate(base_counts):
         rng = np.random.default_rng(500 + i)
-        scenes.append(cached_scene(width=W, height=Hh, levels=L, n_patches=max(n, 1), seed=600 + i, margin=12,
-                                   xi=tuple(synth.random_xi(rng)), depth=float(rng.uniform(1, 4)),
-                                   T_ref_w=tuple(map(tuple, synth.random_pose(rng)))))
+        base_scenes.append(cached_scene(width=W, height=Hh, levels=L, n_patches=max(n, 1), seed=600 + i, margin=12,
+                                        xi=tuple(synth.random_xi(rng)), depth=float(rng.uniform(1, 4)),
+                                        T_ref_w=tuple(map(tuple, synth.random_pose(rng)))))
+    scenes = base_scenes * reps
     ws, hs, st, offs, nbytes = capi.pyramid_layout(W, Hh, L)
     pitch = (nbytes + 255) // 256 * 256
     P = len(counts)
@@ -236,10 +240,13 @@ def test_batch_device_api_with_ragged_feature_counts(gpu_ctx, oracle):
     Tg = t["Tc"].cpu().numpy(); ntg = t["nt"].cpu().numpy()
     stg = np.frombuffer(t["st"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
     import copy
-    for i, (sc, n) in enumerate(zip(scenes, counts)):
+    want = []
+    for sc, n in zip(base_scenes, base_counts):
         s2 = copy.copy(sc)
         s2.px, s2.bearing, s2.p_world, s2.initial = sc.px[:n], sc.bearing[:n], sc.p_world[:n], sc.initial[:n]
-        To, no, so = oracle.sparse_align(s2, L, 0, 10)
+        want.append(oracle.sparse_align(s2, L, 0, 10))
+    for i, (sc, n) in enumerate(zip(scenes, counts)):
+        To, no, so = want[i % len(base_counts)]
         assert ntg[i] == no, (i, ntg[i], no)
         if n < 15:
             assert no == 0 and np.array_equal(Tg[i], sc.T_cur_w_seed.reshape(12))      # pose untouched
