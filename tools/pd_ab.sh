@@ -1,9 +1,7 @@
 #!/bin/bash
-# pyrDown variants, same box (DSDTM_PYRDOWN_OVERLAP=1: the general overlapping-load kernel, which carries the switches)
-for v in "$@"; do
-  cp variants/lib_$v.so dsdtm_amd/csrc/libdsdtm_amd.so
-  python -m pytest tests/test_align2d_gpu.py -m gpu -x -q -k pyrdown 2>&1 | tail -1
-  for rep in 1 2; do
-    DSDTM_PYRDOWN_OVERLAP=1 python tools/kernels.py 2>/dev/null | grep pyrDown | sed "s/^/$v overlap: /" | cut -c1-140
-  done
+# same-box A/B of library variants on the per-level pyramid kernel (2048 640x480 pyramids): tools/pd_ab.sh variants/lib_a.so ...
+cd "$(dirname "$0")/.."
+for so in "$@"; do
+  cp "$so" dsdtm_amd/csrc/libdsdtm_amd.so; touch dsdtm_amd/csrc/libdsdtm_amd.so
+  for i in 1 2; do echo -n "$so: "; DSDTM_PYR_FUSED=0 python tools/kernels.py 2>/dev/null | grep pyrDown | cut -c1-110; done
 done
