@@ -72,6 +72,7 @@ if __name__ == "__main__":
     ap.add_argument("--grid", default=os.environ.get("DSDTM_GRID_T", "double"), choices=["double", "float"])
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--define", action="append", default=[], help="extra -D for experiments, e.g. SA_WAVES_PER_EU=5")
+    ap.add_argument("--flag", action="append", default=[], help="extra raw compiler flag for experiments, e.g. --flag=-mllvm --flag=-amdgpu-sched-strategy=max-ilp")
     a = ap.parse_args()
-    build(a.grid, a.force, extra=["-D" + d for d in a.define])
+    build(a.grid, a.force, extra=["-D" + d for d in a.define] + list(a.flag))
     print(OUT)

@@ -364,7 +364,9 @@ int dsdtm_align2d_batch_device(dsdtm_ctx* ctx, const dsdtm_image_desc* cur,
  * for n_images packed pyramids on the device: level 0 must already be present at
  * pyr + i*pyr_pitch + level_offset[0]; levels 1..levels-1 are written. Bit-exact
  * OpenCV 8-bit semantics: separable [1 4 6 4 1], BORDER_REFLECT_101, (sum+128)>>8,
- * output size ((w+1)/2, (h+1)/2).
+ * output size ((w+1)/2, (h+1)/2). Up to 32 images whose levels have widths that are multiples
+ * of 8 (3..5 levels) are built by ONE launch (intermediate levels in LDS, a new frame of the
+ * live tracker); larger batches and other shapes by one launch per level. Same bytes either way.
  */
 int dsdtm_pyrdown_batch_device(dsdtm_ctx* ctx, uint8_t* pyr, size_t pyr_pitch, int n_images,
                                int levels, const int* width, const int* height,
