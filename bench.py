@@ -63,6 +63,23 @@ def pmc_traffic(kernel_substr, algorithmic_bytes_per_launch, path=PMC_SUMMARY):
     return None
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X FP64 vector: half the 157.3 TFLOP/s FP32 vector rate of MI355X_MICROARCH.md
+
+
+def pmc_fp64_flops(kernel_substr, case="solo", path=PMC_SUMMARY):
+    """FP64 flops per launch of the BASELINE workload (1024 pairs) from the committed SQ_INSTS_VALU_*_F64 pass
+    (64 x (ADD + MUL + 2 FMA + TRANS) wave instructions; tools/profile.sh, tools/summarize_profile.py). None if absent."""
+    try:
+        with open(os.path.join(ROOT, path)) as f:
+            d = json.load(f)
+        for t in d.get("fp64_per_launch", []):
+            if t["case"] == case and kernel_substr in t["kernel"]:
+                return float(t["fp64_flops_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def se3_exp_batch(xi):
     """numpy batch of SE(3) exponentials -> (n,4,4)."""
     from dsdtm_amd import synth
@@ -380,6 +397,23 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
     return out
 
 
+def fp64_block(args, kernel_ms):
+    """The path's second roofline (SURVEY.md §8d asks for both): executed FP64 vector flops of the alignment kernel
+    against the FP64 vector peak. Flops per launch come from the committed counter pass of the BASELINE workload and
+    are null for any other shape."""
+    flops = pmc_fp64_flops("sparse_align_reg_kernel") if (args.pairs, args.patches, args.width, args.height, args.levels, args.iters) == (1024, 300, 640, 480, 4, 10) else None
+    out = {"bound": "fp64_vector", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "flops_per_launch": flops,
+           "note": "executed FP64 vector flops per launch = 64 x (ADD + MUL + 2 FMA + TRANS) wave instructions, rocprofv3 "
+                   "SQ_INSTS_VALU_*_F64 (" + PMC_SUMMARY + "); divided by this run's kernel time"}
+    if flops is not None:
+        out["flops_per_alignment"] = flops / args.pairs
+        out["achieved"] = flops / (kernel_ms * 1e-3) / 1e12
+        out["frac"] = out["achieved"] / FP64_VECTOR_PEAK_TFLOPS
+    else:
+        out["achieved"] = out["frac"] = None
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N worker processes (one per GPU) BEFORE anything in
     this process touches the GPU, with the environment torch.distributed.run would give them. Rank 0's JSON line
@@ -587,6 +621,7 @@ def main():
                        **({"barrier_backend": dist.get_backend()} if world > 1 else {})},
             "roofline": roofline_block("sparse_align_reg_kernel", args.pairs * b_alg, k_avg, k_min, args.pairs, b_alg, "alignment",
                                        {"kernel_time_basis": k_basis}),
+            "fp64": fp64_block(args, k_avg),
             "executed_iterations_per_level_mean": [float(x) for x in iters.mean(axis=0)],
             "executed_iterations_total_mean": float(iters.sum(axis=1).mean()),
             "n_tracked_mean": float(ntg.mean()),

@@ -33,3 +33,16 @@ def test_traffic_lookup_reads_the_committed_pmc_summary():
 def test_usable_cpus_is_positive_and_bounded_by_the_machine():
     n = bench.usable_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_fp64_block_reads_the_committed_counter_pass():
+    """The second roofline of the bench line (FP64 vector fraction) comes from the committed
+    SQ_INSTS_VALU_*_F64 pass and only for the BASELINE workload."""
+    import types
+    import bench
+    a = types.SimpleNamespace(pairs=1024, patches=300, width=640, height=480, levels=4, iters=10)
+    b = bench.fp64_block(a, 0.2)
+    assert b["flops_per_launch"] is not None and 1e9 < b["flops_per_launch"] < 1e10
+    assert abs(b["achieved"] - b["flops_per_launch"] / 0.2e-3 / 1e12) < 1e-9 and 0 < b["frac"] < 1
+    a.patches = 1000
+    assert bench.fp64_block(a, 0.2)["achieved"] is None

@@ -25,6 +25,8 @@ for c in solo n1000 n2000 kernels; do
   echo "counted $c"
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/solo/pmc_sq" -- python3 ${CASE[solo]} > "$OUT/solo/pmc_sq.log" 2>&1 || echo "pmc sq failed"
+# FP64 instruction mix of the alignment kernel (bench.py's fp64 block: flops per launch = 64 x (ADD + MUL + 2 FMA + TRANS))
+timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 --output-format csv -d "$OUT/solo/pmc_fp64" -- python3 ${CASE[solo]} > "$OUT/solo/pmc_fp64.log" 2>&1 || echo "pmc fp64 failed"
 # keep the merge-back small: the per-dispatch CSVs of the long runs are summarised on the box
 cd "$REPO"
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1

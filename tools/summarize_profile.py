@@ -17,7 +17,8 @@ ALG = {   # case -> (kernel substring, algorithmic bytes per launch, dispatches 
     "n2000": ("sparse_align", 256 * 3378292, 1),
     "kernels": ("pyrdown_kernel", 2048 * 504000, 3),
 }
-stats_rows, pmc = [], {"round": 2, "command": "tools/profile.sh (see the file for every command line)", "cases": {}, "hbm_traffic_per_launch": []}
+stats_rows, pmc = [], {"round": 2, "command": "tools/profile.sh (see the file for every command line)", "cases": {}, "hbm_traffic_per_launch": [],
+                       "fp64_per_launch": []}
 for case in sorted(os.listdir(src)):
     d = os.path.join(src, case)
     if not os.path.isdir(d):
@@ -41,6 +42,13 @@ for case in sorted(os.listdir(src)):
     if ctr:
         pmc["cases"][case] = {k: dict(launch=launch[k], counters={c: dict(dispatches=len(v), mean_per_dispatch=sum(v) / len(v))
                                                                       for c, v in sorted(cs.items())}) for k, cs in ctr.items()}
+    for k, cs in ctr.items():
+        if all(c in cs for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")):
+            m = {c: sum(cs[c]) / len(cs[c]) for c in cs if c.startswith("SQ_INSTS_VALU_")}
+            # wave-level instruction counts; a wave instruction is 64 lane operations, an FMA two flops (inactive lanes
+            # — 300 patches on 320 lanes, the solver wave's uniform arithmetic — are counted: an upper bound of ~7 %)
+            flops = 64.0 * (m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + 2.0 * m["SQ_INSTS_VALU_FMA_F64"] + m["SQ_INSTS_VALU_TRANS_F64"])
+            pmc["fp64_per_launch"].append(dict(case=case, kernel=k, wave_instructions=m, fp64_flops_per_launch=flops))
     if case in ALG:
         sub, alg, nd = ALG[case]
         for k, cs in ctr.items():
