@@ -42,7 +42,7 @@ struct PyrDownArgs {
 // are full whatever the level width (640 px = 80 strips used to leave the second block column at 16
 // of 64 lanes).
 #ifndef SA_PD_ROWS
-#define SA_PD_ROWS 8
+#define SA_PD_ROWS 4
 #endif
 #ifndef SA_PD_NT
 #define SA_PD_NT 0          // diagnostic: 1 non-temporal loads, 2 non-temporal stores
