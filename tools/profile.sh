@@ -31,4 +31,6 @@ timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_
 cd "$REPO"
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
 find "$OUT" -name "*_agent_info.csv" -delete
+# the raw per-dispatch CSVs (tens of MB) stay on the box: the summaries above are what is kept (gpurun merges <= 64 MiB back)
+for c in main solo n1000 n2000 kernels; do rm -rf "$OUT/$c/trace" "$OUT/$c"/pmc_*/ ; done
 echo profdone

@@ -48,7 +48,8 @@ for case in sorted(os.listdir(src)):
             # wave-level instruction counts; a wave instruction is 64 lane operations, an FMA two flops (inactive lanes
             # — 300 patches on 320 lanes, the solver wave's uniform arithmetic — are counted: an upper bound of ~7 %)
             flops = 64.0 * (m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + 2.0 * m["SQ_INSTS_VALU_FMA_F64"] + m["SQ_INSTS_VALU_TRANS_F64"])
-            pmc["fp64_per_launch"].append(dict(case=case, kernel=k, wave_instructions=m, fp64_flops_per_launch=flops))
+            if flops > 0:
+                pmc["fp64_per_launch"].append(dict(case=case, kernel=k, wave_instructions=m, fp64_flops_per_launch=flops))
     if case in ALG:
         sub, alg, nd = ALG[case]
         for k, cs in ctr.items():
