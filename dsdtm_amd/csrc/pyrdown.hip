@@ -3,9 +3,10 @@
 // Replaces reference src/Frame.cpp:74-81 (cv::pyrDown per level; OpenCV 2.4 8-bit semantics:
 // separable [1 4 6 4 1], BORDER_REFLECT_101, (sum+128)>>8, output ((w+1)/2,(h+1)/2)).
 // Integer arithmetic, bit-exact. HBM-bound: each thread owns a strip of 4 output columns (one dword
-// store per output row) and walks down 8 output rows with a sliding window of horizontally
+// store per output row) and walks down PD_ROWS output rows with a sliding window of horizontally
 // filtered input rows (v_dot4_u32_u8), each read once as one 16-byte load, vertical pass on packed
-// u16; odd sizes take a byte-wise reflected path.
+// u16; odd sizes take a byte-wise reflected path. Two kernels share that strip task: one launch per
+// level (batches), and one launch per pyramid with the intermediate levels in LDS (a few images).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -38,7 +39,7 @@ struct PyrDownArgs {
 // ONE v_dot4_u32_u8 of the 4-byte window at its column with the constant (1,4,6,4), the fifth tap as
 // the accumulator operand (window assembled with v_alignbyte); the filtered rows are kept as packed
 // u16 pairs (<= 4080 each) and the vertical pass runs on v_pk_* (<= 65280 + 128 fits 16 bits);
-// ~50 instructions per output row. Threads are numbered linearly over (strip, row chunk), so waves
+// ~45 instructions per output row. Threads are numbered linearly over (strip, row chunk), so waves
 // are full whatever the level width (640 px = 80 strips used to leave the second block column at 16
 // of 64 lanes).
 #ifndef SA_PD_ROWS

@@ -1464,7 +1464,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
 // grid_from_rows the register kernels run once per level (same inputs, same arithmetic: bit-identical values).
 // The first version parked the grid itself and was bound by exactly that traffic: 1024 pairs of 1000 patches moved
 // 8.7 GB per launch through HBM (rocprofv3 FETCH_SIZE/WRITE_SIZE, 9.7x the algorithmic bytes) at 6.2 TB/s.
-// patch waves of the workspace kernel (7 + 1 solver = 2 waves per SIMD at up to 256 VGPRs; 11 + 1 = 3 per SIMD at 168)
+// patch waves of the workspace kernel's variant WITH a solver wave (SA_WS_SHARED=0; 7 + 1 = 2 waves per SIMD at up to 256
+// VGPRs; 11 + 1 = 3 per SIMD at 168 spilled heavily). The product shape has no solver wave: WS_SH below.
 #ifndef SA_WS_NPW
 #define SA_WS_NPW 7
 #endif
