@@ -33,23 +33,14 @@ def is_in_image(cam, x: float, y: float, boundary: int, level: int = 0) -> bool:
             cvRound(y) >= boundary and cvRound(y) < cam.height // (1 << level) - boundary)
 
 
-def fill_circle(mask: np.ndarray, cx: int, cy: int, radius: int, value: int = 0):
-    """cv::circle(img, center, radius, value, -1) for 8-bit masks: OpenCV 2.4 drawing.cpp Circle()
-    (midpoint algorithm, filled by horizontal spans, clipped to the image)."""
-    h, w = mask.shape
+def _circle_spans(radius: int):
+    """The horizontal spans (dy, half-width) cv::circle(.., -1) paints for `radius`: OpenCV 2.4 drawing.cpp Circle()
+    (midpoint algorithm, filled by horizontal spans). A row can be painted by several spans: the widest one counts."""
+    half = {}
     err, dx, dy, plus, minus = 0, radius, 0, 1, (radius << 1) - 1
-
-    def hline(y, x1, x2):
-        if 0 <= y < h:
-            x1, x2 = max(x1, 0), min(x2, w - 1)
-            if x1 <= x2:
-                mask[y, x1:x2 + 1] = value
-
     while dx >= dy:
-        hline(cy - dy, cx - dx, cx + dx)
-        hline(cy + dy, cx - dx, cx + dx)
-        hline(cy - dx, cx - dy, cx + dy)
-        hline(cy + dx, cx - dy, cx + dy)
+        for row, hw in ((-dy, dx), (dy, dx), (-dx, dy), (dx, dy)):
+            half[row] = max(half.get(row, -1), hw)
         dy += 1
         err += plus
         plus += 2
@@ -57,6 +48,35 @@ def fill_circle(mask: np.ndarray, cx: int, cy: int, radius: int, value: int = 0)
         err -= minus & m
         dx += m
         minus -= m & 2
+    return half
+
+
+_STENCILS = {}
+
+
+def _circle_stencil(radius: int) -> np.ndarray:
+    """The disc of _circle_spans as a (2r+1) x (2r+1) boolean stencil, built once per radius."""
+    st = _STENCILS.get(radius)
+    if st is None:
+        st = np.zeros((2 * radius + 1, 2 * radius + 1), bool)
+        for row, hw in _circle_spans(radius).items():
+            st[radius + row, radius - hw:radius + hw + 1] = True
+        _STENCILS[radius] = st
+    return st
+
+
+def fill_circle(mask: np.ndarray, cx: int, cy: int, radius: int, value: int = 0):
+    """cv::circle(img, center, radius, value, -1) for 8-bit masks: OpenCV 2.4 drawing.cpp Circle()
+    (midpoint algorithm, filled by horizontal spans, clipped to the image) — the spans are tabulated once per
+    radius (_circle_stencil) and painted with one clipped slice assignment."""
+    h, w = mask.shape
+    st = _circle_stencil(radius)
+    y0, y1 = max(cy - radius, 0), min(cy + radius, h - 1)
+    x0, x1 = max(cx - radius, 0), min(cx + radius, w - 1)
+    if y0 > y1 or x0 > x1:
+        return
+    sub = st[y0 - (cy - radius):y1 - (cy - radius) + 1, x0 - (cx - radius):x1 - (cx - radius) + 1]
+    mask[y0:y1 + 1, x0:x1 + 1][sub] = value
 
 
 @dataclasses.dataclass
