@@ -229,8 +229,37 @@ def load():
     lib.dsdtm_match_candidates_frames.restype = C.c_int
     lib.dsdtm_match_candidates_frames.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(Camera), dp, dp,
                                                   ip32, fp, ip32, dp, dp, C.c_int, C.c_int, C.c_int, dp, ip32, u8p]
+    lib.dsdtm_debug_set_option.restype = C.c_int
+    lib.dsdtm_debug_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.dsdtm_debug_get_option.restype = C.c_int
+    lib.dsdtm_debug_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     _LIB = lib
     return lib
+
+
+class debug_options:
+    """`with capi.debug_options(no_team=1): ...` — diagnostic switches of the library (kernels.h: Options) for the
+    duration of a block. The library reads the environment once, when the first context is created; tests and A/B
+    tools change a switch afterwards through this."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.kv.items():
+            cur = C.c_int()
+            if lib.dsdtm_debug_get_option(k.encode(), C.byref(cur)) != OK:
+                raise KeyError(k)
+            self.old[k] = cur.value
+            lib.dsdtm_debug_set_option(k.encode(), int(v))
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k, v in self.old.items():
+            lib.dsdtm_debug_set_option(k.encode(), v)
+        return False
 
 
 def device_frame_of(ctx, frame):

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
 hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream) {
     if (args.m <= 0) return hipSuccess;
     // DSDTM_A2D_TREE=1 (diagnostic, cost comparison only): DPP tree sums instead of the reference's order
-    if (getenv("DSDTM_A2D_TREE")) hipLaunchKernelGGL(align2d_kernel<true>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
+    if (options().a2d_tree) hipLaunchKernelGGL(align2d_kernel<true>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
     else hipLaunchKernelGGL(align2d_kernel<false>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
     return hipGetLastError();
 }

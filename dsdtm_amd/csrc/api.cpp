@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -75,9 +76,38 @@ static void set_err(dsdtm_ctx* ctx, const char* fmt, ...) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- diagnostic switches (kernels.h: Options) --------------------------------------------------
+namespace {
+struct OptionKey { const char* key; const char* env; int dsdtm::Options::*field; bool flag; };
+const OptionKey kOptionKeys[] = {
+    {"no_team", "DSDTM_NO_TEAM", &dsdtm::Options::no_team, true},
+    {"team_min", "DSDTM_TEAM_MIN", &dsdtm::Options::team_min, false},
+    {"team_spread_min", "DSDTM_TEAM_SPREAD_MIN", &dsdtm::Options::team_spread_min, false},
+    {"ws_from", "DSDTM_WS_FROM", &dsdtm::Options::ws_from, false},
+    {"ws_waves", "DSDTM_WS_WAVES", &dsdtm::Options::ws_waves, false},
+    {"ws_no_windows", "DSDTM_WS_NO_WINDOWS", &dsdtm::Options::ws_no_windows, true},
+    {"pyr_fused", "DSDTM_PYR_FUSED", &dsdtm::Options::pyr_fused, false},
+    {"pyr_band", "DSDTM_PYR_BAND", &dsdtm::Options::pyr_band, false},
+    {"no_zero_copy", "DSDTM_NO_ZERO_COPY", &dsdtm::Options::no_zero_copy, true},
+    {"po_no_cache", "DSDTM_PO_NO_CACHE", &dsdtm::Options::po_no_cache, true},
+    {"a2d_tree", "DSDTM_A2D_TREE", &dsdtm::Options::a2d_tree, true},
+    {"reg_slots", "DSDTM_REG_SLOTS", &dsdtm::Options::reg_slots, false},
+};
+std::once_flag g_options_once;
+void options_from_env() {
+    dsdtm::Options& o = dsdtm::options();
+    for (const OptionKey& k : kOptionKeys)
+        if (const char* v = getenv(k.env)) o.*(k.field) = k.flag ? 1 : atoi(v);    // a flag is set by its presence
+}
+}  // namespace
+dsdtm::Options& dsdtm::options() {
+    static Options o;
+    return o;
+}
+
 extern "C" {
 
-const char* dsdtm_version(void) { return "dsdtm_amd 0.2 (gfx950, HIP; grid=" DSDTM_STR(SA_GRID_T) ", pairs/workgroup=" DSDTM_STR(SA_PPW) ")"; }
+const char* dsdtm_version(void) { return "dsdtm_amd 0.3 (gfx950, HIP; FP64 reference grid)"; }
 
 int dsdtm_device_count(void) {
     int n = 0;
@@ -91,6 +121,7 @@ const char* dsdtm_last_error(const dsdtm_ctx* ctx) { return ctx ? ctx->err : g_c
 int dsdtm_create(int device, dsdtm_ctx** out) {
     if (!out) return DSDTM_ERR_INVALID;
     *out = nullptr;
+    std::call_once(g_options_once, options_from_env);     // the only place the library reads the environment
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -134,6 +165,21 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
     }
     *out = ctx;
     return DSDTM_OK;
+}
+
+// Diagnostic switches by name (tests, A/B tools): the keys of kOptionKeys, process-wide. Returns DSDTM_ERR_INVALID
+// for an unknown key. Not for production use: no entry point synchronises against a concurrent change.
+int dsdtm_debug_set_option(const char* key, int value) {
+    std::call_once(g_options_once, options_from_env);
+    for (const OptionKey& k : kOptionKeys)
+        if (key && strcmp(key, k.key) == 0) { dsdtm::options().*(k.field) = value; return DSDTM_OK; }
+    return DSDTM_ERR_INVALID;
+}
+int dsdtm_debug_get_option(const char* key, int* value) {
+    std::call_once(g_options_once, options_from_env);
+    for (const OptionKey& k : kOptionKeys)
+        if (key && value && strcmp(key, k.key) == 0) { *value = dsdtm::options().*(k.field); return DSDTM_OK; }
+    return DSDTM_ERR_INVALID;
 }
 
 void dsdtm_destroy(dsdtm_ctx* ctx) {
@@ -283,7 +329,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     // of OTHER kinds on other streams can still delay a member: such a wait ends when their workgroups drain; a
     // wait that does not end raises the timeout flag, see dsdtm_sparse_align_check). Not used while capturing
     // (a graph replay could not be ordered against live team launches): those shapes take the one-CU kernels.
-    const bool no_team = getenv("DSDTM_NO_TEAM") != nullptr;      // diagnostic switch, read per call (tests toggle it)
+    const bool no_team = options().no_team != 0;
     if (const int k = (b->n_pairs <= 64 && !no_team && !capturing) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0) {
         if (ctx->team_any && ctx->team_last_stream != stream) {
             // the context's own stream is alive as long as the context: its event is recorded on demand;
@@ -424,7 +470,7 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     memcpy(h + o_tc, T_cur_w, 96);
     // Resident frames: the kernel reads features and poses straight from the pinned staging block (once per
     // pair, ~17 KB over PCIe) and writes its few results there: no H2D / D2H copy operations around the launch.
-    static const bool zero_copy_enabled = getenv("DSDTM_NO_ZERO_COPY") == nullptr;
+    const bool zero_copy_enabled = !options().no_zero_copy;
     const bool zero_copy = zero_copy_enabled && !staged_pyr;
     if (zero_copy) {
         void* hd = nullptr;
@@ -769,15 +815,13 @@ extern "C" int dsdtm_pyrdown_batch_device(dsdtm_ctx* ctx, uint8_t* pyr, size_t p
     // Few images (the live tracker's new frame): ONE launch builds every level, intermediate levels in LDS — the call is
     // bound by launch latency and dependent round trips, 0.0145 -> 0.0079 ms for a 640x480x4 pyramid. Large batches are
     // bound by HBM and run one launch per level (the fused kernel's LDS stages issue no loads: 2..30 % slower from 64
-    // images on, `tools/pyr_ab.py`). DSDTM_PYR_FUSED=0 / 2: never / whenever the shape allows (A/B, tests);
-    // DSDTM_PYR_BAND: rows of the coarsest level per workgroup.
-    const char* env_fused = getenv("DSDTM_PYR_FUSED");            // read per call (tests toggle it)
-    const char* env_band = getenv("DSDTM_PYR_BAND");
-    const int fused_mode = env_fused ? atoi(env_fused) : 1;
+    // images on, `tools/pyr_ab.py`). option pyr_fused = 0 / 2: never / whenever the shape allows (A/B, tests);
+    // pyr_band: rows of the coarsest level per workgroup.
+    const int fused_mode = options().pyr_fused;
     if (fused_mode == 2 || (fused_mode == 1 && n_images <= 32)) {
         bool launched = false;
         HIP_TRY(ctx, pyrdown_fused_launch(pyr, pyr_pitch, n_images, levels, width, height, stride, level_offset,
-                                          env_band ? atoi(env_band) : 0, (hipStream_t)hip_stream, &launched));
+                                          options().pyr_band, (hipStream_t)hip_stream, &launched));
         if (launched) return DSDTM_OK;
     }
     for (int l = 1; l < levels; ++l)
@@ -947,7 +991,7 @@ extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* 
     // Every input is read once per candidate and every result written once: the two kernels take them straight
     // from / to the pinned block (no copy operations around the launches); only the warped patches, which the
     // second kernel re-reads at every iteration, live in device memory.
-    static const bool zero_copy = getenv("DSDTM_NO_ZERO_COPY") == nullptr;
+    const bool zero_copy = !options().no_zero_copy;
     uint8_t* io = d;
     if (zero_copy) {
         void* hd = nullptr;
@@ -1045,8 +1089,8 @@ extern "C" int dsdtm_pose_optimization(dsdtm_ctx* ctx, const double* bearing, co
     // so it reads them straight from the pinned block and writes pose, summary and norms there — no copy operations
     // around the launch (DSDTM_NO_ZERO_COPY=1 restores them). Larger frames re-read their columns at every evaluation
     // and are copied to the device first.
-    static const bool zero_copy_enabled = getenv("DSDTM_NO_ZERO_COPY") == nullptr;
-    const bool zero_copy = zero_copy_enabled && n_features > 64 && n_features <= 512 && getenv("DSDTM_PO_NO_CACHE") == nullptr;
+    const bool zero_copy_enabled = !options().no_zero_copy;
+    const bool zero_copy = zero_copy_enabled && n_features > 64 && n_features <= 512 && !options().po_no_cache;
     if (zero_copy) {
         void* hd = nullptr;
         HIP_TRY(ctx, hipHostGetDevicePointer(&hd, ctx->h_pinned, 0));

@@ -37,19 +37,26 @@ struct SAKernelArgs {
     LevelGeom lv[DSDTM_MAX_LEVELS];
 };
 
-// storage type of the cached reference grid in the register-resident kernels (see sparse_align.hip)
-#ifndef SA_GRID_T
-#define SA_GRID_T double
-#endif
-// pairs per workgroup of the <=320-feature register kernel (see sparse_align.hip)
-#ifndef SA_PPW
-#define SA_PPW 2
-#endif
-// rows per current-image footprint window in LDS (residual_patch): 5 = no vertical slack, 7 = the
-// floor position may move by one row before a lane refills
-#ifndef SA_WIN_ROWS
-#define SA_WIN_ROWS 5
-#endif
+// Diagnostic switches (A/B runs, tests). Process-wide, read from the environment ONCE — by the first dsdtm_create —
+// and changed afterwards only through dsdtm_debug_set_option; no entry point of the library reads the environment
+// on its call path.
+struct Options {
+    int no_team = 0;           // DSDTM_NO_TEAM: large single pairs take the one-CU kernels instead of a team
+    int team_min = 449;        // DSDTM_TEAM_MIN: feature count from which few large pairs run as teams
+    int team_spread_min = 33;  // DSDTM_TEAM_SPREAD_MIN: team size from which members are spread over all XCDs
+    int ws_from = 704;         // DSDTM_WS_FROM: feature counts above this run the workspace kernel in batches
+    int ws_waves = 0;          // DSDTM_WS_WAVES: 4 / 8 forces the workspace kernel's workgroup shape (0: by patch count)
+    int ws_no_windows = 0;     // DSDTM_WS_NO_WINDOWS
+    int pyr_fused = 1;         // DSDTM_PYR_FUSED: 0 never / 1 up to 32 images / 2 whenever the shape allows
+    int pyr_band = 0;          // DSDTM_PYR_BAND: rows of the coarsest level per workgroup of the fused kernel (0: auto)
+    int no_zero_copy = 0;      // DSDTM_NO_ZERO_COPY: single-call entry points copy instead of mapping the pinned block
+    int po_no_cache = 0;       // DSDTM_PO_NO_CACHE: pose refinement without features in registers
+    int a2d_tree = 0;          // DSDTM_A2D_TREE: Align2D with DPP tree sums (cost comparison only; not bit-identical)
+    int reg_slots = 2;         // DSDTM_REG_SLOTS: pair slots per compute unit of the <= 320-feature kernel (2 | 3)
+};
+Options& options();
+
+constexpr int SA_PPW = 2;      // pair slots per workgroup of the <= 320-feature register kernel (see sparse_align.hip)
 #define DSDTM_STR2(x) #x
 #define DSDTM_STR(x) DSDTM_STR2(x)
 enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2, SA_REG128 = 3, SA_REG192 = 4, SA_REG256 = 5, SA_REG704 = 6 };

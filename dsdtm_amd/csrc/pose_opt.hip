@@ -547,7 +547,7 @@ hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream) {
     if (args.n_frames <= 0) return hipSuccess;
     // a few frames (the live tracker refines one): latency counts, four waves share a frame's features;
     // batches: one wave per frame, the solver part is not repeated
-    static const bool no_cache = getenv("DSDTM_PO_NO_CACHE") != nullptr;       // diagnostic (A/B)
+    const bool no_cache = options().po_no_cache != 0;                          // diagnostic (A/B)
     if (args.n_frames <= 32 && args.max_features > 64 && args.max_features <= 256 && !no_cache)
         hipLaunchKernelGGL((pose_opt_kernel<4, 1>), dim3((unsigned)args.n_frames), dim3(256), 0, stream, args);
     else if (args.n_frames <= 32 && args.max_features > 256 && args.max_features <= 512 && !no_cache)

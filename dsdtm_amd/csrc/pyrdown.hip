@@ -45,12 +45,6 @@ struct PyrDownArgs {
 #ifndef SA_PD_ROWS
 #define SA_PD_ROWS 4
 #endif
-#ifndef SA_PD_NT
-#define SA_PD_NT 0          // diagnostic: 1 non-temporal loads, 2 non-temporal stores
-#endif
-#ifndef SA_PD_DIAG
-#define SA_PD_DIAG 0        // diagnostic: 1 = no stores (read rate)
-#endif
 constexpr int PD_ROWS = SA_PD_ROWS;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -118,12 +112,7 @@ __device__ __forceinline__ uint4 pd_load16(const uint8_t* __restrict__ p) {
         return make_uint4(a.x, a.y, b.x, b.y);
     } else {
         const uint32_t* __restrict__ p32 = (const uint32_t*)p;
-#if SA_PD_NT & 1
-        return make_uint4(__builtin_nontemporal_load(p32), __builtin_nontemporal_load(p32 + 1), __builtin_nontemporal_load(p32 + 2),
-                          __builtin_nontemporal_load(p32 + 3));
-#else
         return make_uint4(p32[0], p32[1], p32[2], p32[3]);
-#endif
     }
 }
 
@@ -149,13 +138,7 @@ __device__ __forceinline__ void pd_rows(const uint4* raw, bool left, bool right,
         const u16x2 oB = pd_vert(wB[(2 * r) % 5], wB[(2 * r + 1) % 5], wB[(2 * r + 2) % 5], wB[(2 * r + 3) % 5], wB[(2 * r + 4) % 5]);
         const uint32_t packed = pd_pack(oA, oB);
         if constexpr (DST_LDS) { if (FULL || y < d_hi) *(uint32_t*)(ldst + (ptrdiff_t)(y - d_lo) * lstride + x4) = packed; }
-#if SA_PD_DIAG == 1
-        if (y >= own_lo && y < own_hi && packed == 0x12345678u) *(uint32_t*)(gp + (ptrdiff_t)r * gstride) = packed;   // (diagnostic: reads only)
-#elif SA_PD_NT & 2
-        if (y >= own_lo && y < own_hi) __builtin_nontemporal_store(packed, (uint32_t*)(gp + (ptrdiff_t)r * gstride));
-#else
         if (y >= own_lo && y < own_hi) *(uint32_t*)(gp + (ptrdiff_t)r * gstride) = packed;      // own_hi <= d_hi
-#endif
     }
 }
 
@@ -205,16 +188,11 @@ __device__ __forceinline__ void pd_task(const uint8_t* __restrict__ src, int sst
 // neighbours — are spread over all eight L2s and every halo row is fetched from HBM by two of them. The
 // remapped id gives each XCD a contiguous range of (image, block) pairs, so an image's blocks meet in one L2.
 // SA_PD_XCD=0 restores the plain numbering (A/B).
-#ifndef SA_PD_XCD
-#define SA_PD_XCD 1
-#endif
 __device__ __forceinline__ void pd_block(int& img, int& bx) {
     const unsigned nb = gridDim.x, total = gridDim.x * gridDim.z;
     unsigned lb = blockIdx.z * nb + blockIdx.x;
-#if SA_PD_XCD
     const unsigned q = total / 8u;
     if (lb < q * 8u) lb = (lb % 8u) * q + lb / 8u;
-#endif
     img = (int)(lb / nb);
     bx = (int)(lb % nb);
 }

@@ -109,37 +109,9 @@ struct BlockState {
 // counters instead. All waves of a workgroup are co-resident, every wait has its producer in
 // flight, and every spin is bounded (a broken protocol ends the kernel instead of hanging the GPU).
 constexpr unsigned SPIN_LIMIT = 1u << 24;
-// current-image windows parked byte-aligned to their first column (window_commit / residual_patch); needs 5-row windows
-#ifndef SA_WIN_ALIGNED
-#define SA_WIN_ALIGNED (SA_WIN_ROWS == 5)
-#endif
-#ifndef SA_HESS_LEAN
-#define SA_HESS_LEAN 1
-#endif
-#ifndef SA_HBLOCK_GROUP
-#define SA_HBLOCK_GROUP 1
-#endif
-// SA_PASS_LEAN: instruction diet of the residual pass (see project_patch / residual_patch); 0 restores round 1's code
-#ifndef SA_PASS_LEAN
-#define SA_PASS_LEAN 1
-#endif
-// Row partials of the register kernel by packed butterflies (row_reduce8: 54 instead of 96 instructions per eight
-// values, and none of the s_nops that a chain of dependent DPP steps needs) instead of one DPP rotation chain per
-// value, for the pass's seven sums and the 21 entries of the H block. First measured as "no difference" (a build
-// that still spilled in the solver); on the final kernel: 0.2196 -> 0.2107 ms, +4 % (passes and level starts are
-// bound by VALU issue on the SIMDs that carry three patch waves).
-#ifndef SA_PACKED_REDUCE
-#define SA_PACKED_REDUCE 1
-#endif
-#ifndef SA_VIS_BALLOT
-#define SA_VIS_BALLOT 1
-#endif
-#ifndef SA_SLEEP_ARRIVE
-#define SA_SLEEP_ARRIVE 1   // solver waiting for the patch waves (and for acknowledgements)
-#endif
-#ifndef SA_SLEEP_SEQ
-#define SA_SLEEP_SEQ 4      // patch waves waiting for the solver (polling less often leaves issue slots and LDS to the others: +1 %)
-#endif
+// s_sleep units between two polls: the solver waiting for the patch waves (and for acknowledgements) / the patch
+// waves waiting for the solver (polling less often leaves issue slots and LDS to the others: +1 %)
+constexpr int SLEEP_ARRIVE = 1, SLEEP_SEQ = 4;
 // A spin that runs out means the protocol is broken: the wave leaves the wait (so the kernel always
 // terminates) and raises this device-global flag, which the host entry points turn into an error.
 __device__ unsigned g_handover_timeout = 0;
@@ -156,7 +128,7 @@ __device__ __forceinline__ void pair_signal_arrive(unsigned* counter, int lane) 
 __device__ __forceinline__ void pair_wait_arrive(unsigned* counter, unsigned target) {
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < SPIN_LIMIT)
-        __builtin_amdgcn_s_sleep(SA_SLEEP_ARRIVE);
+        __builtin_amdgcn_s_sleep(SLEEP_ARRIVE);
     if (spins >= SPIN_LIMIT) spin_timeout();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -167,7 +139,7 @@ __device__ __forceinline__ void pair_publish(BlockState& s, unsigned seq, int la
 __device__ __forceinline__ void pair_wait_seq(BlockState& s, unsigned seq) {
     unsigned spins = 0;
     while (__hip_atomic_load(&s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq && ++spins < SPIN_LIMIT)
-        __builtin_amdgcn_s_sleep(SA_SLEEP_SEQ);
+        __builtin_amdgcn_s_sleep(SLEEP_SEQ);
     if (spins >= SPIN_LIMIT) spin_timeout();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -198,11 +170,11 @@ __device__ __forceinline__ double ub(uint32_t w, int k) {
 }
 
 // Per-patch state that lives across the Gauss-Newton iterations of one level.
-// GT = storage type of the interpolated reference intensities (double = what the reference
-// caches in mRefPatch; float halves the register footprint, arithmetic stays FP64).
-template <typename GT>
+// The interpolated reference intensities are doubles, what the reference caches in mRefPatch. (They are EXACT: the
+// subpixel offsets of a float pixel position >= 3 * 2^level have at most 22 fractional bits each, so every weighted
+// sum of four bytes fits 8 + 44 bits — no rounding whatever the order of operations.)
 struct PatchRegs {
-    GT g[6][6];       // bilinear reference intensities on the 6x6 grid (corners unused)
+    double g[6][6];   // bilinear reference intensities on the 6x6 grid (corners unused)
     double X[3];      // 3-D point in the reference camera, bearing * |P_w - C_ref| (:117-119), kept in
                       // normalised form (x/z, y/z, 1/z)
     bool valid;
@@ -213,8 +185,7 @@ struct PatchRegs {
 // VGPRs — several hundred bytes per lane, which is exactly the cache this kernel avoids. An empty
 // asm with a read-write VGPR operand makes the state opaque once per iteration (no instruction is
 // emitted), so derived values are recomputed where they are used.
-template <typename GT>
-__device__ __forceinline__ void pin_patch(PatchRegs<GT>& P) {
+__device__ __forceinline__ void pin_patch(PatchRegs& P) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -346,9 +317,8 @@ __device__ __forceinline__ void ref_rows_unpack(const SAKernelArgs& a, const Lev
 // The grid g[r][c] = bilinear value at pixel (fv-3+r, fu-3+c) + subpixel offset, built row by row.
 // Patch pixel (i,k), i,k in 0..3, is g[i+1][k+1] (offsets -2..+1 from floor, quirk Q4); its
 // gradient neighbours are g[i+1][k], g[i+1][k+2], g[i][k+1], g[i+2][k+1] (:150-158).
-template <typename GT>
 __device__ __forceinline__ void grid_from_rows(const FeatureRegs& F, const RefGeom& g, const uint32_t* rlo, const uint32_t* rhi,
-                                               PatchRegs<GT>& P) {
+                                               PatchRegs& P) {
     // lanes without a valid patch get a harmless point: their A, B (patch_AB) stay finite, so that zeroing the three
     // gradient sums is enough to keep them out of the H block (patch_hess_factors)
     P.X[0] = g.valid ? F.X[0] : 0.0; P.X[1] = g.valid ? F.X[1] : 0.0; P.X[2] = g.valid ? F.X[2] : 1.0;
@@ -364,8 +334,8 @@ __device__ __forceinline__ void grid_from_rows(const FeatureRegs& F, const RefGe
         if (r > 0) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                if ((r - 1 == 0 || r - 1 == 5) && (c == 0 || c == 5)) { P.g[r - 1][c] = (GT)0; continue; }   // corners: unused
-                P.g[r - 1][c] = (GT)(w00 * top[c] + w01 * top[c + 1] + w10 * bot[c] + w11 * bot[c + 1]);
+                if ((r - 1 == 0 || r - 1 == 5) && (c == 0 || c == 5)) { P.g[r - 1][c] = 0.0; continue; }   // corners: unused
+                P.g[r - 1][c] = (w00 * top[c] + w01 * top[c + 1] + w10 * bot[c] + w11 * bot[c + 1]);
             }
         }
 #pragma unroll
@@ -374,10 +344,9 @@ __device__ __forceinline__ void grid_from_rows(const FeatureRegs& F, const RefGe
     }
 }
 
-template <typename GT>
 __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const LevelGeom& lg, int level,
                                                  const uint8_t* __restrict__ ref_base,  // pair's ref pyramid
-                                                 const FeatureRegs& F, PatchRegs<GT>& P) {
+                                                 const FeatureRegs& F, PatchRegs& P) {
     const RefGeom g = ref_geom(F, lg, level);
     uint32_t rlo[7], rhi[7];
     {
@@ -386,7 +355,7 @@ __device__ __forceinline__ void precompute_patch(const SAKernelArgs& a, const Le
         ref_rows_unpack(a, lg, g, w, rlo, rhi);
     }
     __builtin_amdgcn_sched_barrier(0);
-    grid_from_rows<GT>(F, g, rlo, rhi, P);
+    grid_from_rows(F, g, rlo, rhi, P);
 }
 
 // Per-patch Gauss-Newton matrix  Sxx A A^T + Sxy (A B^T + B A^T) + Syy B B^T  (upper triangle,
@@ -397,51 +366,38 @@ struct PatchHess {
     double A[6], B[6];
     // A = [a0, 0, A2..A5], B = [0, b0, B2..B5] (GetJocabianBA's zeros): with P_j = sxx A_j + sxy B_j and
     // Q_j = sxy A_j + syy B_j the entry (i, j) is A_i P_j + B_i Q_j — two operations instead of six, and nothing is
-    // multiplied by the structural zeros (SA_HESS_LEAN; the level start is bound by VALU issue like the pass)
+    // multiplied by the structural zeros (the level start is bound by VALU issue like the pass)
     double Pj[6], Qj[6];
     template <int I, int J>
     __device__ __forceinline__ double entry() const {
-#if SA_HESS_LEAN
         if constexpr (I == 0 && J == 0) return A[0] * Pj[0];
         else if constexpr (I == 0 && J == 1) return A[0] * Pj[1];
         else if constexpr (I == 0) return A[0] * Pj[J];
         else if constexpr (I == 1 && J == 1) return B[1] * Qj[1];
         else if constexpr (I == 1) return B[1] * Qj[J];
         else return A[I] * Pj[J] + B[I] * Qj[J];
-#else
-        return sxx * (A[I] * A[J]) + sxy * (A[I] * B[J] + B[I] * A[J]) + syy * (B[I] * B[J]);
-#endif
     }
 };
 
 // `use` = the patch contributes (valid / visible): otherwise its three sums, hence all 21 entries, are zero
-template <typename GT>
-__device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs<GT>& P, double fs, bool use = true) {
+__device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs& P, double fs, bool use = true) {
     PatchHess h;
     double sxx = 0.0, sxy = 0.0, syy = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-#if SA_HESS_LEAN
             // the 0.5 of the central differences as ONE exact scaling of the three sums (power of two)
-            const double dx = (double)P.g[i + 1][k + 2] - (double)P.g[i + 1][k];
-            const double dy = (double)P.g[i + 2][k + 1] - (double)P.g[i][k + 1];
-#else
-            const double dx = 0.5 * ((double)P.g[i + 1][k + 2] - (double)P.g[i + 1][k]);
-            const double dy = 0.5 * ((double)P.g[i + 2][k + 1] - (double)P.g[i][k + 1]);
-#endif
+            const double dx = P.g[i + 1][k + 2] - P.g[i + 1][k];
+            const double dy = P.g[i + 2][k + 1] - P.g[i][k + 1];
             sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
         }
-#if SA_HESS_LEAN
     sxx = use ? sxx * 0.25 : 0.0; sxy = use ? sxy * 0.25 : 0.0; syy = use ? syy * 0.25 : 0.0;
-#endif
     h.sxx = sxx; h.sxy = sxy; h.syy = syy;
     double A5[5], B5[5];
     patch_AB(fs, P.X, A5, B5);
     h.A[0] = A5[0]; h.A[1] = 0.0;   h.A[2] = A5[1]; h.A[3] = A5[2]; h.A[4] = A5[3]; h.A[5] = A5[4];
     h.B[0] = 0.0;   h.B[1] = B5[0]; h.B[2] = B5[1]; h.B[3] = B5[2]; h.B[4] = B5[3]; h.B[5] = B5[4];
-#if SA_HESS_LEAN
     h.Pj[0] = sxx * h.A[0]; h.Qj[0] = sxy * h.A[0];               // B_0 = 0
     h.Pj[1] = sxy * h.B[1]; h.Qj[1] = syy * h.B[1];               // A_1 = 0
 #pragma unroll
@@ -449,7 +405,6 @@ __device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs<GT>& P, 
         h.Pj[j] = sxx * h.A[j] + sxy * h.B[j];
         h.Qj[j] = sxy * h.A[j] + syy * h.B[j];
     }
-#endif
     return h;
 }
 
@@ -469,18 +424,11 @@ __device__ __forceinline__ double patch_hess_entry_q(const PatchHess& h) {
 template <int G>
 __device__ __forceinline__ void patch_hess_rows_group(const PatchHess& ph, bool use, int lane, double* Hout) {
     double v[8];
-#if SA_HESS_LEAN
     (void)use;       // the factors were built with `use`: a patch that does not contribute has zero sums
     v[0] = patch_hess_entry_q<8 * G + 0>(ph); v[1] = patch_hess_entry_q<8 * G + 1>(ph);
     v[2] = patch_hess_entry_q<8 * G + 2>(ph); v[3] = patch_hess_entry_q<8 * G + 3>(ph);
     v[4] = patch_hess_entry_q<8 * G + 4>(ph); v[5] = patch_hess_entry_q<8 * G + 5>(ph);
     v[6] = patch_hess_entry_q<8 * G + 6>(ph); v[7] = patch_hess_entry_q<8 * G + 7>(ph);
-#else
-    v[0] = use ? patch_hess_entry_q<8 * G + 0>(ph) : 0.0; v[1] = use ? patch_hess_entry_q<8 * G + 1>(ph) : 0.0;
-    v[2] = use ? patch_hess_entry_q<8 * G + 2>(ph) : 0.0; v[3] = use ? patch_hess_entry_q<8 * G + 3>(ph) : 0.0;
-    v[4] = use ? patch_hess_entry_q<8 * G + 4>(ph) : 0.0; v[5] = use ? patch_hess_entry_q<8 * G + 5>(ph) : 0.0;
-    v[6] = use ? patch_hess_entry_q<8 * G + 6>(ph) : 0.0; v[7] = use ? patch_hess_entry_q<8 * G + 7>(ph) : 0.0;
-#endif
     const double t = row_reduce8(v, lane);
     const int q = 8 * G + row_reduce8_index(lane);
     if (!(lane & 4) && q < 21) Hout[q] = t;
@@ -509,7 +457,7 @@ __device__ __forceinline__ void patch_hess_foreach(const PatchHess& h, F&& f) {
 // filled it; a pass whose floor position is within [u0-1, u0+3] x [v0-t, v0+t], t = (WIN_ROWS-5)/2,
 // reads LDS only, otherwise the lane refills its window from the pyramid. Layout [row*3+dword][lane]
 // (`win` points at this lane's column, planes are WIN_NL dwords apart): conflict-free.
-constexpr int WIN_ROWS = SA_WIN_ROWS;
+constexpr int WIN_ROWS = 5;
 constexpr uint32_t WIN_EMPTY = 0xffffffffu;
 
 
@@ -524,23 +472,17 @@ __device__ __forceinline__ bool project_patch(const SAKernelArgs& a, const Level
     const double pzc = sR[6] * X[0] + sR[7] * X[1] + sR[8] + st[2] * X[2];
     // Camera2Pixel (src/Camera.cpp:167-171), * tScale (:255)
     // one reciprocal for both coordinates (the reference divides twice; <= 1 ulp on u,v)
-    const double izc = SA_PASS_LEAN ? rcp_f64_newton(pzc) : 1.0 / pzc;
+    const double izc = rcp_f64_newton(pzc);
     u = ((double)a.fx * pxc * izc + (double)a.cx) * scale;
     v = ((double)a.fy * pyc * izc + (double)a.cy) * scale;
     // :262 with mnboarder = 3 on floored ints: floor(u) >= 3 && floor(u)+3 < cols (NaN fails). Evaluated without
     // short-circuits: the pass is bound by VALU issue, and nested early-outs made the compiler re-zero the seven
     // result registers on every arm (21 moves on the visible path)
-#if SA_VIS_BALLOT
     // four v_cmp into SGPR pairs + three s_and (scalar unit) + the combined mask as the lane condition; written with `&`
     // on the bools, the vectoriser packs the four bits into an i4 and the backend spends ~15 VALU instructions on it
-    {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(u >= 3.0) & __builtin_amdgcn_ballot_w64(u < (double)(lg.w - 3)) &
-                                     __builtin_amdgcn_ballot_w64(v >= 3.0) & __builtin_amdgcn_ballot_w64(v < (double)(lg.h - 3));
-        return __builtin_amdgcn_inverse_ballot_w64(m);
-    }
-#endif
-    if (SA_PASS_LEAN) return (u >= 3.0) & (u < (double)(lg.w - 3)) & (v >= 3.0) & (v < (double)(lg.h - 3));
-    return u >= 3.0 && u < (double)(lg.w - 3) && v >= 3.0 && v < (double)(lg.h - 3);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(u >= 3.0) & __builtin_amdgcn_ballot_w64(u < (double)(lg.w - 3)) &
+                                 __builtin_amdgcn_ballot_w64(v >= 3.0) & __builtin_amdgcn_ballot_w64(v < (double)(lg.h - 3));
+    return __builtin_amdgcn_inverse_ballot_w64(m);
 }
 
 // A window fill in flight: the row gathers have been issued, window_commit parks them in LDS.
@@ -573,7 +515,6 @@ __device__ __forceinline__ void window_commit(const SAKernelArgs& a, const Level
         const uint32_t o = lg.off + (uint32_t)(f.v_i - HR + r) * (uint32_t)lg.stride + (uint32_t)(f.u_i - 3);
         const bool in = min(o >> 2, last_dw - 2u) == (o >> 2);
         const uint32_t d0 = in ? f.w[r].a : f.w[r].b, d1 = in ? f.w[r].b : f.w[r].c, d2 = in ? f.w[r].c : 0u;
-#if SA_WIN_ALIGNED
         // parked with column u_i - 3 in byte 0 of the row's first dword (9..12 valid bytes): a pass then needs the same
         // dword offset and byte shift for all five rows and no per-row address arithmetic (the pass is bound by VALU
         // issue; this is done once per fill)
@@ -581,32 +522,22 @@ __device__ __forceinline__ void window_commit(const SAKernelArgs& a, const Level
         win[(r * 3 + 0) * WIN_NL] = __builtin_amdgcn_alignbit(d1, d0, sh);
         win[(r * 3 + 1) * WIN_NL] = __builtin_amdgcn_alignbit(d2, d1, sh);
         win[(r * 3 + 2) * WIN_NL] = d2 >> sh;
-#else
-        win[(r * 3 + 0) * WIN_NL] = d0;
-        win[(r * 3 + 1) * WIN_NL] = d1;
-        win[(r * 3 + 2) * WIN_NL] = d2;
-#endif
     }
     worg = (uint32_t)f.u_i | ((uint32_t)f.v_i << 16);
 }
 
 // ComputeResiduals for one patch (reference :252-296). Returns visibility; produces chi2 and
 // b = sum_px J*res (as A*gx + B*gy) of this patch.
-template <typename GT, int WIN_NL = 0>
+template <int WIN_NL = 0>
 __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const LevelGeom& lg, double scale, double fs,
-                                               const uint8_t* __restrict__ cur_base, const PatchRegs<GT>& P,
+                                               const uint8_t* __restrict__ cur_base, const PatchRegs& P,
                                                const double* __restrict__ sR, const double* __restrict__ st,
                                                double& chi2, double* b, LdsU32* win = nullptr, uint32_t* worg = nullptr) {
     chi2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = 0.0;
     double u, v;
-#if SA_PASS_LEAN
     if (!(project_patch(a, lg, scale, P.X, sR, st, u, v) & P.valid)) return false;    // ONE exit for lanes without a visible patch
-#else
-    if (!P.valid) return false;
-    if (!project_patch(a, lg, scale, P.X, sR, st, u, v)) return false;
-#endif
     const double fu_d = floor(u), fv_d = floor(v);
     const int u_i = (int)fu_d, v_i = (int)fv_d;
     const double su = u - fu_d, sv = v - fv_d;
@@ -627,7 +558,6 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
             window_commit<WIN_NL>(a, lg, f, win, *worg);
             u0 = u_i; v0 = v_i;
         }
-#if SA_WIN_ALIGNED
         static_assert(WIN_ROWS == 5, "aligned windows: the window's rows are the pass's rows");
         {
             const uint32_t p = (uint32_t)(u_i - u0 + 1);          // byte of column u_i - 2 in the parked rows: 0..4
@@ -640,19 +570,6 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
                 whi[r] = hi >> sh;                                  // byte 4 in bits 0..7
             }
         }
-#else
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const uint32_t rowb = lg.off + (uint32_t)(v_i - 2 + r) * (uint32_t)lg.stride;
-            const uint32_t o = rowb + (uint32_t)(u_i - 2);
-            const uint32_t c = (o >> 2) - ((rowb + (uint32_t)(u0 - 3)) >> 2);      // 0 or 1
-            const uint32_t plane = (uint32_t)(v_i - 2 + r - (v0 - HR)) * 3u + c;
-            const uint32_t lo = win[plane * WIN_NL], hi = win[(plane + 1u) * WIN_NL];
-            const uint32_t sh = (o & 3u) * 8u;
-            wlo[r] = __builtin_amdgcn_alignbit(hi, lo, sh);     // bytes 0..3 of the row
-            whi[r] = hi >> sh;                                  // byte 4 in bits 0..7
-        }
-#endif
     } else {
         U32x2 wr[5];
 #pragma unroll
@@ -682,9 +599,9 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const double cur = tl * top[k] + trw * top[k + 1] + bl * bot[k] + br * bot[k + 1];   // :281
-            const double res = cur - (double)P.g[i + 1][k + 1];                                   // :282
-            const double ddx = (double)P.g[i + 1][k + 2] - (double)P.g[i + 1][k];      // 2*dx (:150)
-            const double ddy = (double)P.g[i + 2][k + 1] - (double)P.g[i][k + 1];      // 2*dy (:155)
+            const double res = cur - P.g[i + 1][k + 1];                                   // :282
+            const double ddx = P.g[i + 1][k + 2] - P.g[i + 1][k];      // 2*dx (:150)
+            const double ddy = P.g[i + 2][k + 1] - P.g[i][k + 1];      // 2*dy (:155)
             if (k & 1) { c2b += res * res; gxb += ddx * res; gyb += ddy * res; }
             else       { c2a += res * res; gxa += ddx * res; gya += ddy * res; }
         }
@@ -693,7 +610,6 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
         __builtin_amdgcn_sched_barrier(0);
     }
     chi2 = c2a + c2b;
-#if SA_PASS_LEAN
     // JRes += J*res (:291) with J = dx*A + dy*B, written out in the normalised point (patch_AB's entries) so that the
     // ten products A_i, B_i are never formed: with gX = fs/2 * sum(2dx res), gY likewise and s = xn gX + yn gY
     //   b = [-zi gX, -zi gY, zi s, yn s + gY, -(xn s + gX), yn gX - xn gY]          (11 instead of 24 instructions)
@@ -708,19 +624,6 @@ __device__ __forceinline__ bool residual_patch(const SAKernelArgs& a, const Leve
     b[3] = yn * sxy + gY;
     b[4] = -(xn * sxy + gX);
     b[5] = yn * gX - xn * gY;
-#else
-    // the 0.5 of the central difference commutes exactly with every rounding in the sums
-    const double gx = 0.5 * (gxa + gxb);
-    const double gy = 0.5 * (gya + gyb);
-    double A[5], B[5];
-    patch_AB(fs, P.X, A, B);
-    b[0] = A[0] * gx;                      // JRes += J*res (:291) with J = dx*A + dy*B
-    b[1] = B[0] * gy;
-    b[2] = A[1] * gx + B[1] * gy;
-    b[3] = A[2] * gx + B[2] * gy;
-    b[4] = A[3] * gx + B[3] * gy;
-    b[5] = A[4] * gx + B[4] * gy;
-#endif
     return true;
 }
 
@@ -1122,11 +1025,6 @@ __device__ __attribute__((noinline)) void solver_finish(double* T_cur_w_pair, in
 // fits: PPW = 2 runs two independent pair pipelines in one workgroup, synchronised by the
 // pair-local counters above instead of s_barrier, so one pair's solve overlaps the other's pass and
 // the 10 patch waves balance over the 4 SIMDs.
-#ifndef SA_WAVES_PER_EU
-#define SA_WAVES_ATTR
-#else
-#define SA_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SA_WAVES_PER_EU, SA_WAVES_PER_EU)))
-#endif
 // LDS of the register kernel. One struct
 // so that the layout is ours: the small, hot structures sit at the lowest addresses (ds_read/ds_write
 // immediate offsets reach 64 KB; behind a large array every access would need extra address
@@ -1139,8 +1037,8 @@ struct RegSmem {
     uint32_t win[PPW][WIN_ROWS * 3 * NPW * 64];          // current-image footprint windows (residual_patch), [plane][lane]
 };
 
-template <int NPW, typename GT, int PPW, bool STAMPS = false>
-__global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_align_reg_kernel(const SAKernelArgs a) {
+template <int NPW, int PPW, bool STAMPS = false>
+__global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(const SAKernelArgs a) {
     constexpr int NP = NPW * 4;            // one partial slot per 16-lane DPP row
     constexpr int WPP = NPW + 1;           // waves per pair
     __shared__ RegSmem<NPW, PPW> sm;
@@ -1317,12 +1215,12 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             const LevelGeom lg = a.lv[level];
             const double scale = (double)(1.0f / (float)(1 << level));
             const double fs = (double)a.f * scale;
-            PatchRegs<GT> P;
+            PatchRegs P;
             uint32_t worg = WIN_EMPTY;                                 // the level's window is filled by its first pass
             unsigned long long tp0 = 0;
             if (STAMPS) tp0 = __builtin_amdgcn_s_memtime();
             LdsU32* const win = (LdsU32*)&sm.win[slot][ltid];
-            precompute_patch<GT>(a, lg, level, ref_base, F, P);
+            precompute_patch(a, lg, level, ref_base, F, P);
             if (STAMPS) {
                 pin_patch(P);   // make the stamp wait for the precompute results
                 const unsigned long long dtp = __builtin_amdgcn_s_memtime() - tp0;
@@ -1338,19 +1236,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
             {
                 unsigned long long th0 = 0;
                 if (STAMPS) th0 = __builtin_amdgcn_s_memtime();
-                const PatchHess ph = patch_hess_factors<GT>(P, fs, P.valid);
-#if SA_PACKED_REDUCE
+                const PatchHess ph = patch_hess_factors(P, fs, P.valid);
                 patch_hess_rows(ph, P.valid, lane, my_part.H);
-#else
-                double* Hout = my_part.H;
-                patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
-                    const double hs = row_sum16(P.valid ? v : 0.0);
-                    if (row_writer) Hout[q] = hs;
-                    // SA_HBLOCK_GROUP entries in flight: with one (round 1, to keep few values live) every DPP step
-                    // waits out its read-after-write hazard in s_nops (87 of them in the level-start code)
-                    if ((q % SA_HBLOCK_GROUP) == SA_HBLOCK_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
-                });
-#endif
                 pair_signal_arrive(&s.arrive_h, lane);                 // BH
                 if (STAMPS) st_h += __builtin_amdgcn_s_memtime() - th0;
             }
@@ -1364,12 +1251,11 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 // favours the older wave 0: 4.0 k vs 5.2 k cycles per pass, and the solver waits for the
                 // slower one. Giving wave 4 issue priority for part of its pass moves cycles between the
                 // two but not the slower finish: measured, no gain.)
-                const bool vis = residual_patch<GT, NPW * 64>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b,
+                const bool vis = residual_patch<NPW * 64>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b,
                                                                               win, &worg);
                 const unsigned long long vmask = __ballot(vis);
                 // reduce to the 16-lane DPP rows only; the solver's lane-parallel summation folds the 4*NPW row
                 // partials
-#if SA_PACKED_REDUCE
                 {
                     // b[0..5] and chi2 in ONE packed butterfly (row_reduce8): the lane holds the row total of value
                     // row_reduce8_index(lane); doubles 0..6 of a WavePartial are b[0..5], chi2
@@ -1382,18 +1268,6 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                     my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
                     my_part.n_ref = n_ref_row;
                 }
-#else
-#pragma unroll
-                for (int i = 0; i < 6; ++i) b[i] = row_sum16(b[i]);
-                chi2 = row_sum16(chi2);
-                if (row_writer) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) my_part.b[i] = b[i];
-                    my_part.chi2 = chi2;
-                    my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
-                    my_part.n_ref = n_ref_row;
-                }
-#endif
                 if (STAMPS) {
                     tq1 = __builtin_amdgcn_s_memtime(); st_pass += tq1 - tq0;
 #pragma unroll
@@ -1401,17 +1275,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
                 }
                 const bool h_changed = (vmask != cached_mask);        // wave-uniform, rare
                 if (h_changed) {
-                    const PatchHess ph = patch_hess_factors<GT>(P, fs, vis);
-#if SA_PACKED_REDUCE
+                    const PatchHess ph = patch_hess_factors(P, fs, vis);
                     patch_hess_rows(ph, vis, lane, my_part.H);
-#else
-                    double* Hout = my_part.H;
-                    patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
-                        const double hs = row_sum16(vis ? v : 0.0);
-                        if (row_writer) Hout[q] = hs;
-                        __builtin_amdgcn_sched_barrier(0);   // one entry live at a time
-                    });
-#endif
                     cached_mask = vmask;
                 }
                 if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
@@ -1464,23 +1329,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) SA_WAVES_ATTR void sparse_ali
 // grid_from_rows the register kernels run once per level (same inputs, same arithmetic: bit-identical values).
 // The first version parked the grid itself and was bound by exactly that traffic: 1024 pairs of 1000 patches moved
 // 8.7 GB per launch through HBM (rocprofv3 FETCH_SIZE/WRITE_SIZE, 9.7x the algorithmic bytes) at 6.2 TB/s.
-// patch waves of the workspace kernel's variant WITH a solver wave (SA_WS_SHARED=0; 7 + 1 = 2 waves per SIMD at up to 256
-// VGPRs; 11 + 1 = 3 per SIMD at 168 spilled heavily). The product shape has no solver wave: WS_SH below.
-#ifndef SA_WS_NPW
-#define SA_WS_NPW 7
-#endif
-#ifndef SA_WS_WINDOWS
-#define SA_WS_WINDOWS 1
-#endif
-#ifndef SA_WS_FROM
-#define SA_WS_FROM 704      // feature counts above this run the workspace kernel in batches
-#endif
-#ifndef SA_WS_SHARED
-#define SA_WS_SHARED 1      // 8 patch waves, the last one also solves (0: SA_WS_NPW patch waves + a solver wave)
-#endif
-constexpr bool WS_SH = SA_WS_SHARED != 0;
-constexpr int WS_NPW = WS_SH ? 8 : SA_WS_NPW;
-constexpr int WS_THREADS = (WS_SH ? WS_NPW : WS_NPW + 1) * 64;
+// The workgroup has no solver wave (a variant with 7 + 1 waves was measured: 1.5 % slower): 8 patch waves, or 4 when
+// two workgroups share a compute unit; the last patch wave also solves.
+constexpr int WS_NPW = 8;
+constexpr int WS_THREADS = WS_NPW * 64;
 constexpr int WS_DWORDS = 22;   // rlo[7], rhi[7], px, py, X[3] as dword pairs
 __host__ __device__ inline size_t ws_doubles_per_pair(int max_features) {
     const size_t npad = ((size_t)max_features + 63) / 64 * 64;
@@ -1518,9 +1370,9 @@ __device__ __forceinline__ void ws_load(const uint32_t* __restrict__ ws, size_t 
 }
 
 // the register-resident patch state of one parked patch (what precompute_patch leaves behind in the register kernels)
-__device__ __forceinline__ void ws_patch_regs(const WsPatch& w, const LevelGeom& lg, int level, PatchRegs<double>& P) {
+__device__ __forceinline__ void ws_patch_regs(const WsPatch& w, const LevelGeom& lg, int level, PatchRegs& P) {
     const RefGeom g = ref_geom(w.F, lg, level);          // valid == w.F.ok: the border test passed when the patch was parked
-    grid_from_rows<double>(w.F, g, w.rlo, w.rhi, P);
+    grid_from_rows(w.F, g, w.rlo, w.rhi, P);
 }
 
 // WCAP > 0: current-image footprint windows in LDS as in the register kernels (residual_patch, WIN_NL = WCAP): one
@@ -1528,16 +1380,16 @@ __device__ __forceinline__ void ws_patch_regs(const WsPatch& w, const LevelGeom&
 // dynamic LDS — 64 KB for up to 1024 patches, 128 KB for up to 2048. Without them every pass gathers its five
 // footprint rows per patch through the CU's texture-address path again (the round-2 kernel: 1024 pairs of 1000
 // patches 1.03 ms per launch).
-// SH (shared solver): no solver wave — the workgroup is NPW patch waves and the last of them runs the solve between
+// No solver wave — the workgroup is NPW patch waves and the last of them runs the solve between
 // the two barriers of an iteration. This kernel's patch state does not live in registers across passes (the grid is
 // rebuilt from the parked inputs every pass), so one wave can be both; at ~205 VGPRs a CU holds 8 waves, and 8 patch
 // waves instead of 7 + 1 turn the 1000 patches of BASELINE config 3 from three rounds of 448 lanes (the third 23 %
 // full) into two rounds of 512, and 2000 patches from five rounds into four.
-template <int NPW, int WCAP, bool SH>
-__global__ __launch_bounds__((SH ? NPW : NPW + 1) * 64) __attribute__((amdgpu_waves_per_eu(SH && NPW <= 4 ? 2 : 1, 2)))
+template <int NPW, int WCAP>
+__global__ __launch_bounds__(NPW * 64) __attribute__((amdgpu_waves_per_eu(NPW <= 4 ? 2 : 1, 2)))
 void sparse_align_ws_kernel(const SAKernelArgs a) {
     constexpr int PT = NPW * 64;   // patch threads
-    constexpr int SW = NPW - 1;    // SH: the wave that also solves
+    constexpr int SW = NPW - 1;    // the wave that also solves
     __shared__ WavePartial s_part[NPW];
     __shared__ BlockState s;
     extern __shared__ __attribute__((aligned(16))) uint32_t ws_win[];   // [16][WCAP]: 15 window planes + origins
@@ -1553,33 +1405,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
         return;
     }
 
-    if (!SH && wave == NPW) {
-        solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
-        if (lane == 0) stats_clear(a, pair);
-        __syncthreads();                                               // B0
-        for (int level = a.max_level - 1; level >= a.min_level; --level) {
-            if (lane == 0) {
-                s.chi2 = 0.0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s.qo[i] = s.u.q[i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) s.to[i] = s.u.t[i];
-            }
-            double hrow[6];                                            // row of H^+, rebuilt when a wave reports a new visible set
-            for (int it = 0; it < a.max_iters; ++it) {
-                __syncthreads();                                       // B1
-                SolverCarry carry;
-                const int ctrl = solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry);
-                __syncthreads();                                       // B2
-                solver_commit(a, pair, s, lane, carry);
-                if (ctrl) break;
-            }
-        }
-        solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
-        report_timeout(a, lane);
-        return;
-    }
-    const bool solves = SH && wave == SW;
+    const bool solves = wave == SW;
     if (solves) {
         solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
         if (lane == 0) stats_clear(a, pair);
@@ -1633,7 +1459,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
             int cnt = 0;
             unsigned long long vis_new = 0ull, bit = 1ull;
             for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
-                PatchRegs<double> P;
+                PatchRegs P;
                 {
                     WsPatch w;
                     ws_load(ws, npad, p, w);
@@ -1644,10 +1470,10 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                 if constexpr (WCAP > 0) {
                     uint32_t worg = ws_win[15 * WCAP + p];
                     const uint32_t worg0 = worg;
-                    vis = residual_patch<double, WCAP>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp, (LdsU32*)&ws_win[p], &worg);
+                    vis = residual_patch<WCAP>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp, (LdsU32*)&ws_win[p], &worg);
                     if (worg != worg0) ws_win[15 * WCAP + p] = worg;
                 } else {
-                    vis = residual_patch<double>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp);
+                    vis = residual_patch<>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp);
                 }
                 if (vis) {
 #pragma unroll
@@ -1667,7 +1493,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                 for (int i = 0; i < 21; ++i) H[i] = 0.0;
                 bit = 1ull;
                 for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
-                    PatchRegs<double> P;
+                    PatchRegs P;
                     if (maskable) {
                         if (!(vis_new & bit)) continue;
                         WsPatch w;
@@ -1680,7 +1506,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                         double u, v;
                         if (!P.valid || !project_patch(a, lg, scale, P.X, s.u.R, s.u.tt, u, v)) continue;
                     }
-                    const PatchHess ph = patch_hess_factors<double>(P, fs);
+                    const PatchHess ph = patch_hess_factors(P, fs);
                     patch_hess_foreach<0, 0>(ph, [&](int q, double v) { H[q] += v; });
                 }
 #pragma unroll
@@ -1702,22 +1528,18 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                 s_part[wave].h_changed = h_new ? 1 : 0;
             }
             __syncthreads();                                           // B1
-            if constexpr (SH) {
-                SolverCarry carry;
-                if (solves) {
-                    // row of H^+ from LDS at every step (refresh_hinv_to_lds parks it there): nothing of the solver
-                    // is live in registers across the pass
-                    double hrow[6];
-                    const int li = lane < 6 ? lane : 5;
+            SolverCarry carry;
+            if (solves) {
+                // row of H^+ from LDS at every step (refresh_hinv_to_lds parks it there): nothing of the solver
+                // is live in registers across the pass
+                double hrow[6];
+                const int li = lane < 6 ? lane : 5;
 #pragma unroll
-                    for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];
-                    (void)solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry);
-                }
-                __syncthreads();                                       // B2
-                if (solves) solver_commit(a, pair, s, lane, carry);
-            } else {
-                __syncthreads();                                       // B2
+                for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];
+                (void)solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry);
             }
+            __syncthreads();                                           // B2
+            if (solves) solver_commit(a, pair, s, lane, carry);
             if (s.ctrl) break;
         }
     }
@@ -1891,15 +1713,15 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
         const LevelGeom lg = a.lv[level];
         const double scale = (double)(1.0f / (float)(1 << level));
         const double fs = (double)a.f * scale;
-        PatchRegs<double> P;
+        PatchRegs P;
         uint32_t worg = WIN_EMPTY;
-        precompute_patch<double>(a, lg, level, ref_base, F, P);
+        precompute_patch(a, lg, level, ref_base, F, P);
         const int n_ref_wave = __popcll(__ballot(P.valid));
         unsigned long long cached_mask = 0ull;
         for (int it = 0; it < a.max_iters; ++it) {
             double chi2, b[6];
             pin_patch(P);
-            const bool vis = residual_patch<double, PT>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b, win, &worg);
+            const bool vis = residual_patch<PT>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, chi2, b, win, &worg);
             const unsigned long long vmask = __ballot(vis);
             const bool h_new = (it == 0) || (vmask != cached_mask);
 #pragma unroll
@@ -1914,7 +1736,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
                 my_part[wave].h_changed = h_new ? 1 : 0;
             }
             if (h_new) {
-                const PatchHess ph = patch_hess_factors<double>(P, fs);
+                const PatchHess ph = patch_hess_factors(P, fs);
                 double* Hout = my_part[wave].H;
                 patch_hess_foreach<0, 0>(ph, [&](int q, double v) {
                     const double hs = wave_sum_to_lane63(vis ? v : 0.0);
@@ -1945,15 +1767,13 @@ constexpr int TEAM_NPW = 4;
 static int team_pairs_pad(int n_pairs, int k) {
     // members of a team are workgroups b, b + P, b + 2P ..: P a multiple of 8 keeps a team on one XCD (one L2, 32
     // CUs); teams of more than 32 members cannot fit one XCD and are spread over all of them instead (P odd)
-    static const int spread_min = getenv("DSDTM_TEAM_SPREAD_MIN") ? atoi(getenv("DSDTM_TEAM_SPREAD_MIN")) : 33;   // diagnostic override
-    if (k < spread_min) return (n_pairs + 7) / 8 * 8;
+    if (k < options().team_spread_min) return (n_pairs + 7) / 8 * 8;
     return n_pairs | 1;
 }
 int sparse_align_team_size(int n_pairs, int max_features, int num_cus) {
     // from 449 features a team of 2..3 CUs beats the 11 + 1 wave register kernel on one CU (N = 600: 0.113 vs
-    // 0.121 ms per Run); below, one CU wins (N = 300: 0.108 vs 0.115 ms). DSDTM_TEAM_MIN overrides (diagnostic).
-    static const int team_min = getenv("DSDTM_TEAM_MIN") ? atoi(getenv("DSDTM_TEAM_MIN")) : 449;
-    if (max_features < team_min || n_pairs <= 0) return 0;
+    // 0.121 ms per Run); below, one CU wins (N = 300: 0.108 vs 0.115 ms).
+    if (max_features < options().team_min || n_pairs <= 0) return 0;
     const int k = (max_features + TEAM_NPW * 64 - 1) / (TEAM_NPW * 64);
     // every member must be resident at once (they spin on each other): the LIVE workgroups (n_pairs * k; the
     // padding workgroups exit at once) may take half the CUs
@@ -1988,8 +1808,7 @@ hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t
 //   <= 128 features: 2+1 waves x 4 slots     <= 192: 3+1 x 3     <= 256: 4+1 x 2
 //   <= 320 features: 5+1 x 2 (BASELINE shape) <= 448: 7+1 x 1     <= 704: 11+1 x 1
 SAVariant sparse_align_pick_variant(int max_features) {
-    static const int ws_from = getenv("DSDTM_WS_FROM") ? atoi(getenv("DSDTM_WS_FROM")) : SA_WS_FROM;   // diagnostic (A/B)
-    if (max_features > ws_from) return SA_WS;
+    if (max_features > options().ws_from) return SA_WS;   // 704 unless a diagnostic run moved it
     if (max_features <= 128) return SA_REG128;
     if (max_features <= 192) return SA_REG192;
     if (max_features <= 256) return SA_REG256;
@@ -2017,9 +1836,9 @@ hipError_t sparse_align_clear_timeout_flag() {
 
 int sparse_align_occupancy(int variant) {
     int nb = -1;
-    if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_GRID_T, SA_PPW, false>, SA_PPW * 6 * 64, 0);
-    else if (variant == SA_REG448) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<7, SA_GRID_T, 1, false>, 8 * 64, 0);
-    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<WS_NPW, 0, WS_SH>, WS_THREADS, 0);
+    if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_PPW, false>, SA_PPW * 6 * 64, 0);
+    else if (variant == SA_REG448) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<7, 1, false>, 8 * 64, 0);
+    else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<WS_NPW, 0>, WS_THREADS, 0);
     return nb;
 }
 
@@ -2032,7 +1851,7 @@ static unsigned persistent_grid(int n_pairs, int ppw, int num_cus) {
 template <int NPW, int PPW, bool STAMPS>
 static hipError_t launch_reg(const SAKernelArgs& args, int num_cus, hipStream_t stream) {
     static_assert(sizeof(RegSmem<NPW, PPW>) <= 64 * 1024, "static LDS");
-    hipLaunchKernelGGL((sparse_align_reg_kernel<NPW, SA_GRID_T, PPW, STAMPS>), dim3(persistent_grid(args.n_pairs, PPW, num_cus)),
+    hipLaunchKernelGGL((sparse_align_reg_kernel<NPW, PPW, STAMPS>), dim3(persistent_grid(args.n_pairs, PPW, num_cus)),
                        dim3(PPW * (NPW + 1) * 64), 0, stream, args);
     return hipGetLastError();
 }
@@ -2053,24 +1872,24 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
         case SA_REG704: return launch_reg<11, 1, false>(args, num_cus, stream);
         case SA_WS: {
             const int npad = (args.max_features + 63) / 64 * 64;
-            static const bool ws_windows = SA_WS_WINDOWS && getenv("DSDTM_WS_NO_WINDOWS") == nullptr;
+            const bool ws_windows = !options().ws_no_windows;
             // Two workgroups of four waves per CU (two pairs in flight: one's gathers overlap the other's arithmetic,
             // as the two slots of the register kernel do) when their windows fit side by side, else one of eight.
-            static const int ws_waves = getenv("DSDTM_WS_WAVES") ? atoi(getenv("DSDTM_WS_WAVES")) : 0;
+            const int ws_waves = options().ws_waves;
             const dim3 grid((unsigned)args.n_pairs);
-            if (WS_SH && ws_windows && npad <= 1024 && ws_waves != 8) {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<4, 1024, true>), grid, dim3(256), 16 * 1024 * sizeof(uint32_t), stream, args);
+            if (ws_windows && npad <= 1024 && ws_waves != 8) {
+                hipLaunchKernelGGL((sparse_align_ws_kernel<4, 1024>), grid, dim3(256), 16 * 1024 * sizeof(uint32_t), stream, args);
             } else if (ws_windows && npad <= 1024) {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024, WS_SH>), grid, dim3(WS_THREADS), 16 * 1024 * sizeof(uint32_t), stream, args);
+                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024>), grid, dim3(WS_THREADS), 16 * 1024 * sizeof(uint32_t), stream, args);
             } else if (ws_windows && npad <= 2048 && ws_waves != 4) {
-                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 2048, WS_SH>,
+                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 2048>,
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * sizeof(uint32_t));
                 if (attr != hipSuccess) return attr;
-                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 2048, WS_SH>), grid, dim3(WS_THREADS), 16 * 2048 * sizeof(uint32_t), stream, args);
-            } else if (WS_SH && ws_waves == 4) {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<4, 0, true>), grid, dim3(256), 0, stream, args);
+                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 2048>), grid, dim3(WS_THREADS), 16 * 2048 * sizeof(uint32_t), stream, args);
+            } else if (ws_waves == 4) {
+                hipLaunchKernelGGL((sparse_align_ws_kernel<4, 0>), grid, dim3(256), 0, stream, args);
             } else {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 0, WS_SH>), grid, dim3(WS_THREADS), 0, stream, args);
+                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 0>), grid, dim3(WS_THREADS), 0, stream, args);
             }
             break;
         }

@@ -3,7 +3,6 @@ the one-launch-per-pyramid kernel (band buffers in LDS) and the one-launch-per-l
 oracle, byte for byte, on batches — several band heights, 3..5 levels, odd heights, and shapes that are not
 eligible for the fused kernel (they must fall back, with the same bytes)."""
 import ctypes as C
-import os
 
 import numpy as np
 import pytest
@@ -25,19 +24,11 @@ def _run(gpu_ctx, imgs, levels, env):
     dev = torch.from_numpy(host).to("cuda:0")
     wa, ha, sa = (C.c_int * levels)(*ws), (C.c_int * levels)(*hs), (C.c_int * levels)(*ss)
     oa = (C.c_size_t * levels)(*offs)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with capi.debug_options(**env):
         st = torch.cuda.current_stream()
         gpu_ctx.check(gpu_ctx.lib.dsdtm_pyrdown_batch_device(gpu_ctx.handle, dev.data_ptr(), pitch, n, levels, wa, ha, sa, oa,
                                                             st.cuda_stream))
         torch.cuda.synchronize()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
     out = dev.cpu().numpy()
     return [[out[i, offs[l]:offs[l] + ws[l] * hs[l]].reshape(hs[l], ws[l]) for l in range(levels)] for i in range(n)], \
         out[:, nbytes:]
@@ -58,9 +49,8 @@ def test_batched_pyramids_match_the_oracle(gpu_ctx, oracle, shape, levels, n):
         want.append(pyr)
     ref_tail = None
     # band heights: automatic, the smallest, one that does not divide the coarsest level, the whole level
-    F = {"DSDTM_PYR_FUSED": "2"}                          # the fused kernel wherever the shape allows it
-    for env in ({}, F, dict(F, DSDTM_PYR_BAND="2"), dict(F, DSDTM_PYR_BAND="7"), dict(F, DSDTM_PYR_BAND="100000"),
-                {"DSDTM_PYR_FUSED": "0"}):
+    F = {"pyr_fused": 2}                                  # the fused kernel wherever the shape allows it
+    for env in ({}, F, dict(F, pyr_band=2), dict(F, pyr_band=7), dict(F, pyr_band=100000), {"pyr_fused": 0}):
         got, tail = _run(gpu_ctx, imgs, levels, env)
         for i in range(n):
             for l in range(levels):

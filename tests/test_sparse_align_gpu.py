@@ -609,7 +609,7 @@ def test_batch_launch_is_graph_capturable(gpu_ctx, oracle, N, P):
 def test_team_kernel_over_several_compute_units(gpu_ctx, oracle):
     """More features than one workgroup's registers hold (N > 704) and few pairs: every pair runs on a TEAM
     of K workgroups that exchange their partial sums and the pose through HBM each iteration. Same results
-    as the oracle and — to rounding — as the single-workgroup workspace kernel (DSDTM_NO_TEAM=1), bit-identical
+    as the oracle and — to rounding — as the single-workgroup workspace kernel (option no_team), bit-identical
     from launch to launch, ragged feature counts included; with many pairs the launcher falls back."""
     import ctypes as C
     import os
@@ -637,11 +637,8 @@ def test_team_kernel_over_several_compute_units(gpu_ctx, oracle):
     for _ in range(3):                                        # no dependence on timing
         T2, n2 = run(t, b, scenes)
         assert np.array_equal(T1, T2) and np.array_equal(n1, n2)
-    os.environ["DSDTM_NO_TEAM"] = "1"
-    try:
+    with capi.debug_options(no_team=1):
         Tw, nw = run(t, b, scenes)
-    finally:
-        del os.environ["DSDTM_NO_TEAM"]
     assert np.array_equal(n1, nw) and np.abs(T1 - Tw).max() < 1e-12
     # ragged feature counts: members without a live patch still take part in every exchange
     nf = np.array([1000, 720, 300], np.int32)

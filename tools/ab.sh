@@ -1,9 +1,12 @@
 #!/bin/bash
 # Same-box A/B of prebuilt library variants: tools/ab.sh variants/lib_a.so variants/lib_b.so ...
-# (each is copied over dsdtm_amd/csrc/libdsdtm_amd.so in turn; the last one stays in place). Per variant: two runs
+# (each is copied over dsdtm_amd/csrc/libdsdtm_amd.so in turn; the product library is restored at the end). Per variant: two runs
 # with one launch stream (kernel time by HIP events) and two with the bench's default streams (throughput).
 set -e
 cd "$(dirname "$0")/.."
+# the product library is put back when the script ends (the variants only ever replace it for the duration of a run)
+LIB=dsdtm_amd/csrc/libdsdtm_amd.so
+cp -p "$LIB" "$LIB.orig" && trap 'mv -f "$LIB.orig" "$LIB"' EXIT
 mkdir -p gpurun_out
 for so in "$@"; do
   cp "$so" dsdtm_amd/csrc/libdsdtm_amd.so

@@ -2,6 +2,9 @@
 # tools/ab_sizes.sh lib_a.so lib_b.so ... : bench at several batch sizes for each variant (same box)
 set -e
 cd "$(dirname "$0")/.."
+# the product library is put back when the script ends (the variants only ever replace it for the duration of a run)
+LIB=dsdtm_amd/csrc/libdsdtm_amd.so
+cp -p "$LIB" "$LIB.orig" && trap 'mv -f "$LIB.orig" "$LIB"' EXIT
 mkdir -p gpurun_out
 for so in "$@"; do
   cp "$so" dsdtm_amd/csrc/libdsdtm_amd.so; touch dsdtm_amd/csrc/libdsdtm_amd.so

@@ -1,5 +1,6 @@
 #!/bin/bash
-REPO="$GRAFT_REPO_ROOT"; OUT="$REPO/gpurun_out/fp64"; mkdir -p "$OUT"
+set -u
+REPO="$(cd "$(dirname "$0")/.." && pwd)"; OUT="$REPO/gpurun_out/fp64"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 5 120 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/p" -- python3 $REPO/bench.py --steps 40 --warmup 5 --streams 1 --no-cpu --no-secondary > "$OUT/p.log" 2>&1 || echo failed
 cd "$REPO"

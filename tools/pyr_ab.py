@@ -22,10 +22,9 @@ def case(W, H, L, n, reps, bands=(8, 10, 12, 15, 20, 30)):
     wa, ha, sa, oa = (C.c_int * L)(*ws), (C.c_int * L)(*hs), (C.c_int * L)(*ss), (C.c_size_t * L)(*offs)
     alg = sum(ws[l] * hs[l] + ws[l + 1] * hs[l + 1] for l in range(L - 1))
     fn = lambda: ctx.check(ctx.lib.dsdtm_pyrdown_batch_device(ctx.handle, pyr.data_ptr(), pitch, n, L, wa, ha, sa, oa, st.cuda_stream))
-    for name, env in [("per level", {"DSDTM_PYR_FUSED": "0"}), ("fused auto", {"DSDTM_PYR_FUSED": "2"})] + [(f"fused band {b}", {"DSDTM_PYR_FUSED": "2", "DSDTM_PYR_BAND": str(b)}) for b in bands]:
-        for k in ("DSDTM_PYR_FUSED", "DSDTM_PYR_BAND"): os.environ.pop(k, None)
-        os.environ.update(env)
-        ts = [timed(fn, reps) for _ in range(3)]
+    for name, opt in [("per level", dict(pyr_fused=0)), ("fused auto", dict(pyr_fused=2))] + [(f"fused band {b}", dict(pyr_fused=2, pyr_band=b)) for b in bands]:
+        with capi.debug_options(**{"pyr_band": 0, **opt}):
+            ts = [timed(fn, reps) for _ in range(3)]
         t = min(ts)
         print(f"{W}x{H} L={L} n={n:5d} {name:14s}: {t*1e3:8.4f} ms  {n/t/1e6:7.3f} M pyramids/s  {alg*n/t/1e9:7.0f} GB/s algorithmic", flush=True)
 
