@@ -38,7 +38,9 @@ struct dsdtm_ctx {
     //  * a launch captured into a hipGraph gets a word of its own from the graph pool, for the life of the
     //    context, and a memset node in front of it (a hipGraphExec never overlaps itself).
     unsigned* d_counter = nullptr;
-    struct StreamRing { hipStream_t stream; unsigned seq; bool used; void* d_ws; size_t ws_cap; unsigned long long last_use; };   // + the stream's workspace
+    // + the stream's workspace, and an event recorded behind the entry's last launch: what a 17th stream waits for
+    // before it takes the entry over (the old stream itself may be gone by then)
+    struct StreamRing { hipStream_t stream; unsigned seq; bool used; void* d_ws; size_t ws_cap; unsigned long long last_use; hipEvent_t last; bool last_recorded; };
     unsigned long long ring_tick = 0;
     static constexpr int MAX_STREAMS = 16, COUNTERS_PER_STREAM = 8, GRAPH_COUNTERS = 256;
     StreamRing rings[MAX_STREAMS] = {};
@@ -189,7 +191,7 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
-    for (auto& r : ctx->rings) if (r.d_ws) (void)hipFree(r.d_ws);
+    for (auto& r : ctx->rings) { if (r.d_ws) (void)hipFree(r.d_ws); if (r.last) (void)hipEventDestroy(r.last); }
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->d_team) (void)hipFree(ctx->d_team);
     if (ctx->team_event) (void)hipEventDestroy(ctx->team_event);
@@ -240,6 +242,17 @@ static int validate_params(dsdtm_ctx* ctx, const dsdtm_align_params* p, int leve
         set_err(ctx, "level range [%d,%d) does not fit a %d-level pyramid", p->min_level, p->max_level, levels);
         return DSDTM_ERR_INVALID;
     }
+    return DSDTM_OK;
+}
+
+// behind a launch that used ring entry `ring`: once every entry is taken, leave an event for a later hand-over
+static int ring_mark_launch(dsdtm_ctx* ctx, int ring, hipStream_t stream) {
+    if (ring < 0) return DSDTM_OK;
+    bool full = true;
+    for (const auto& r : ctx->rings) full = full && r.used;
+    if (!full) return DSDTM_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->rings[ring].last, stream));
+    ctx->rings[ring].last_recorded = true;
     return DSDTM_OK;
 }
 
@@ -299,15 +312,25 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
             if (ctx->rings[i].used && ctx->rings[i].stream == stream) ri = i;
         for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
-            if (!ctx->rings[i].used) { ctx->rings[i] = dsdtm_ctx::StreamRing{stream, 0u, true, nullptr, 0, 0ull}; ri = i; }
+            if (!ctx->rings[i].used) {
+                hipEvent_t ev = nullptr;
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                ctx->rings[i] = dsdtm_ctx::StreamRing{stream, 0u, true, nullptr, 0, 0ull, ev, false};
+                ri = i;
+            }
         if (ri < 0) {
             // A 17th stream (applications that keep creating streams): the entry that has been idle longest is handed
-            // over. Its old stream may be gone, so it cannot be waited for; the whole device is — once per eviction —
-            // after which nothing can still be using the entry's counters or workspace.
+            // over once the launches behind it have finished — the host waits for the event recorded behind the
+            // entry's last launch (an event outlives its stream; no device-wide synchronisation, which would also be
+            // illegal while another stream is capturing). After that nothing uses the entry's counters or workspace.
+            // Events are only recorded once all entries are taken (rings_full), so that applications with few
+            // streams pay nothing; an entry last used before that is waited for with the device, once.
             ri = 0;
             for (int i = 1; i < dsdtm_ctx::MAX_STREAMS; ++i)
                 if (ctx->rings[i].last_use < ctx->rings[ri].last_use) ri = i;
-            HIP_TRY(ctx, hipDeviceSynchronize());
+            if (ctx->rings[ri].last_recorded) HIP_TRY(ctx, hipEventSynchronize(ctx->rings[ri].last));
+            else HIP_TRY(ctx, hipDeviceSynchronize());
+            ctx->rings[ri].last_recorded = false;
             ctx->rings[ri].stream = stream;
             ctx->rings[ri].seq = 0;
         }
@@ -342,6 +365,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         HIP_TRY(ctx, hipMemsetAsync(slot, 0, sparse_align_team_bytes(b->n_pairs), stream));
         if (g_team_drop_members) a.spin_limit = 1u << 12;      // the test's waits give up after ~4 k polls
         HIP_TRY(ctx, sparse_align_launch_team(a, k, stream, g_team_drop_members));
+        if (int rc = ring_mark_launch(ctx, ring, stream)) return rc;
         if (stream != ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->team_event, stream));
         ctx->team_any = true; ctx->team_last_stream = stream;
         return DSDTM_OK;
@@ -370,7 +394,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         }
     }
     HIP_TRY(ctx, sparse_align_launch(a, v, ctx->num_cus, stream));
-    return DSDTM_OK;
+    return ring_mark_launch(ctx, ring, stream);
 }
 
 // Result check for callers of the asynchronous batch entry point: waits for `hip_stream`, then reads (and clears)
@@ -385,6 +409,9 @@ extern "C" int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream) {
     unsigned flag = 0;
     HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_timeout_flag, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) {
+        // the rare path: launches of this context may still be in flight on other streams (each owns live counter
+        // words), and the flag is device-global — wait for the whole device before anything is reset
+        (void)hipDeviceSynchronize();
         (void)sparse_align_clear_timeout_flag();
         (void)hipMemset(ctx->d_counter, 0, sizeof(unsigned) * (dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + dsdtm_ctx::GRAPH_COUNTERS));
         set_err(ctx, "sparse-align kernel: a hand-over wait timed out (results since the last check are invalid)");

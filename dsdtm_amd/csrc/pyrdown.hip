@@ -101,14 +101,18 @@ __device__ __forceinline__ uint32_t pd_pack(u16x2 oA, u16x2 oB) {
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, oB), __builtin_bit_cast(uint32_t, oA), 0x06040200u);
 }
 
-// 16 bytes of a source row: from HBM as one global_load_dwordx4 (4-byte aligned), from LDS as two ds_read_b64 (strip
-// bases are multiples of 8). The 4th dword of the right-border strip starts at the row end: in HBM it lies inside
-// the pyramid (a source level is never the last level), in LDS inside the band buffer's padding; it is not used.
+// 16 bytes of a source row: from HBM as one global_load_dwordx4, from LDS as two 8-byte reads. Strip bases are only
+// 4-byte aligned (2 * x4 - 4 is 4 mod 8 for every strip but the left one), so the LDS reads go through a type that
+// says so: the compiler may still pick ds_read_b64 where the hardware's unaligned DS access allows it, or two
+// ds_read2_b32, but never assumes an 8-byte alignment that does not hold. The 4th dword of the right-border strip
+// starts at the row end: in HBM it lies inside the pyramid (a source level is never the last level), in LDS inside
+// the band buffer's padding; it is not used.
+struct __attribute__((packed, aligned(4))) PdU32x2 { uint32_t x, y; };
 template <bool SRC_LDS>
 __device__ __forceinline__ uint4 pd_load16(const uint8_t* __restrict__ p) {
     if constexpr (SRC_LDS) {
-        const uint2* __restrict__ q = (const uint2*)p;
-        const uint2 a = q[0], b = q[1];
+        const PdU32x2* __restrict__ q = (const PdU32x2*)p;
+        const PdU32x2 a = q[0], b = q[1];
         return make_uint4(a.x, a.y, b.x, b.y);
     } else {
         const uint32_t* __restrict__ p32 = (const uint32_t*)p;
