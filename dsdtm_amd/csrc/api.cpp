@@ -93,7 +93,6 @@ const OptionKey kOptionKeys[] = {
     {"no_zero_copy", "DSDTM_NO_ZERO_COPY", &dsdtm::Options::no_zero_copy, true},
     {"po_no_cache", "DSDTM_PO_NO_CACHE", &dsdtm::Options::po_no_cache, true},
     {"a2d_tree", "DSDTM_A2D_TREE", &dsdtm::Options::a2d_tree, true},
-    {"reg_slots", "DSDTM_REG_SLOTS", &dsdtm::Options::reg_slots, false},
 };
 std::once_flag g_options_once;
 void options_from_env() {

@@ -52,7 +52,6 @@ struct Options {
     int no_zero_copy = 0;      // DSDTM_NO_ZERO_COPY: single-call entry points copy instead of mapping the pinned block
     int po_no_cache = 0;       // DSDTM_PO_NO_CACHE: pose refinement without features in registers
     int a2d_tree = 0;          // DSDTM_A2D_TREE: Align2D with DPP tree sums (cost comparison only; not bit-identical)
-    int reg_slots = 2;         // DSDTM_REG_SLOTS: pair slots per compute unit of the <= 320-feature kernel (2 | 3)
 };
 Options& options();
 

@@ -1325,531 +1325,6 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// THREE pair slots per compute unit (Options::reg_slots = 3; <= 320 features). 16 waves = 4 per SIMD at <= 128
-// VGPRs: 3 slots x 5 patch waves + one HELPER wave. At 128 VGPRs the 6x6 reference grid (64 VGPRs) cannot live in
-// registers: a slot keeps the INPUT of the grid — the 7x7 u8 footprint, 14 dwords per patch — in LDS and every
-// pass rebuilds the grid rows it needs, streaming (three grid rows live at a time). The values are the same bits:
-// the grid is exact (see PatchRegs), and the per-pixel arithmetic of the pass is residual_patch's, in its order.
-// Bytes reach the arithmetic as ds_read_u8 + v_cvt_f64_u32: one VALU instruction per byte (the register kernel's
-// unpacking of packed dwords costs two), for the footprint and for the current-image window alike.
-// No solver wave: 3 x 6 waves do not fit. A slot's LAST patch wave (44 of its 64 lanes carry patches) is its LEAD:
-// it runs the pair prologue, solver_step and the epilogue, in program order with its passes. What the dedicated
-// solver wave of the two-slot kernel does off the critical path goes to the helper wave, which serves the three
-// slots from LDS job words: the speculative H^+ of a level (while the first pass runs), solver_commit (quaternion
-// state, statistics) behind the hand-over, and the staging of a slot's next pair.
-// ---------------------------------------------------------------------------------------------
-constexpr int R3_NPW = 5, R3_NS = 3, R3_NL = R3_NPW * 64, R3_NP = R3_NPW * 4;
-struct R3Slot {
-    SolverCarry carry;          // lead -> helper: the step solver_commit finishes
-    int carry_pair;
-    unsigned commit_req, commit_done;
-    unsigned hinv_ready;        // levels of this slot whose all-visible H^+ the helper has parked in BlockState::Hinv
-    unsigned prep_req, prep_done;
-    int prep_pair;
-    unsigned done;              // the slot's lead has left the pair loop
-};
-struct R3Smem {                 // hot, small structures first (ds immediate offsets), per-patch planes behind them
-    BlockState st[R3_NS];
-    R3Slot hx[R3_NS];
-    WavePartial part[R3_NS][R3_NP];
-    uint32_t sink[64];
-    double park[R3_NS][4 * 64];                    // the lead wave's patch state while it solves
-    uint8_t win[R3_NS][WIN_ROWS * 9 * R3_NL];      // current-image windows as byte planes, [row * 9 + column][lane]
-    uint32_t rows[R3_NS][14 * R3_NL];              // reference footprints: plane r = bytes 0..3 of row r, plane 7 + r = bytes 4..6
-};
-static_assert(sizeof(R3Smem) <= 160 * 1024, "LDS of one compute unit");
-typedef __attribute__((address_space(3))) uint8_t LdsU8;
-typedef __attribute__((address_space(3))) R3Slot LdsR3Slot;
-
-// Bytes of the parked planes are read one ds_read_u8 each (volatile: merged into dword reads they would have to be
-// extracted on the VALU again) and always ONE ROW AHEAD of the arithmetic that consumes them, so that the LDS latency
-// of a row hides under the previous row's ~80 FP64 instructions.
-typedef volatile __attribute__((address_space(3))) uint8_t LdsU8v;
-__device__ __forceinline__ uint32_t lds_u8(const LdsU8* p, int off) { return (uint32_t)((const LdsU8v*)p)[off]; }
-// raw bytes C0 .. C0+N-1 of footprint row r (byte (r, c) = byte c & 3 of plane r for c < 4, of plane 7 + r beyond)
-template <int NL, int C0, int N>
-__device__ __forceinline__ void fp_row_issue(const LdsU8* col, int r, uint32_t* raw) {
-#pragma unroll
-    for (int c = C0; c < C0 + N; ++c) raw[c] = lds_u8(col, (c < 4 ? r : 7 + r) * NL * 4 + (c & 3));
-}
-template <int C0, int N>
-__device__ __forceinline__ void fp_row_cvt(const uint32_t* raw, double* d) {
-#pragma unroll
-    for (int c = C0; c < C0 + N; ++c) d[c] = (double)raw[c];
-}
-// Grid row R (g[R][C0 .. C0+N-1]) from footprint rows R (top) and R + 1 (bot), both given as doubles of columns 0..6
-template <int C0, int N>
-__device__ __forceinline__ void grid_row(const double* top, const double* bot, double w00, double w01, double w10, double w11, double* out) {
-#pragma unroll
-    for (int c = 0; c < N; ++c)
-        out[c] = w00 * top[C0 + c] + w01 * top[C0 + c + 1] + w10 * bot[C0 + c] + w11 * bot[C0 + c + 1];
-}
-// Streams the 6x6 grid of one patch from its parked footprint: calls f(i, gu, gc, gd) for the patch rows i = 0..3 with
-//   gu[k] = g[i][k+1] (k = 0..3), gc[c] = g[i+1][c] (c = 0..5), gd[k] = g[i+2][k+1] (k = 0..3)
-// i.e. what pixel (i, k) needs: centre gc[k+1], x neighbours gc[k], gc[k+2], y neighbours gu[k], gd[k]. pre(i) is
-// called before the arithmetic of row i (pre(-1) before anything) for the caller's own loads of the row after.
-template <int NL, typename Pre, typename Fn>
-__device__ __forceinline__ void stream_grid(const LdsU8* col, double w00, double w01, double w10, double w11, Pre&& pre, Fn&& f) {
-    // Footprint rows wait as RAW bytes (one VGPR each) and are converted where they are consumed — a row is converted
-    // twice, as the lower and as the upper row of a grid row: 35 more conversions per patch for 14 fewer live VGPRs
-    // (at 128 VGPRs per wave the pass has no room for both rows as doubles beside the three grid rows).
-    double t[7], b[7];
-    double gu[4], gc[6], gn[6];
-    uint32_t rw[3][7];                                        // raw rows: [r % 3]
-    fp_row_issue<NL, 1, 5>(col, 0, rw[0]);
-    fp_row_issue<NL, 0, 7>(col, 1, rw[1]);
-    fp_row_issue<NL, 0, 7>(col, 2, rw[2]);
-    pre(-1);
-    t[0] = 0.0; t[6] = 0.0;                                   // corners of the grid are never used
-    fp_row_cvt<1, 5>(rw[0], t);
-    fp_row_cvt<0, 7>(rw[1], b);
-    grid_row<1, 4>(t, b, w00, w01, w10, w11, gu);             // g[0][1..4]
-    fp_row_issue<NL, 0, 7>(col, 3, rw[0]);                    // row 3 (row 0 is consumed)
-    fp_row_cvt<0, 7>(rw[2], t);
-    grid_row<0, 6>(b, t, w00, w01, w10, w11, gc);             // g[1][0..5] from rows 1 (b), 2 (t)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        // grid row i + 2 from footprint rows i + 2 (raw in rw[(i + 2) % 3]) and i + 3 (raw in rw[(i + 3) % 3] = rw[i % 3]);
-        // the row after (i + 4) is requested first, into the buffer of row i + 1, which nobody needs any more
-        if (i < 2) fp_row_issue<NL, 0, 7>(col, i + 4, rw[(i + 1) % 3]);
-        else if (i == 2) fp_row_issue<NL, 1, 5>(col, 6, rw[(i + 1) % 3]);
-        pre(i);
-        fp_row_cvt<0, 7>(rw[(i + 2) % 3], t);
-        if (i < 3) {
-            fp_row_cvt<0, 7>(rw[i % 3], b);
-            grid_row<0, 6>(t, b, w00, w01, w10, w11, gn);     // g[i+2][0..5]
-        } else {
-            b[0] = 0.0; b[6] = 0.0;
-            fp_row_cvt<1, 5>(rw[i % 3], b);
-            grid_row<1, 4>(t, b, w00, w01, w10, w11, gn + 1); // g[5][1..4]
-        }
-        f(i, gu, gc, gn + 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gu[k] = gc[k + 1];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) gc[c] = gn[c];
-        __builtin_amdgcn_sched_barrier(0);                    // one patch row at a time: short live ranges
-    }
-}
-
-// the three gradient sums of patch_hess_factors from the parked footprint (same differences, same order)
-template <int NL>
-__device__ __forceinline__ void hess_sums_stream(const LdsU8* col, double w00, double w01, double w10, double w11,
-                                                 double& sxx, double& sxy, double& syy) {
-    double axx = 0.0, axy = 0.0, ayy = 0.0;
-    stream_grid<NL>(col, w00, w01, w10, w11, [](int) {}, [&](int, const double* gu, const double* gc, const double* gd) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double dx = gc[k + 2] - gc[k];
-            const double dy = gd[k] - gu[k];
-            axx += dx * dx; axy += dx * dy; ayy += dy * dy;
-        }
-    });
-    sxx = axx; sxy = axy; syy = ayy;
-}
-
-// Row partials of the H block of this lane's patch from its parked footprint. Out of line: it runs once per level (and
-// when the visible set changes), and its temporaries stay out of the register allocation of the pass.
-template <int NL>
-__device__ __attribute__((noinline)) void r3_hess_rows(const LdsU8* col, float px, float py, int level, const double* Xn, bool valid,
-                                                       bool use, double fs, int lane, LdsWavePartial* part) {
-    const double scale = (double)(1.0f / (float)(1 << level));
-    const double pxl = (double)px * scale, pyl = (double)py * scale;
-    const double su = pxl - floor(pxl), sv = pyl - floor(pyl);
-    const double omx = 1.0 - su, omy = 1.0 - sv;
-    double sxx, sxy, syy;
-    hess_sums_stream<NL>(col, omx * omy, su * omy, omx * sv, su * sv, sxx, sxy, syy);
-    const double Xh[3] = {valid ? Xn[0] : 0.0, valid ? Xn[1] : 0.0, valid ? Xn[2] : 1.0};   // finite A, B for lanes without a patch
-    const PatchHess ph = patch_hess_from_sums(sxx, sxy, syy, Xh, fs, use);
-    patch_hess_rows(ph, use, lane, (__attribute__((address_space(3))) double*)part->H);
-}
-
-// A window fill parked as BYTE planes: plane r * 9 + j holds column u_i - 3 + j (j = 0..8) of window row r, one byte per
-// lane (`win` points at this lane's byte of plane 0, planes are NL bytes apart). Written once per level and lane
-// (and on the rare refill); read one byte at a time by the pass.
-template <int NL>
-__device__ __forceinline__ void window_commit_bytes(const SAKernelArgs& a, const LevelGeom& lg, const WinFill& f, LdsU8* win, uint32_t& worg) {
-    constexpr int HR = (WIN_ROWS - 1) / 2;
-    const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
-#pragma unroll
-    for (int r = 0; r < WIN_ROWS; ++r) {
-        const uint32_t o = lg.off + (uint32_t)(f.v_i - HR + r) * (uint32_t)lg.stride + (uint32_t)(f.u_i - 3);
-        const bool in = min(o >> 2, last_dw - 2u) == (o >> 2);
-        const uint32_t d0 = in ? f.w[r].a : f.w[r].b, d1 = in ? f.w[r].b : f.w[r].c, d2 = in ? f.w[r].c : 0u;
-        const uint32_t sh = (o & 3u) * 8u;
-        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh), top = d2 >> sh;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) win[(r * 9 + j) * NL] = (uint8_t)(lo >> (8 * j));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) win[(r * 9 + 4 + j) * NL] = (uint8_t)(hi >> (8 * j));
-        win[(r * 9 + 8) * NL] = (uint8_t)top;
-    }
-    worg = (uint32_t)f.u_i | ((uint32_t)f.v_i << 16);
-}
-
-// ComputeResiduals for one patch whose reference footprint is parked in LDS: residual_patch with the grid rebuilt
-// on the fly. Same projection, same window logic, same per-pixel expressions and accumulation order.
-template <int NL>
-__device__ __forceinline__ bool residual_patch_stream(const SAKernelArgs& a, const LevelGeom& lg, double scale, double fs,
-                                                      const uint8_t* __restrict__ cur_base, const double* Xn, bool valid,
-                                                      float px, float py, const LdsU8* col,
-                                                      const double* __restrict__ sR, const double* __restrict__ st,
-                                                      double& chi2, double* b, LdsU8* win, uint32_t* worg) {
-    chi2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = 0.0;
-    double u, v;
-    if (!(project_patch(a, lg, scale, Xn, sR, st, u, v) & valid)) return false;
-    const double fu_d = floor(u), fv_d = floor(v);
-    const int u_i = (int)fu_d, v_i = (int)fv_d;
-    const double su = u - fu_d, sv = v - fv_d;
-    const double tl = (1.0 - su) * (1.0 - sv);
-    const double trw = su * (1.0 - sv);
-    const double bl = (1.0 - su) * sv;
-    const double br = su * sv;
-    int u0 = (int)(*worg & 0xffffu), v0 = (int)(*worg >> 16);
-    const bool covered = (unsigned)(u_i - u0 + 1) <= 4u && v_i == v0;
-    if (!covered) {
-        WinFill f;
-        window_issue(a, lg, cur_base, u_i, v_i, f);
-        window_commit_bytes<NL>(a, lg, f, win, *worg);
-        u0 = u_i;
-    }
-    // byte planes: column u_i - 2 + k of window row r is plane r * 9 + p + k, p = u_i - u0 + 1 — ONE address register,
-    // everything else is an immediate offset
-    const LdsU8* const wb = win + (uint32_t)(u_i - u0 + 1) * (uint32_t)NL;
-    uint32_t rc[3][5];                                        // raw window rows: [r % 3]
-    double c2a = 0.0, c2b = 0.0, gxa = 0.0, gxb = 0.0, gya = 0.0, gyb = 0.0;
-    // the reference-side bilinear weights again (ref_geom's arithmetic: a level constant that costs ten instructions
-    // per pass and would cost eight registers for the whole level)
-    const double pxl = (double)px * scale, pyl = (double)py * scale;
-    const double rsu = pxl - floor(pxl), rsv = pyl - floor(pyl);
-    const double omx = 1.0 - rsu, omy = 1.0 - rsv;
-    stream_grid<NL>(col, omx * omy, rsu * omy, omx * rsv, rsu * rsv, [&](int i) {
-        if (i < 0) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) rc[0][k] = lds_u8(wb, k * NL);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) rc[1][k] = lds_u8(wb, (9 + k) * NL);
-        } else if (i < 3) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) rc[(i + 2) % 3][k] = lds_u8(wb, ((i + 2) * 9 + k) * NL);
-        }
-    }, [&](int i, const double* gu, const double* gc, const double* gd) {
-        // window rows i (top) and i + 1 (bot), converted column by column as the pixel loop slides over them
-        double t0 = (double)rc[i % 3][0], b0 = (double)rc[(i + 1) % 3][0];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double t1 = (double)rc[i % 3][k + 1], b1 = (double)rc[(i + 1) % 3][k + 1];
-            const double cur = tl * t0 + trw * t1 + bl * b0 + br * b1;                       // :281
-            const double res = cur - gc[k + 1];                                              // :282
-            const double ddx = gc[k + 2] - gc[k];                                            // 2*dx (:150)
-            const double ddy = gd[k] - gu[k];                                                // 2*dy (:155)
-            if (k & 1) { c2b += res * res; gxb += ddx * res; gyb += ddy * res; }
-            else       { c2a += res * res; gxa += ddx * res; gya += ddy * res; }
-            t0 = t1; b0 = b1;
-        }
-    });
-    chi2 = c2a + c2b;
-    const double fsh = 0.5 * fs;
-    const double gX = (gxa + gxb) * fsh, gY = (gya + gyb) * fsh;
-    const double xn = Xn[0], yn = Xn[1], zi = Xn[2];
-    const double sxy = xn * gX + yn * gY;
-    b[0] = -(zi * gX);
-    b[1] = -(zi * gY);
-    b[2] = zi * sxy;
-    b[3] = yn * sxy + gY;
-    b[4] = -(xn * sxy + gX);
-    b[5] = yn * gX - xn * gY;
-    return true;
-}
-
-// bounded wait for a helper job word (monotonic counter reaching `target`)
-__device__ __forceinline__ void r3_wait_word(unsigned* word, unsigned target) {
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0 && ++spins < SPIN_LIMIT)
-        __builtin_amdgcn_s_sleep(1);
-    if (spins >= SPIN_LIMIT) spin_timeout();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void r3_post_word(unsigned* word, unsigned value, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// the helper wave: serves the three slots until every lead has left. (Inlined into the kernel: a function that takes
-// the kernel arguments by reference makes the compiler copy them to scratch memory, after which every pointer in
-// them is a flat pointer of unknown address space — the gathers of ALL waves turn into flat loads.)
-__device__ __forceinline__ void r3_helper(const SAKernelArgs& a, R3Smem& sm, int lane) {
-    unsigned commits[R3_NS] = {0, 0, 0}, levels[R3_NS] = {0, 0, 0}, preps[R3_NS] = {0, 0, 0};
-    unsigned idle = 0;
-    __builtin_amdgcn_s_setprio(1);
-    while (true) {
-        bool did = false;
-        int ndone = 0;
-#pragma unroll
-        for (int sl = 0; sl < R3_NS; ++sl) {
-            BlockState& s = sm.st[sl];
-            R3Slot& hx = sm.hx[sl];
-            // (1) the step behind the hand-over: quaternion state, chi2, statistics
-            if (__hip_atomic_load(&hx.commit_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != commits[sl]) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                SolverCarry c = hx.carry;
-                solver_commit(a, hx.carry_pair, s, lane, c);
-                r3_post_word(&hx.commit_done, ++commits[sl], lane);
-                did = true;
-            }
-            // (2) the level's all-visible H^+, as soon as all patch waves have published their H partials (BH)
-            if ((int)(__hip_atomic_load(&s.arrive_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - (levels[sl] + 1u) * R3_NPW) >= 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                refresh_hinv_to_lds<R3_NP>((const LdsWavePartial*)sm.part[sl], (LdsBlockState*)&s, lane);
-                r3_post_word(&hx.hinv_ready, ++levels[sl], lane);
-                did = true;
-            }
-            // (3) the slot's next pair: pose block staged, feature lines pulled towards this CU
-            if (__hip_atomic_load(&hx.prep_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != preps[sl]) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const int np = __builtin_amdgcn_readfirstlane(hx.prep_pair);
-                const size_t nfm = (size_t)a.max_features;
-                prepare_next(a.T_ref_w + 12 * (size_t)np, a.T_cur_w + 12 * (size_t)np, a.px_xy + 2 * np * nfm,
-                             a.bearing + 3 * np * nfm, a.p_world + 3 * np * nfm, a.initial + np * nfm,
-                             a.max_features, np, (LdsBlockState*)&s, (LdsVoid*)sm.sink, lane);
-                r3_post_word(&hx.prep_done, ++preps[sl], lane);
-                did = true;
-            }
-            ndone += __hip_atomic_load(&hx.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
-        }
-        if (did) { idle = 0; continue; }
-        if (ndone == R3_NS) break;
-        if (++idle >= SPIN_LIMIT) { spin_timeout(); break; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// STAMPS: diagnostic instantiation (dsdtm_debug_sparse_align_stamps with Options::reg_slots = 3): 16 cycle counters per
-// pair in a.workspace — lead wave [0..7]: pair total, own passes, wait for the slot's arrivals, wait for the helper,
-// solves, level starts, iterations, prologue; wave 0 [8..10]: passes, wait for the lead, level starts.
-template <bool STAMPS>
-__global__ __launch_bounds__(1024) void sparse_align_reg3_kernel(const SAKernelArgs a) {
-    constexpr int NPW = R3_NPW, NL = R3_NL, NP = R3_NP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char r3_lds[];
-    R3Smem& sm = *(R3Smem*)r3_lds;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int gwave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < R3_NS) {
-        BlockState& z = sm.st[tid];
-        z.arrive = 0u; z.arrive_h = 0u; z.seq = 0u; z.ack = 0u; z.nx_pair = -1;
-        R3Slot& h = sm.hx[tid];
-        h.commit_req = 0u; h.commit_done = 0u; h.hinv_ready = 0u; h.prep_req = 0u; h.prep_done = 0u; h.done = 0u;
-    }
-    __syncthreads();                                                   // the only workgroup barrier
-    if (gwave == R3_NS * NPW) { r3_helper(a, sm, lane); return; }
-    const int slot = gwave / NPW;
-    const int wave = gwave - slot * NPW;
-    const int ltid = tid - slot * NL;
-    const bool lead = wave == NPW - 1;
-    WavePartial* s_part = sm.part[slot];
-    BlockState& s = sm.st[slot];
-    R3Slot& hx = sm.hx[slot];
-    const int row = lane >> 4;
-    const bool row_writer = (lane & 15) == 15;
-    WavePartial& my_part = s_part[wave * 4 + row];
-    LdsU8* const win = (LdsU8*)&sm.win[slot][ltid];
-    LdsU32* const rows32 = (LdsU32*)&sm.rows[slot][ltid];
-    const LdsU8* const col = (const LdsU8*)rows32;
-
-    // lead-only bookkeeping (wave-uniform)
-    unsigned seen = 0, published = 0, expected = 0, acks = 0, commits = 0, levels_seen = 0, preps = 0;
-    const int first_dynamic = (int)gridDim.x * R3_NS;
-    int pair = (int)blockIdx.x * R3_NS + slot;
-    int next_raw = 0;
-    while (true) {
-        if (lead) {
-            pair_wait_arrive(&s.ack, acks);                            // the other patch waves are done with the previous pair
-            r3_wait_word(&hx.prep_done, preps);                        // a staging in flight has landed
-            const bool have = pair < a.n_pairs;
-            const int nfp = have ? (a.n_features ? a.n_features[pair] : a.max_features) : 0;
-            const bool run = have && nfp >= a.min_fts && a.max_level - 1 >= a.min_level;
-            const bool staged = have && __builtin_amdgcn_readfirstlane(s.nx_pair) == pair;
-            if (lane == 0) { s.pair = pair; s.run = run ? 1 : 0; s.nx_pair = -1; }
-            if (!have) {
-                pair_publish(s, ++published, lane);                    // B0 with "no more work"
-                r3_post_word(&hx.done, 1u, lane);
-                break;
-            }
-            acks += NPW - 1;
-            if (!run) {
-                if (lane == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
-                pair_publish(s, ++published, lane);                    // B0 with "skip"
-                int v = 0;
-                if (lane == 0) v = first_dynamic + (int)atomicAdd(a.pair_counter, 1u);
-                v = __builtin_amdgcn_readfirstlane(v);
-                if (lane == 0 && v - first_dynamic == a.n_pairs - 1)
-                    __hip_atomic_store(a.pair_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pair = v;
-                continue;
-            }
-            next_raw = 0;
-            if (lane == 0) next_raw = first_dynamic + (int)atomicAdd(a.pair_counter, 1u);   // latency hidden under this pair
-            if (staged) commit_next(*(LdsBlockState*)&s, lane);
-            else solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
-            if (lane == 0) stats_clear(a, pair);
-            pair_publish(s, ++published, lane);                        // B0
-        } else {
-            pair_wait_seq(s, ++seen);                                  // B0 of the slot's next pair
-            pair = __builtin_amdgcn_readfirstlane(s.pair);
-            if (pair >= a.n_pairs) break;
-            if (!s.run) { pair_signal_arrive(&s.ack, lane); continue; }
-        }
-        const int nf = a.n_features ? a.n_features[pair] : a.max_features;
-        const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
-        const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
-        unsigned long long z_pass = 0, z_arr = 0, z_help = 0, z_solve = 0, z_lvl = 0, z_it = 0, z_begin = 0;
-        if (STAMPS) z_begin = __builtin_amdgcn_s_memtime();
-        FeatureRegs F;
-        {
-            const FeatureRaw fraw = load_feature_raw(a, (size_t)pair * a.max_features + ltid, ltid < nf);
-            const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
-            F = make_feature(fraw, Cref);
-        }
-        bool prepared = false;
-        for (int level = a.max_level - 1; level >= a.min_level; --level) {
-            const LevelGeom lg = a.lv[level];
-            const double scale = (double)(1.0f / (float)(1 << level));
-            const double fs = (double)a.f * scale;
-            if (lead) {
-                r3_wait_word(&hx.commit_done, commits);                // the previous level's last step is in the state
-                if (lane == 0) {                                       // GaussNewtonSolver entry (:304-308)
-                    s.chi2 = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s.qo[i] = s.u.q[i];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) s.to[i] = s.u.t[i];
-                }
-            }
-            // level start: footprint rows -> LDS, all-visible H partial of the row
-            unsigned long long zl0 = 0;
-            if (STAMPS) zl0 = __builtin_amdgcn_s_memtime();
-            const RefGeom g = ref_geom(F, lg, level);
-            {
-                uint32_t rlo[7], rhi[7];
-                {
-                    U32x3 w[7];
-                    ref_rows_issue(a, lg, ref_base, g, w);
-                    ref_rows_unpack(a, lg, g, w, rlo, rhi);
-                }
-#pragma unroll
-                for (int r = 0; r < 7; ++r) { rows32[r * NL] = rlo[r]; rows32[(7 + r) * NL] = rhi[r]; }
-            }
-            const bool valid = g.valid;
-            uint32_t worg = WIN_EMPTY;
-            const unsigned long long valid_mask = __ballot(valid);
-            const int n_ref_row = __popc((unsigned)(valid_mask >> (16 * row)) & 0xffffu);
-            unsigned long long cached_mask = valid_mask;
-            r3_hess_rows<NL>(col, F.px, F.py, level, F.X, valid, valid, fs, lane, (LdsWavePartial*)&my_part);
-            pair_signal_arrive(&s.arrive_h, lane);                     // BH (the helper sums + inverts meanwhile)
-            if (STAMPS) z_lvl += __builtin_amdgcn_s_memtime() - zl0;
-            for (int it = 0; it < a.max_iters; ++it) {
-                double chi2, b[6];
-                unsigned long long zp0 = 0, zp1 = 0, zp2 = 0, zp3 = 0;
-                if (STAMPS) zp0 = __builtin_amdgcn_s_memtime();
-                asm volatile("" ::: "memory");                         // the parked bytes are re-read every pass, not hoisted
-                const bool vis = residual_patch_stream<NL>(a, lg, scale, fs, cur_base, F.X, valid, F.px, F.py, col,
-                                                           s.u.R, s.u.tt, chi2, b, win, &worg);
-                const unsigned long long vmask = __ballot(vis);
-                {
-                    const double v8[8] = {b[0], b[1], b[2], b[3], b[4], b[5], chi2, 0.0};
-                    const double t = row_reduce8(v8, lane);
-                    const int q = row_reduce8_index(lane);
-                    if (!(lane & 4) && q < 7) ((double*)&my_part)[q] = t;
-                }
-                if (row_writer) {
-                    my_part.cnt = __popc((unsigned)(vmask >> (16 * row)) & 0xffffu);
-                    my_part.n_ref = n_ref_row;
-                }
-                const bool h_changed = (vmask != cached_mask);        // wave-uniform, rare
-                if (h_changed) {
-                    r3_hess_rows<NL>(col, F.px, F.py, level, F.X, valid, vis, fs, lane, (LdsWavePartial*)&my_part);
-                    cached_mask = vmask;
-                }
-                if (row_writer) my_part.h_changed = h_changed ? 1 : 0;
-                pair_signal_arrive(&s.arrive, lane);                   // B1
-                if (STAMPS) { zp1 = __builtin_amdgcn_s_memtime(); z_pass += zp1 - zp0; z_it += 1; }
-                int ctrl;
-                if (lead) {
-                    expected += NPW;
-                    pair_wait_arrive(&s.arrive, expected);
-                    if (STAMPS) { zp2 = __builtin_amdgcn_s_memtime(); z_arr += zp2 - zp1; }
-                    if (it == 0) r3_wait_word(&hx.hinv_ready, ++levels_seen);
-                    r3_wait_word(&hx.commit_done, commits);
-                    if (STAMPS) { zp3 = __builtin_amdgcn_s_memtime(); z_help += zp3 - zp2; }
-                    __builtin_amdgcn_s_setprio(2);
-                    // the lead's own patch state goes through LDS around the solve (a live-range split by hand: the
-                    // solver code then has the whole register budget, and nothing is spilled to scratch memory)
-                    {
-                        __attribute__((address_space(3))) double* pk = (__attribute__((address_space(3))) double*)sm.park[slot] + lane;
-                        pk[0] = F.X[0]; pk[64] = F.X[1]; pk[128] = F.X[2];
-                        pk[192] = __hiloint2double(__float_as_int(F.py), __float_as_int(F.px));
-                    }
-                    double hrow[6];
-                    const int li = lane < 6 ? lane : 5;
-#pragma unroll
-                    for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];
-                    SolverCarry carry;
-                    ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hrow, carry);
-                    pair_publish(s, ++published, lane);                // B2
-                    __builtin_amdgcn_s_setprio(0);
-                    if (STAMPS) z_solve += __builtin_amdgcn_s_memtime() - zp3;
-                    if (lane == 0) { *(SolverCarry*)&hx.carry = carry; hx.carry_pair = pair; }
-                    r3_post_word(&hx.commit_req, ++commits, lane);
-                    {
-                        const __attribute__((address_space(3))) double* pk = (const __attribute__((address_space(3))) double*)sm.park[slot] + lane;
-                        F.X[0] = pk[0]; F.X[1] = pk[64]; F.X[2] = pk[128];
-                        const double pp = pk[192];
-                        F.px = __int_as_float(__double2loint(pp)); F.py = __int_as_float(__double2hiint(pp));
-                    }
-                    if (!ctrl && !prepared && level < a.max_level - 1) {
-                        prepared = true;
-                        const int np = __builtin_amdgcn_readfirstlane(next_raw);
-                        if (np < a.n_pairs) {
-                            if (lane == 0) hx.prep_pair = np;
-                            r3_post_word(&hx.prep_req, ++preps, lane);
-                        }
-                    }
-                } else {
-                    ++seen;
-                    pair_wait_seq(s, seen);                            // B2
-                    ctrl = s.ctrl;
-                    if (STAMPS) z_arr += __builtin_amdgcn_s_memtime() - zp1;
-                }
-                if (ctrl) break;
-            }
-        }
-        if (lead) {
-            r3_wait_word(&hx.commit_done, commits);
-            solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
-            report_timeout(a, lane);
-            if (STAMPS && lane == 0 && a.workspace) {
-                unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 16;
-                o[0] = __builtin_amdgcn_s_memtime() - z_begin; o[1] = z_pass; o[2] = z_arr; o[3] = z_help; o[4] = z_solve; o[5] = z_lvl; o[6] = z_it;
-            }
-            const int v = __builtin_amdgcn_readfirstlane(next_raw);
-            if (lane == 0 && v - first_dynamic == a.n_pairs - 1)
-                __hip_atomic_store(a.pair_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pair = v;
-        } else {
-            pair_signal_arrive(&s.ack, lane);                          // done with this pair's shared state
-            if (STAMPS && wave == 0 && lane == 0 && a.workspace) {
-                unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 16;
-                o[8] = z_pass; o[9] = z_arr; o[10] = z_lvl;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Generic kernel for any feature count: each lane of the NPW patch waves loops over patches
 // p = tid, tid + NPW*64, ...; the per-patch state is parked in an HBM workspace laid out
 // [slot][patch] so that the lanes of a wave read consecutive doubles (coalesced 512-B rows).
@@ -2387,18 +1862,8 @@ static hipError_t launch_reg(const SAKernelArgs& args, int num_cus, hipStream_t 
     return hipGetLastError();
 }
 
-template <bool STAMPS>
-static hipError_t launch_reg3(const SAKernelArgs& args, int num_cus, hipStream_t stream) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_reg3_kernel<STAMPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)sizeof(R3Smem));
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(sparse_align_reg3_kernel<STAMPS>, dim3(persistent_grid(args.n_pairs, R3_NS, num_cus)), dim3(1024), sizeof(R3Smem), stream, args);
-    return hipGetLastError();
-}
-
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
-    if (options().reg_slots == 3) return launch_reg3<true>(args, num_cus, stream);
     return launch_reg<5, SA_PPW, true>(args, num_cus, stream);
 }
 
@@ -2408,9 +1873,7 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
         case SA_REG128: return launch_reg<2, 4, false>(args, num_cus, stream);
         case SA_REG192: return launch_reg<3, 3, false>(args, num_cus, stream);
         case SA_REG256: return launch_reg<4, 2, false>(args, num_cus, stream);
-        case SA_REG320:
-            if (options().reg_slots == 3 && args.max_features > 256) return launch_reg3<false>(args, num_cus, stream);
-            return launch_reg<5, SA_PPW, false>(args, num_cus, stream);
+        case SA_REG320: return launch_reg<5, SA_PPW, false>(args, num_cus, stream);
         case SA_REG448: return launch_reg<7, 1, false>(args, num_cus, stream);
         case SA_REG704: return launch_reg<11, 1, false>(args, num_cus, stream);
         case SA_WS: {
