@@ -86,7 +86,6 @@ const OptionKey kOptionKeys[] = {
     {"team_min", "DSDTM_TEAM_MIN", &dsdtm::Options::team_min, false},
     {"team_spread_min", "DSDTM_TEAM_SPREAD_MIN", &dsdtm::Options::team_spread_min, false},
     {"ws_from", "DSDTM_WS_FROM", &dsdtm::Options::ws_from, false},
-    {"ws_waves", "DSDTM_WS_WAVES", &dsdtm::Options::ws_waves, false},
     {"ws_no_windows", "DSDTM_WS_NO_WINDOWS", &dsdtm::Options::ws_no_windows, true},
     {"pyr_fused", "DSDTM_PYR_FUSED", &dsdtm::Options::pyr_fused, false},
     {"pyr_band", "DSDTM_PYR_BAND", &dsdtm::Options::pyr_band, false},

@@ -45,7 +45,6 @@ struct Options {
     int team_min = 449;        // DSDTM_TEAM_MIN: feature count from which few large pairs run as teams
     int team_spread_min = 33;  // DSDTM_TEAM_SPREAD_MIN: team size from which members are spread over all XCDs
     int ws_from = 704;         // DSDTM_WS_FROM: feature counts above this run the workspace kernel in batches
-    int ws_waves = 0;          // DSDTM_WS_WAVES: 4 / 8 forces the workspace kernel's workgroup shape (0: by patch count)
     int ws_no_windows = 0;     // DSDTM_WS_NO_WINDOWS
     int pyr_fused = 1;         // DSDTM_PYR_FUSED: 0 never / 1 up to 32 images / 2 whenever the shape allows
     int pyr_band = 0;          // DSDTM_PYR_BAND: rows of the coarsest level per workgroup of the fused kernel (0: auto)

@@ -1335,8 +1335,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
 // grid_from_rows the register kernels run once per level (same inputs, same arithmetic: bit-identical values).
 // The first version parked the grid itself and was bound by exactly that traffic: 1024 pairs of 1000 patches moved
 // 8.7 GB per launch through HBM (rocprofv3 FETCH_SIZE/WRITE_SIZE, 9.7x the algorithmic bytes) at 6.2 TB/s.
-// The workgroup has no solver wave (a variant with 7 + 1 waves was measured: 1.5 % slower): 8 patch waves, or 4 when
-// two workgroups share a compute unit; the last patch wave also solves.
+// The workgroup has no solver wave (a variant with 7 + 1 waves was measured: 1.5 % slower): 8 patch waves, the last of
+// which also solves.
 constexpr int WS_NPW = 8;
 constexpr int WS_THREADS = WS_NPW * 64;
 constexpr int WS_DWORDS = 22;   // rlo[7], rhi[7], px, py, X[3] as dword pairs
@@ -1350,7 +1350,9 @@ struct WsPatch {
     FeatureRegs F;               // px, py, X; ok = the patch passed the reference-side checks of this level
 };
 
-__device__ __forceinline__ void ws_store(uint32_t* __restrict__ ws, size_t npad, int p, const WsPatch& w) {
+// WP = uint32_t* (HBM workspace, planes `npad` dwords apart) or an LDS-qualified pointer (planes WCAP dwords apart)
+template <typename WP>
+__device__ __forceinline__ void ws_store(WP ws, size_t npad, int p, const WsPatch& w) {
 #pragma unroll
     for (int r = 0; r < 7; ++r) { ws[(size_t)r * npad + p] = w.rlo[r]; ws[(size_t)(7 + r) * npad + p] = w.rhi[r]; }
     ws[(size_t)14 * npad + p] = __float_as_uint(w.F.px);
@@ -1364,14 +1366,21 @@ __device__ __forceinline__ void ws_store(uint32_t* __restrict__ ws, size_t npad,
     }
 }
 
-__device__ __forceinline__ void ws_load(const uint32_t* __restrict__ ws, size_t npad, int p, WsPatch& w) {
+// The HBM workspace is streamed: every parked dword is read exactly once per pass, by the thread that wrote it, and a
+// pass reads far more than the L2 keeps until the next one — non-temporal loads leave the cache to the footprint gathers.
+__device__ __forceinline__ uint32_t ws_word(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint32_t ws_word(const LdsU32* p) { return *p; }
+template <typename WP>
+__device__ __forceinline__ void ws_load(WP ws, size_t npad, int p, WsPatch& w) {
+    uint32_t d[WS_DWORDS];
 #pragma unroll
-    for (int r = 0; r < 7; ++r) { w.rlo[r] = ws[(size_t)r * npad + p]; w.rhi[r] = ws[(size_t)(7 + r) * npad + p]; }
-    w.F.px = __uint_as_float(ws[(size_t)14 * npad + p]);
-    w.F.py = __uint_as_float(ws[(size_t)15 * npad + p]);
+    for (int i = 0; i < WS_DWORDS; ++i) d[i] = ws_word(ws + (size_t)i * npad + p);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        w.F.X[i] = __hiloint2double((int)ws[(size_t)(17 + 2 * i) * npad + p], (int)ws[(size_t)(16 + 2 * i) * npad + p]);
+    for (int r = 0; r < 7; ++r) { w.rlo[r] = d[r]; w.rhi[r] = d[7 + r]; }
+    w.F.px = __uint_as_float(d[14]);
+    w.F.py = __uint_as_float(d[15]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w.F.X[i] = __hiloint2double((int)d[17 + 2 * i], (int)d[16 + 2 * i]);
     w.F.ok = (w.F.X[2] == w.F.X[2]);
 }
 
@@ -1391,8 +1400,11 @@ __device__ __forceinline__ void ws_patch_regs(const WsPatch& w, const LevelGeom&
 // rebuilt from the parked inputs every pass), so one wave can be both; at ~205 VGPRs a CU holds 8 waves, and 8 patch
 // waves instead of 7 + 1 turn the 1000 patches of BASELINE config 3 from three rounds of 448 lanes (the third 23 %
 // full) into two rounds of 512, and 2000 patches from five rounds into four.
-template <int NPW, int WCAP>
-__global__ __launch_bounds__(NPW * 64) __attribute__((amdgpu_waves_per_eu(NPW <= 4 ? 2 : 1, 2)))
+// PARK_LDS: the parked grid inputs (88 B per patch) live in LDS behind the windows instead of the HBM workspace —
+// up to 1024 patches (4 + 60 + 88 KB of dynamic LDS: one workgroup per compute unit), nothing of a pass touches HBM
+// but the pose; without it a pass streams them from the workspace (written once per level, re-read every pass).
+template <int NPW, int WCAP, bool PARK_LDS = false>
+__global__ __launch_bounds__(NPW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void sparse_align_ws_kernel(const SAKernelArgs a) {
     constexpr int PT = NPW * 64;   // patch threads
     constexpr int SW = NPW - 1;    // the wave that also solves
@@ -1420,7 +1432,11 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
     const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
     const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
     const size_t npad = ((size_t)a.max_features + 63) / 64 * 64;
-    uint32_t* __restrict__ ws = (uint32_t*)(a.workspace + (size_t)pair * ws_doubles_per_pair(a.max_features));
+    const size_t pstride = PARK_LDS ? (size_t)WCAP : npad;                        // dwords between two parked planes
+    auto ws = [&]() {
+        if constexpr (PARK_LDS) return (LdsU32*)(ws_win + 16 * WCAP);
+        else return (uint32_t*)(a.workspace + (size_t)pair * ws_doubles_per_pair(a.max_features));
+    }();
     __syncthreads();                                                   // B0
 
     for (int level = a.max_level - 1; level >= a.min_level; --level) {
@@ -1448,7 +1464,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                     ref_rows_unpack(a, lg, g, rows, w.rlo, w.rhi);
                 }
                 w.F.ok = g.valid;
-                ws_store(ws, npad, p, w);          // read back only by this same thread
+                ws_store(ws, pstride, p, w);          // read back only by this same thread
                 n_valid_lane += g.valid ? 1 : 0;
             }
         }
@@ -1468,7 +1484,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                 PatchRegs P;
                 {
                     WsPatch w;
-                    ws_load(ws, npad, p, w);
+                    ws_load(ws, pstride, p, w);
                     ws_patch_regs(w, lg, level, P);
                 }
                 double c2, bp[6];
@@ -1503,11 +1519,11 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                     if (maskable) {
                         if (!(vis_new & bit)) continue;
                         WsPatch w;
-                        ws_load(ws, npad, p, w);
+                        ws_load(ws, pstride, p, w);
                         ws_patch_regs(w, lg, level, P);
                     } else {                                           // more patches per lane than mask bits: project again
                         WsPatch w;
-                        ws_load(ws, npad, p, w);
+                        ws_load(ws, pstride, p, w);
                         ws_patch_regs(w, lg, level, P);
                         double u, v;
                         if (!P.valid || !project_patch(a, lg, scale, P.X, s.u.R, s.u.tt, u, v)) continue;
@@ -1826,6 +1842,7 @@ SAVariant sparse_align_pick_variant(int max_features) {
 
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
     if (sparse_align_pick_variant(max_features) != SA_WS) return 0;
+    if (!options().ws_no_windows && (max_features + 63) / 64 * 64 <= 1024) return 0;     // parked in LDS
     return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
 }
 
@@ -1879,21 +1896,19 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
         case SA_WS: {
             const int npad = (args.max_features + 63) / 64 * 64;
             const bool ws_windows = !options().ws_no_windows;
-            // Two workgroups of four waves per CU (two pairs in flight: one's gathers overlap the other's arithmetic,
-            // as the two slots of the register kernel do) when their windows fit side by side, else one of eight.
-            const int ws_waves = options().ws_waves;
             const dim3 grid((unsigned)args.n_pairs);
-            if (ws_windows && npad <= 1024 && ws_waves != 8) {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<4, 1024>), grid, dim3(256), 16 * 1024 * sizeof(uint32_t), stream, args);
-            } else if (ws_windows && npad <= 1024) {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024>), grid, dim3(WS_THREADS), 16 * 1024 * sizeof(uint32_t), stream, args);
-            } else if (ws_windows && npad <= 2048 && ws_waves != 4) {
+            if (ws_windows && npad <= 1024) {
+                // everything a pass needs in LDS: window origins + windows + parked grid inputs (4 + 60 + 88 KB)
+                constexpr size_t lds = (16 + WS_DWORDS) * 1024 * sizeof(uint32_t);
+                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 1024, true>,
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (attr != hipSuccess) return attr;
+                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024, true>), grid, dim3(WS_THREADS), lds, stream, args);
+            } else if (ws_windows && npad <= 2048) {
                 static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 2048>,
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * sizeof(uint32_t));
                 if (attr != hipSuccess) return attr;
                 hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 2048>), grid, dim3(WS_THREADS), 16 * 2048 * sizeof(uint32_t), stream, args);
-            } else if (ws_waves == 4) {
-                hipLaunchKernelGGL((sparse_align_ws_kernel<4, 0>), grid, dim3(256), 0, stream, args);
             } else {
                 hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 0>), grid, dim3(WS_THREADS), 0, stream, args);
             }
