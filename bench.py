@@ -44,17 +44,39 @@ def algorithmic_bytes(width, height, levels, n_patches):
     return 2 * pyr + n_patches * 57 + 292
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02_bench_pmc.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_bench_pmc.json")
+
+
+def library_sha():
+    """sha256 (first 16 hex digits) of the libdsdtm_amd.so this process loads: the counter summary under profiles/
+    carries the hash of the binary it was taken with, and its numbers are only reported for that binary."""
+    import hashlib
+    from dsdtm_amd import capi
+    try:
+        with open(capi.lib_path(), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def pmc_summary(path=PMC_SUMMARY):
+    """The committed counter summary, or {} when it is missing or describes another binary than the loaded one."""
+    try:
+        with open(os.path.join(ROOT, path)) as f:
+            d = json.load(f)
+    except Exception:
+        return {}
+    return d if d.get("profile_binary_sha") and d.get("profile_binary_sha") == library_sha() else {}
 
 
 def pmc_traffic(kernel_substr, algorithmic_bytes_per_launch, path=PMC_SUMMARY):
     """HBM bytes per launch of the kernel whose name contains `kernel_substr`, from the committed rocprofv3
     PMC passes (profiles/, separate --pmc runs of this same command, folded by tools/summarize_profile.py;
     bench.py cannot sample PMCs itself): FETCH_SIZE [KiB] x 1024 x 2 (gfx950 correction of the microarch
-    guide) + WRITE_SIZE [KiB] x 1024. None when the summary is missing or was taken for another launch size."""
+    guide) + WRITE_SIZE [KiB] x 1024. None when the summary is missing, was taken for another launch size, or
+    was taken with another build of the library than the one loaded now (profile_binary_sha)."""
     try:
-        with open(os.path.join(ROOT, path)) as f:
-            d = json.load(f)
+        d = pmc_summary(path)
         for t in d.get("hbm_traffic_per_launch", []):
             if kernel_substr in t["kernel"] and int(t["algorithmic_bytes_per_launch"]) == int(algorithmic_bytes_per_launch):
                 return float(t["fetch_bytes_gfx950_corrected"]) + float(t["write_bytes"])
@@ -70,8 +92,7 @@ def pmc_fp64_flops(kernel_substr, case="solo", path=PMC_SUMMARY):
     """FP64 flops per launch of the BASELINE workload (1024 pairs) from the committed SQ_INSTS_VALU_*_F64 pass
     (64 x (ADD + MUL + 2 FMA + TRANS) wave instructions; tools/profile.sh, tools/summarize_profile.py). None if absent."""
     try:
-        with open(os.path.join(ROOT, path)) as f:
-            d = json.load(f)
+        d = pmc_summary(path)
         for t in d.get("fp64_per_launch", []):
             if t["case"] == case and kernel_substr in t["kernel"]:
                 return float(t["fp64_flops_per_launch"])
@@ -310,8 +331,12 @@ def roofline_block(kernel, alg_bytes_per_launch, ms_avg, ms_min, units_per_launc
                          "[KiB] x 1024, separate --pmc passes of this command (" + PMC_SUMMARY + "); null when no "
                          "summary was committed for this launch size; algorithmic bytes per launch = "
                          + str(int(alg_bytes_per_launch)),
-         "kernel": kernel, "kernel_ms_avg": ms_avg, "kernel_ms_min": ms_min,
+         "kernel": kernel, "kernel_ms_avg": ms_avg,
          "algorithmic_bytes_per_" + unit_name: alg_bytes_per_unit, unit_name + "s_per_launch": units_per_launch}
+    if ms_min is not None:
+        r["kernel_ms_min"] = ms_min
+    if r["traffic"] is None:
+        r["traffic_note"] += "; no committed counter summary matches this launch size AND the loaded binary (sha " + str(library_sha()) + ")"
     if extra:
         r.update(extra)
     return r
@@ -394,7 +419,177 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
         "workload": f"Frame::ComputeImagePyramid: levels 1..{levels - 1} of {n_img} {width}x{height} pyramids per call",
         "value": n_img / (ms_avg * 1e-3), "unit": "pyramids/s",
         "roofline": roofline_block("pyrdown", n_img * b_pyr, ms_avg, ms_min, n_img, b_pyr, "pyramid")})
+    del pyr
+    torch.cuda.empty_cache()
+    out.append(streamed_entry(torch, dev, ctx, synth.Camera.tum(args.width, args.height), cam_struct_640, args))
     return out
+
+
+def streamed_entry(torch, dev, ctx, cam, cam_struct, args, n_frames=2049, chunk=128):
+    """The path fed from HOST memory (reference: src/Tracking.cpp:45-57 -> src/Frame.cpp:35-41,74-81 ->
+    src/Sprase_ImageAlign.cpp:29-60): a sequence of n_frames level-0 images and their feature columns in pinned host
+    memory -> H2D in chunks on copy streams -> dsdtm_pyrdown_batch_device -> dsdtm_sparse_align_batch_device on the
+    CHAINED batch (one device array of pyramids, cur_pyr = ref_pyr + pitch: frame k is `cur` of pair k - 1 and `ref`
+    of pair k, uploaded and built once). Upload of chunk j + 1 overlaps pyramid + alignment of chunk j (events, no
+    host synchronisation inside). Reported: frames/s end to end, the H2D rate against a bare hipMemcpyAsync of the same
+    bytes on this box, and the fraction of the transfer hidden behind it. PCIe-inclusive — never the headline value."""
+    import torch.nn.functional as F
+    from dsdtm_amd import capi, synth
+    from tests import oracle_lib
+    W, Hh, L, N = args.width, args.height, args.levels, args.patches
+    ws, hs, strides, offs, pyr_bytes = capi.pyramid_layout(W, Hh, L, 64)
+    pitch = (pyr_bytes + 255) // 256 * 256
+    P = n_frames - 1
+    rng = np.random.default_rng(0x5EC)
+    # camera path in front of a textured plane z = depth (world = frame 0); frames rendered on the GPU
+    depth = 2.0
+    # a smooth closed path around the start (the plane stays in view): per-frame motion <= ~0.02 m / ~0.01 rad
+    amp = np.array([0.15, 0.15, 0.08, 0.07, 0.07, 0.07])
+    frq = rng.uniform(0.06, 0.13, 6)
+    phs = rng.uniform(0, 2 * np.pi, 6)
+    T = np.stack([synth.se3_exp(amp * np.sin(frq * k + phs)) for k in range(n_frames)])
+    K = cam.K(); Kinv = np.linalg.inv(K); nrm = np.array([0.0, 0.0, 1.0])
+    Hrc = np.stack([np.linalg.inv(K @ (T[k, :3, :3] + np.outer(T[k, :3, 3], nrm) / depth) @ Kinv) for k in range(n_frames)])
+    tex = torch.from_numpy(synth.make_texture(Hh, W, 0x5EC).astype(np.float32)).to(dev)
+    uu, vv = torch.meshgrid(torch.arange(W, device=dev, dtype=torch.float32), torch.arange(Hh, device=dev, dtype=torch.float32), indexing="xy")
+    host_frames = torch.empty((n_frames, W * Hh), dtype=torch.uint8).pin_memory()
+    for i0 in range(0, n_frames, 64):
+        i1 = min(n_frames, i0 + 64)
+        Hm = torch.tensor(Hrc[i0:i1], dtype=torch.float32, device=dev)
+        den = Hm[:, 2, 0, None, None] * uu + Hm[:, 2, 1, None, None] * vv + Hm[:, 2, 2, None, None]
+        xr = (Hm[:, 0, 0, None, None] * uu + Hm[:, 0, 1, None, None] * vv + Hm[:, 0, 2, None, None]) / den
+        yr = (Hm[:, 1, 0, None, None] * uu + Hm[:, 1, 1, None, None] * vv + Hm[:, 1, 2, None, None]) / den
+        grid = torch.stack([xr / (W - 1) * 2 - 1, yr / (Hh - 1) * 2 - 1], dim=-1)
+        img = F.grid_sample(tex[None, None].expand(i1 - i0, -1, -1, -1), grid, mode="bicubic", padding_mode="reflection", align_corners=True)[:, 0]
+        host_frames[i0:i1].copy_(img.round().clamp(0, 255).to(torch.uint8).reshape(i1 - i0, -1))
+    # features of every reference frame (host, pinned): pixels, bearings, points where the rays meet the plane
+    px = np.stack([rng.uniform(30, W - 30, (P, N)), rng.uniform(30, Hh - 30, (P, N))], axis=2).astype(np.float32)
+    bearing = synth.bearing_from_px(cam, px.reshape(-1, 2)).reshape(P, N, 3)
+    R, t = T[:P, :3, :3], T[:P, :3, 3]
+    Cw = -np.einsum("pji,pj->pi", R, t)
+    dw = np.einsum("pji,pnj->pni", R, bearing)
+    sd = (depth - Cw[:, None, 2]) / dw[:, :, 2]
+    p_world = Cw[:, None, :] + dw * sd[:, :, None]
+    pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+    h = dict(px=pin(px), bearing=pin(bearing), p_world=pin(p_world), initial=pin(np.ones((P, N), np.uint8)),
+             T_ref_w=pin(T[:P, :3, :].reshape(P, 12)))
+    dv = {k: torch.empty(v.shape, dtype=v.dtype, device=dev) for k, v in h.items()}
+    d_pyr = torch.zeros((n_frames, pitch), dtype=torch.uint8, device=dev)
+    d_T = torch.empty((P, 12), dtype=torch.float64, device=dev)
+    d_nt = torch.zeros(P, dtype=torch.int32, device=dev)
+    d_st = torch.zeros((P, capi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    h_T = torch.empty((P, 12), dtype=torch.float64).pin_memory()
+    prm = capi.AlignParams(L, 0, args.iters, 15)
+    wa, ha, sa = (C.c_int * L)(*ws), (C.c_int * L)(*hs), (C.c_int * L)(*strides)
+    oa = (C.c_size_t * L)(*offs)
+    base = capi.BatchDesc()
+    base.max_features, base.levels, base.pyr_pitch = N, L, pitch
+    for l in range(L):
+        base.width[l], base.height[l], base.stride[l], base.level_offset[l] = ws[l], hs[l], strides[l], offs[l]
+    copy_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    comp = torch.cuda.Stream(device=dev)
+    n_chunks = (n_frames + chunk - 1) // chunk
+    descs = []
+    for j in range(n_chunks):                     # pairs whose `cur` frame arrives with chunk j: [max(0, j*chunk - 1), min(P, (j+1)*chunk - 1))
+        lo, hi = max(0, j * chunk - 1), min(P, (j + 1) * chunk - 1)
+        b = capi.BatchDesc.from_buffer_copy(bytes(base))
+        b.n_pairs = hi - lo
+        b.ref_pyr = d_pyr.data_ptr() + lo * pitch
+        b.cur_pyr = b.ref_pyr + pitch
+        b.px_xy, b.bearing, b.p_world = dv["px"][lo:].data_ptr(), dv["bearing"][lo:].data_ptr(), dv["p_world"][lo:].data_ptr()
+        b.initial, b.n_features = dv["initial"][lo:].data_ptr(), None
+        b.T_ref_w, b.T_cur_w = dv["T_ref_w"][lo:].data_ptr(), d_T[lo:].data_ptr()
+        b.n_tracked, b.stats = d_nt[lo:].data_ptr(), d_st[lo:].data_ptr()
+        descs.append((lo, hi, b))
+
+    def upload(j, s):
+        f0, f1 = j * chunk, min(n_frames, (j + 1) * chunk)
+        with torch.cuda.stream(s):
+            d_pyr[f0:f1, :W * Hh].copy_(host_frames[f0:f1], non_blocking=True)
+            p0, p1 = min(P, f0), min(P, f1)          # the feature columns of the frames of this chunk (as reference frames)
+            if p1 > p0:
+                for k in h:
+                    dv[k][p0:p1].copy_(h[k][p0:p1], non_blocking=True)
+
+    def compute(j):
+        f0, f1 = j * chunk, min(n_frames, (j + 1) * chunk)
+        lo, hi, b = descs[j]
+        ctx.check(ctx.lib.dsdtm_pyrdown_batch_device(ctx.handle, d_pyr.data_ptr() + f0 * pitch, pitch, f1 - f0, L, wa, ha, sa, oa, comp.cuda_stream))
+        if hi > lo:
+            with torch.cuda.stream(comp):
+                d_T[lo:hi].copy_(dv["T_ref_w"][lo:hi], non_blocking=True)      # seed: cur.pose = ref.pose (src/Tracking.cpp:201)
+            ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cam_struct), C.byref(prm), comp.cuda_stream))
+
+    def run(do_copy, do_compute):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs = []
+        for j in range(n_chunks):
+            if do_copy:
+                s = copy_streams[j % 2]
+                upload(j, s)
+                e = torch.cuda.Event(); e.record(s); evs.append(e)
+                if do_compute:
+                    comp.wait_event(e)
+            if do_compute:
+                compute(j)
+        if do_compute:
+            with torch.cuda.stream(comp):
+                h_T.copy_(d_T, non_blocking=True)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(True, True)                                   # warm-up (allocations, clocks)
+    t_pipe = min(run(True, True) for _ in range(3))
+    T_pipe = h_T.numpy().copy()
+    nt_pipe = d_nt.cpu().numpy().copy()
+    st_pipe = np.frombuffer(d_st.cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE).copy()
+    t_copy = min(run(True, False) for _ in range(3))
+    t_comp = min(run(False, True) for _ in range(3))
+    # the box's ceiling: one hipMemcpyAsync of the same number of bytes, pinned -> device, contiguous
+    nbytes = host_frames.numel() + sum(v.numel() * v.element_size() for v in h.values())
+    flat_h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    flat_d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    flat_d.copy_(flat_h, non_blocking=True); torch.cuda.synchronize()
+    t_ceil = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        flat_d.copy_(flat_h, non_blocking=True); torch.cuda.synchronize()
+        t_ceil = min(t_ceil, time.perf_counter() - t0)
+    ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, comp.cuda_stream))
+    # parity of a sample of the chained pairs against the CPU oracle on the same bytes
+    lib = oracle_lib.load()
+    sample = 16
+    hostpyr = d_pyr[:sample + 1].cpu().numpy()
+    hb = capi.BatchDesc.from_buffer_copy(bytes(base))
+    hb.n_pairs = sample
+    hb.ref_pyr, hb.cur_pyr = hostpyr.ctypes.data, hostpyr.ctypes.data + pitch
+    hx = {k: v[:sample].numpy().copy() for k, v in h.items()}
+    To = hx["T_ref_w"].copy(); nto = np.zeros(sample, np.int32); sto = np.zeros(sample, capi.STATS_DTYPE)
+    hb.px_xy, hb.bearing, hb.p_world, hb.initial = (hx[k].ctypes.data for k in ("px", "bearing", "p_world", "initial"))
+    hb.n_features, hb.T_ref_w, hb.T_cur_w, hb.n_tracked, hb.stats = None, hx["T_ref_w"].ctypes.data, To.ctypes.data, nto.ctypes.data, sto.ctypes.data
+    lib.oracle_sparse_align_batch_timed(C.byref(hb), C.byref(cam_struct), C.byref(prm), usable_cpus())
+    dl = np.array([synth.pose_error(T_pipe[i], To[i]) for i in range(sample)])
+    err = np.array([synth.pose_error(T_pipe[i], T[i + 1, :3]) for i in range(P)])
+    return {
+        "workload": f"streamed: {n_frames} chained {W}x{Hh} frames from pinned host memory ({P} pairs, {N} patches, {L} levels, cap "
+                    f"{args.iters}), chunks of {chunk} frames: H2D (level 0 + feature columns) on 2 copy streams -> pyramids on the "
+                    f"device -> chained alignment; every frame uploaded and built once",
+        "value": n_frames / t_pipe, "unit": "frames/s (PCIe-inclusive, end to end; = alignments/s + 1 frame)",
+        "ms_total": t_pipe * 1e3, "ms_copy_alone": t_copy * 1e3, "ms_compute_alone": t_comp * 1e3,
+        "h2d_bytes": int(nbytes), "h2d_achieved_GBps": nbytes / t_pipe / 1e9, "h2d_chunked_alone_GBps": nbytes / t_copy / 1e9,
+        "h2d_ceiling_GBps": nbytes / t_ceil / 1e9,
+        "h2d_ceiling_note": "one hipMemcpyAsync of the same number of bytes, pinned host -> device, on this box",
+        "overlap_ms": (t_copy + t_comp - t_pipe) * 1e3,
+        "transfer_overlapped_fraction": max(0.0, min(1.0, (t_copy + t_comp - t_pipe) / t_copy)),
+        "compute_hidden_fraction": max(0.0, min(1.0, (t_copy + t_comp - t_pipe) / t_comp)),
+        "overlap_note": "overlap = copy alone + compute alone - pipeline. The pipeline is bound by the link: the compute (pyramids + "
+                        "alignments, a sixth of the upload time) hides under the transfer almost completely; the share of the TRANSFER "
+                        "that runs beside compute can therefore not exceed compute / copy",
+        "pose_delta_vs_cpu": {"max_rad": float(dl[:, 0].max()), "max_m": float(dl[:, 1].max()), "pairs_checked": sample,
+                              "n_tracked_equal": bool(np.array_equal(nt_pipe[:sample], nto)),
+                              "iterations_equal": bool(np.array_equal(st_pipe["iters"][:sample], sto["iters"]))},
+        "err_vs_ground_truth_median": {"rad": float(np.median(err[:, 0])), "m": float(np.median(err[:, 1]))}}
 
 
 def fp64_block(args, kernel_ms):
@@ -559,15 +754,19 @@ def main():
     torch.cuda.synchronize()
 
     per_kernel = n_streams == 1
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_kernel else 1)]
+    # One stream: HIP events around every launch. Several streams: one pair around the whole timed region (its span is
+    # what a step costs the GPU; events around every launch were tried — they cost 4 % and, with other streams' kernels
+    # in flight, do not bracket the kernel)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_kernel else 0)]
+    span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     join = [torch.cuda.Event() for _ in streams]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if not per_kernel:
-        ev[0][0].record(streams[0])           # span of the whole timed region on the launch streams
+        span[0].record(streams[0])            # span of the whole timed region on the launch streams
         for s in streams[1:]:
-            s.wait_event(ev[0][0])
+            s.wait_event(span[0])
     for k in range(args.steps):
         if per_kernel:
             ev[k][0].record(stream)           # HIP events on the stream the kernel is launched on
@@ -578,7 +777,7 @@ def main():
         for i, s in enumerate(streams[1:], 1):
             join[i].record(s)
             streams[0].wait_event(join[i])
-        ev[0][1].record(streams[0])
+        span[1].record(streams[0])
     for s in streams:
         s.synchronize()
     torch.cuda.synchronize()
@@ -587,15 +786,39 @@ def main():
     if world > 1:
         elapsed = shard.max_over_ranks(elapsed, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
     ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, stream.cuda_stream))   # no hand-over wait timed out in any launch
-    d["T_cur_w"] = d["T_steps"][n_slots - 1]          # the last step's results are the ones checked below
+    d["T_cur_w"] = d["T_steps"][n_slots - 1].clone()  # the last step's results are the ones checked below
     if per_kernel:
         kernel_ms = [a.elapsed_time(b) for a, b in ev]
-        k_avg, k_min = float(np.mean(kernel_ms)), float(np.min(kernel_ms))
+        k_avg, k_min, k_extra = float(np.mean(kernel_ms)), float(np.min(kernel_ms)), {}
         k_basis = "HIP events around every launch on the launch stream (one stream: launches do not overlap)"
     else:
-        k_avg = k_min = ev[0][0].elapsed_time(ev[0][1]) / args.steps
-        k_basis = (f"HIP-event span of the timed region / steps: {n_streams} streams, consecutive launches overlap at "
-                   f"their edges, so a launch's own begin-to-end time is longer than its share of the GPU")
+        k_avg = span[0].elapsed_time(span[1]) / args.steps
+        k_min = None
+        # a short one-stream burst OUTSIDE the timed region: the duration of the kernel when nothing overlaps it
+        solo_n = min(30, args.warmup + args.steps)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(solo_n)]
+        d["T_steps"][:solo_n].copy_(d["T_seed"].unsqueeze(0).expand(solo_n, -1, -1))
+        torch.cuda.synchronize()
+        for k in range(solo_n):
+            evs[k][0].record(streams[0])
+            ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(descs[k]), C.byref(cam_struct), C.byref(prm),
+                                                              streams[0].cuda_stream))
+            evs[k][1].record(streams[0])
+        streams[0].synchronize()
+        k_solo = float(np.mean([a.elapsed_time(b) for a, b in evs][5:]))
+        ov = pmc_summary().get("overlap", {})     # from the committed kernel trace of this binary (tools/profile.sh, case main)
+        k_extra = {"span_ms_per_step": k_avg,
+                   "kernel_ms_own_in_flight": ov.get("own_duration_avg_ns", 0) * 1e-6 or None,
+                   "launches_in_flight": ov.get("launches_in_flight_avg"),
+                   "in_flight_note": "a launch's own begin-to-end time and the number of launches in flight with the default streams: "
+                                     "rocprofv3 --kernel-trace of this command, committed in " + PMC_SUMMARY + " (null when that "
+                                     "summary was taken with another build of the library)",
+                   "kernel_ms_solo": k_solo,
+                   "kernel_ms_solo_note": f"mean of {solo_n - 5} launches on ONE stream after the timed region (HIP events around each): "
+                                          "the kernel's duration as rocprofv3 --kernel-trace reports it for a one-stream run"}
+        k_basis = (f"kernel_ms_avg = HIP-event span of the timed region / steps ({n_streams} launch streams: consecutive launches "
+                   f"overlap at their edges, so a launch's own begin-to-end time is longer than its share of the GPU); "
+                   f"kernel_ms_solo = the kernel alone")
 
     rc = 0
     if rank == 0:
@@ -620,7 +843,7 @@ def main():
                        "parallelism": f"independent pairs x{world} (no collective)",
                        **({"barrier_backend": dist.get_backend()} if world > 1 else {})},
             "roofline": roofline_block("sparse_align_reg_kernel", args.pairs * b_alg, k_avg, k_min, args.pairs, b_alg, "alignment",
-                                       {"kernel_time_basis": k_basis}),
+                                       {"kernel_time_basis": k_basis, **k_extra}),
             "fp64": fp64_block(args, k_avg),
             "executed_iterations_per_level_mean": [float(x) for x in iters.mean(axis=0)],
             "executed_iterations_total_mean": float(iters.sum(axis=1).mean()),

@@ -129,6 +129,7 @@ EXPORTED_SYMBOLS = [
     "dsdtm_frame_create", "dsdtm_frame_create_from_image", "dsdtm_frame_destroy", "dsdtm_sparse_align_frames",
     "dsdtm_detect_cells", "dsdtm_detect_cells_frame", "dsdtm_match_candidates_frames",
     "dsdtm_pose_optimization", "dsdtm_pose_optimization_batch_device",
+    "dsdtm_sparse_align_batch_sharded", "dsdtm_shard_range",
 ]
 
 
@@ -229,6 +230,11 @@ def load():
     lib.dsdtm_match_candidates_frames.restype = C.c_int
     lib.dsdtm_match_candidates_frames.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(Camera), dp, dp,
                                                   ip32, fp, ip32, dp, dp, C.c_int, C.c_int, C.c_int, dp, ip32, u8p]
+    lib.dsdtm_sparse_align_batch_sharded.restype = C.c_int
+    lib.dsdtm_sparse_align_batch_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(BatchDesc), C.POINTER(Camera),
+                                                     C.POINTER(AlignParams)]
+    lib.dsdtm_shard_range.restype = None
+    lib.dsdtm_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.dsdtm_debug_set_option.restype = C.c_int
     lib.dsdtm_debug_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.dsdtm_debug_get_option.restype = C.c_int

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/dsdtm_amd.h"
@@ -415,6 +416,94 @@ extern "C" int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream) {
         set_err(ctx, "sparse-align kernel: a hand-over wait timed out (results since the last check are invalid)");
         return DSDTM_ERR_HIP;
     }
+    return DSDTM_OK;
+}
+
+// ---- the batch from host memory over several contexts / devices ------------------------------
+extern "C" void dsdtm_shard_range(int n_pairs, int n_shards, int shard, int* lo, int* hi) {
+    const int per = n_shards > 0 ? (n_pairs + n_shards - 1) / n_shards : n_pairs;
+    int l = shard * per, h = l + per;
+    if (l > n_pairs) l = n_pairs;
+    if (h > n_pairs) h = n_pairs;
+    if (n_pairs <= 0 || shard < 0 || shard >= n_shards) l = h = 0;
+    if (lo) *lo = l;
+    if (hi) *hi = h;
+}
+
+// One shard: pairs [lo, hi) of the host batch on `ctx` (its device, its stream). Device scratch comes from the
+// context's staging buffer (device side only: the caller's arrays may be pageable, the copies are then staged by
+// the runtime; pinned arrays are copied directly).
+static int sharded_one(dsdtm_ctx* ctx, const dsdtm_batch_desc* hb, const dsdtm_camera* cam, const dsdtm_align_params* prm,
+                       int lo, int hi) {
+    const int n = hi - lo;
+    if (n <= 0) return DSDTM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t nf = (size_t)hb->max_features, pit = hb->pyr_pitch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_ref = take(n * pit), o_cur = take(n * pit), o_px = take(n * nf * 8), o_be = take(n * nf * 24),
+                 o_pw = take(n * nf * 24), o_in = take(n * nf), o_nf = take(hb->n_features ? n * 4 : 0),
+                 o_tr = take(n * 96), o_tc = take(n * 96), o_nt = take(n * 4),
+                 o_st = take(hb->stats ? n * sizeof(dsdtm_align_stats) : 0);
+    if (off > ctx->d_cap) {
+        if (ctx->d_stage) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_stage); }
+        ctx->d_stage = nullptr; ctx->d_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_stage, off));
+        ctx->d_cap = off;
+    }
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    hipStream_t st = ctx->stream;
+    auto up = [&](size_t o, const void* src, size_t bytes) {
+        return bytes ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+    };
+    HIP_TRY(ctx, up(o_ref, hb->ref_pyr + (size_t)lo * pit, n * pit));
+    HIP_TRY(ctx, up(o_cur, hb->cur_pyr + (size_t)lo * pit, n * pit));
+    HIP_TRY(ctx, up(o_px, hb->px_xy + (size_t)lo * nf * 2, n * nf * 8));
+    HIP_TRY(ctx, up(o_be, hb->bearing + (size_t)lo * nf * 3, n * nf * 24));
+    HIP_TRY(ctx, up(o_pw, hb->p_world + (size_t)lo * nf * 3, n * nf * 24));
+    HIP_TRY(ctx, up(o_in, hb->initial + (size_t)lo * nf, n * nf));
+    if (hb->n_features) HIP_TRY(ctx, up(o_nf, hb->n_features + lo, n * 4));
+    HIP_TRY(ctx, up(o_tr, hb->T_ref_w + (size_t)lo * 12, n * 96));
+    HIP_TRY(ctx, up(o_tc, hb->T_cur_w + (size_t)lo * 12, n * 96));
+    dsdtm_batch_desc b = *hb;
+    b.n_pairs = n;
+    b.ref_pyr = d + o_ref; b.cur_pyr = d + o_cur;
+    b.px_xy = (const float*)(d + o_px); b.bearing = (const double*)(d + o_be); b.p_world = (const double*)(d + o_pw);
+    b.initial = d + o_in; b.n_features = hb->n_features ? (const int32_t*)(d + o_nf) : nullptr;
+    b.T_ref_w = (const double*)(d + o_tr); b.T_cur_w = (double*)(d + o_tc);
+    b.n_tracked = (int32_t*)(d + o_nt); b.stats = hb->stats ? (dsdtm_align_stats*)(d + o_st) : nullptr;
+    if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, st)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(hb->T_cur_w + (size_t)lo * 12, d + o_tc, n * 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(hb->n_tracked + lo, d + o_nt, n * 4, hipMemcpyDeviceToHost, st));
+    if (hb->stats) HIP_TRY(ctx, hipMemcpyAsync(hb->stats + lo, d + o_st, n * sizeof(dsdtm_align_stats), hipMemcpyDeviceToHost, st));
+    return dsdtm_sparse_align_check(ctx, st);
+}
+
+extern "C" int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx, const dsdtm_batch_desc* hb,
+                                                const dsdtm_camera* cam, const dsdtm_align_params* prm) {
+    if (!ctx || n_ctx <= 0 || !hb || !cam || !prm) return DSDTM_ERR_INVALID;
+    for (int g = 0; g < n_ctx; ++g) if (!ctx[g]) return DSDTM_ERR_INVALID;
+    if (hb->n_pairs < 0 || !hb->ref_pyr || !hb->cur_pyr || !hb->T_ref_w || !hb->T_cur_w || !hb->n_tracked ||
+        (hb->max_features > 0 && (!hb->px_xy || !hb->bearing || !hb->p_world || !hb->initial))) {
+        set_err(ctx[0], "sharded batch: NULL host pointers"); return DSDTM_ERR_INVALID;
+    }
+    for (int g = 0; g < n_ctx; ++g)
+        for (int h = g + 1; h < n_ctx; ++h)
+            if (ctx[g] == ctx[h]) { set_err(ctx[0], "sharded batch: a context appears twice (one context per shard)"); return DSDTM_ERR_INVALID; }
+    std::vector<int> rc(n_ctx, DSDTM_OK);
+    std::vector<std::thread> th;
+    for (int g = 1; g < n_ctx; ++g) {
+        int lo, hi;
+        dsdtm_shard_range(hb->n_pairs, n_ctx, g, &lo, &hi);
+        th.emplace_back([=, &rc]() { rc[g] = sharded_one(ctx[g], hb, cam, prm, lo, hi); });
+    }
+    {
+        int lo, hi;
+        dsdtm_shard_range(hb->n_pairs, n_ctx, 0, &lo, &hi);
+        rc[0] = sharded_one(ctx[0], hb, cam, prm, lo, hi);      // the calling thread takes the first shard
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < n_ctx; ++g) if (rc[g] != DSDTM_OK) return rc[g];
     return DSDTM_OK;
 }
 

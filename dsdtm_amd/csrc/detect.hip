@@ -26,18 +26,43 @@ namespace dsdtm {
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// (one launch covers all levels: blockIdx.z = level, the grid has level 0's extent and the blocks
-// outside a smaller level leave at once)
-__global__ __launch_bounds__(256) void fast_score_kernel(const DetectArgs a) {
-    const int level = blockIdx.z;
+// FAST-10 score of one pixel from its centre and ring (order of fast_10_score.cpp:3146-3163): min and max over
+// every window of 10 contiguous ring pixels (circular) by doubling — 2, 4, 8, 8 + 2 — then
+// margin = max(best window minimum - c, c - best window maximum): a corner at barrier b iff margin > b, and the
+// score (fast_10_score.cpp: the largest such b) is margin - 1. T = int (one pixel) or a packed pair of u16 (two
+// pixels per instruction: v_pk_min_u16 / v_pk_max_u16).
+template <typename T, typename MinF, typename MaxF>
+__device__ __forceinline__ void fast10_extrema(const T* d, T& best_min, T& worst_max, MinF mn, MaxF mx) {
+    T mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { mn2[i] = mn(d[i], d[(i + 1) & 15]); mx2[i] = mx(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { mn4[i] = mn(mn2[i], mn2[(i + 2) & 15]); mx4[i] = mx(mx2[i], mx2[(i + 2) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { mn8[i] = mn(mn4[i], mn4[(i + 4) & 15]); mx8[i] = mx(mx4[i], mx4[(i + 4) & 15]); }
+    best_min = mn(mn8[0], mn2[8]);
+    worst_max = mx(mx8[0], mx2[8]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        best_min = mx(best_min, mn(mn8[i], mn2[(i + 8) & 15]));
+        worst_max = mn(worst_max, mx(mx8[i], mx2[(i + 8) & 15]));
+    }
+}
+
+// ---- one thread per pixel: levels whose width is not a multiple of 4 ---------------------------------------------
+// (grid: x = pixel columns of level 0 / 256, y = rows of level 0, z = frame * levels + level; blocks outside a smaller
+// level leave at once)
+__global__ __launch_bounds__(256) void fast_score_kernel(const DetectArgs a, unsigned level_mask) {
+    const int level = blockIdx.z % a.levels, frame = blockIdx.z / a.levels;
+    if (!((level_mask >> level) & 1u)) return;
     const LevelGeom lg = a.lv[level];
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= lg.w || y >= lg.h) return;
-    uint8_t* __restrict__ out = a.score + lg.off + (size_t)y * lg.stride + x;
+    uint8_t* __restrict__ out = a.score + (size_t)frame * a.pyr_pitch + lg.off + (size_t)y * lg.stride + x;
     // faster_corner_10_sse.cpp:23-186: rows 3..h-4, columns 3..w-4
     if (x < 3 || x >= lg.w - 3 || y < 3 || y >= lg.h - 3) { *out = 0; return; }
-    const uint8_t* __restrict__ p = a.pyr + lg.off + (size_t)y * lg.stride + x;
+    const uint8_t* __restrict__ p = a.pyr + (size_t)frame * a.pyr_pitch + lg.off + (size_t)y * lg.stride + x;
     const int st = lg.stride;
     const int c = *p;
     int d[16];   // ring in the order of fast_10_score.cpp:3146-3163
@@ -45,22 +70,101 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const DetectArgs a) {
     d[4] = p[3];            d[5] = p[-st + 3];      d[6] = p[-2 * st + 2];  d[7] = p[-3 * st + 1];
     d[8] = p[-3 * st];      d[9] = p[-3 * st - 1];  d[10] = p[-2 * st - 2]; d[11] = p[-st - 3];
     d[12] = p[-3];          d[13] = p[st - 3];      d[14] = p[2 * st - 2];  d[15] = p[3 * st - 1];
-    // min and max over every window of 10 contiguous ring pixels (circular), by doubling: 2, 4, 8, 8+2
-    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+    int best_min, worst_max;
+    fast10_extrema<int>(d, best_min, worst_max, [](int u, int v) { return imin(u, v); }, [](int u, int v) { return imax(u, v); });
+    const int margin = imax(best_min - c, c - worst_max);
+    *out = margin > a.barrier ? (uint8_t)(margin - 1) : (uint8_t)0;
+}
+
+// ---- one thread per strip of 4 pixels x FS_ROWS rows: levels whose width and stride are multiples of 4 ------------
+// A thread walks down FS_ROWS output rows with a sliding window of the seven image rows a ring touches; every row
+// of the strip is fetched ONCE per thread (three aligned dwords: columns x - 4 .. x + 7 cover the ring columns x - 3
+// .. x + 6 of the four pixels) instead of 17 byte loads per pixel, the four scores leave as one dword, and the
+// min / max network runs on packed u16 pairs (two pixels per instruction). The ring bytes of a pixel pair come out
+// of the row registers with ONE v_perm each (all selectors are compile-time constants). Tasks (strip, row chunk) are
+// numbered linearly per level, so waves are full at every level width.
+constexpr int FS_ROWS = 4;
+typedef uint16_t fs_u16x2 __attribute__((ext_vector_type(2)));
+struct FsRow { uint32_t d0, d1, d2; };          // columns x-4..x-1, x..x+3, x+4..x+7
+
+// pixels (I, I + 1) of the strip, column offset DX: bytes 4 + I + DX and 5 + I + DX of the row, as a u16 pair
+template <int I, int DX>
+__device__ __forceinline__ fs_u16x2 fs_pair(const FsRow& r) {
+    constexpr int B = 4 + I + DX;                 // 1 .. 9
+    static_assert(B >= 1 && B + 1 <= 10, "ring column inside the three dwords");
+    uint32_t v;
+    if constexpr (B + 1 <= 7) v = __builtin_amdgcn_perm(r.d1, r.d0, 0x0c000c00u | (uint32_t)B | ((uint32_t)(B + 1) << 16));
+    else v = __builtin_amdgcn_perm(r.d2, r.d1, 0x0c000c00u | (uint32_t)(B - 4) | ((uint32_t)(B - 3) << 16));
+    return __builtin_bit_cast(fs_u16x2, v);
+}
+__device__ __forceinline__ fs_u16x2 fs_min(fs_u16x2 u, fs_u16x2 v) { return __builtin_elementwise_min(u, v); }
+__device__ __forceinline__ fs_u16x2 fs_max(fs_u16x2 u, fs_u16x2 v) { return __builtin_elementwise_max(u, v); }
+
+// scores of pixels (I, I + 1) of the strip in the low bytes of the two halves; w[k] = image row y - 3 + k
+template <int I>
+__device__ __forceinline__ uint32_t fs_score_pair(const FsRow* w, int barrier) {
+    fs_u16x2 d[16];
+    d[0] = fs_pair<I, 0>(w[6]);   d[1] = fs_pair<I, 1>(w[6]);   d[2] = fs_pair<I, 2>(w[5]);   d[3] = fs_pair<I, 3>(w[4]);
+    d[4] = fs_pair<I, 3>(w[3]);   d[5] = fs_pair<I, 3>(w[2]);   d[6] = fs_pair<I, 2>(w[1]);   d[7] = fs_pair<I, 1>(w[0]);
+    d[8] = fs_pair<I, 0>(w[0]);   d[9] = fs_pair<I, -1>(w[0]);  d[10] = fs_pair<I, -2>(w[1]); d[11] = fs_pair<I, -3>(w[2]);
+    d[12] = fs_pair<I, -3>(w[3]); d[13] = fs_pair<I, -3>(w[4]); d[14] = fs_pair<I, -2>(w[5]); d[15] = fs_pair<I, -1>(w[6]);
+    const fs_u16x2 c = fs_pair<I, 0>(w[3]);
+    fs_u16x2 best_min, worst_max;
+    fast10_extrema<fs_u16x2>(d, best_min, worst_max, fs_min, fs_max);
+    // margin = max(best_min - c, c - worst_max) on unsigned halves: saturating differences (a negative one is never the maximum
+    // unless both are, and then the margin is <= 0 and the pixel is no corner)
+    const fs_u16x2 zero = {0, 0};
+    const fs_u16x2 up = fs_max(best_min, c) - c, dn = c - fs_min(worst_max, c);
+    const fs_u16x2 margin = fs_max(up, dn);
+    const fs_u16x2 one = {1, 1};
+    const fs_u16x2 bar = {(uint16_t)barrier, (uint16_t)barrier};
+    const fs_u16x2 sc = fs_max(margin, one) - one;                     // margin - 1, 0 for margin 0
+    const fs_u16x2 keep = (margin > bar) ? sc : zero;
+    return __builtin_bit_cast(uint32_t, keep);
+}
+
+__global__ __launch_bounds__(256) void fast_score_strip_kernel(const DetectArgs a, unsigned level_mask) {
+    const int level = blockIdx.y, frame = blockIdx.z;
+    if (!((level_mask >> level) & 1u)) return;
+    const LevelGeom lg = a.lv[level];
+    const int strips = lg.w >> 2, chunks = (lg.h + FS_ROWS - 1) / FS_ROWS;
+    const int task = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)(blockIdx.x * blockDim.x) >= strips * chunks) return;      // block-uniform
+    if (task >= strips * chunks) return;
+    const int chunk = task / strips, q = task - chunk * strips;         // q: dword (strip) index inside a row
+    const int y0 = chunk * FS_ROWS;
+    const uint32_t* __restrict__ img = (const uint32_t*)(a.pyr + (size_t)frame * a.pyr_pitch);
+    uint32_t* __restrict__ out = (uint32_t*)(a.score + (size_t)frame * a.pyr_pitch);
+    const uint32_t last_dw = (uint32_t)(a.pyr_pitch >> 2) - 1u;
+    const uint32_t sdw = (uint32_t)lg.stride >> 2, odw = lg.off >> 2;
+    // row y of the strip; rows outside the level and the dwords beside the row ends are clamped to harmless
+    // addresses — they only feed pixels whose score is forced to 0 below
+    auto load_row = [&](int y) {
+        const int yc = imin(imax(y, 0), lg.h - 1);
+        const uint32_t rb = odw + (uint32_t)yc * sdw + (uint32_t)q;
+        FsRow r;
+        r.d0 = img[q > 0 ? rb - 1u : rb];
+        r.d1 = img[rb];
+        r.d2 = img[rb + 1u < last_dw ? rb + 1u : last_dw];
+        return r;
+    };
+    FsRow w[7 + FS_ROWS - 1];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { mn2[i] = imin(d[i], d[(i + 1) & 15]); mx2[i] = imax(d[i], d[(i + 1) & 15]); }
+    for (int k = 0; k < 7 + FS_ROWS - 1; ++k) w[k] = load_row(y0 - 3 + k);          // all rows of the chunk in flight
+    const int x = q << 2;
+    // valid columns: 3 <= x + i < w - 3 (faster_corner_10_sse.cpp:23-186)
+    uint32_t colmask = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { mn4[i] = imin(mn2[i], mn2[(i + 2) & 15]); mx4[i] = imax(mx2[i], mx2[(i + 2) & 15]); }
+    for (int i = 0; i < 4; ++i) if (x + i >= 3 && x + i < lg.w - 3) colmask |= 0xffu << (8 * i);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { mn8[i] = imin(mn4[i], mn4[(i + 4) & 15]); mx8[i] = imax(mx4[i], mx4[(i + 4) & 15]); }
-    int best_min = 0, worst_max = 255;   // brighter arcs: max over arcs of (min - c); darker: max of (c - max)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        best_min = imax(best_min, imin(mn8[i], mn2[(i + 8) & 15]));
-        worst_max = imin(worst_max, imax(mx8[i], mx2[(i + 8) & 15]));
+    for (int r = 0; r < FS_ROWS; ++r) {
+        const int y = y0 + r;
+        const uint32_t p01 = fs_score_pair<0>(w + r, a.barrier), p23 = fs_score_pair<2>(w + r, a.barrier);
+        // bytes: p01 = [s0, 0, s1, 0], p23 = [s2, 0, s3, 0] -> [s0, s1, s2, s3]
+        uint32_t v = __builtin_amdgcn_perm(p23, p01, 0x06040200u) & colmask;
+        if (y < 3 || y >= lg.h - 3) v = 0;
+        if (y < lg.h) out[odw + (uint32_t)y * sdw + (uint32_t)q] = v;
     }
-    const int margin = imax(best_min - c, c - worst_max);     // corner at barrier b iff margin > b
-    *out = margin > a.barrier ? (uint8_t)(margin - 1) : (uint8_t)0;      // fast_10_score.cpp: largest such b
 }
 
 // Feature_detector::shiTomasiScore (:157-198) for the corner (u, v), computed by the WHOLE wave: lane =

@@ -184,6 +184,37 @@ def make_scene(width=640, height=480, levels=4, n_patches=300, seed=0xD5D7,
                       p_world, initial, T_ref_w.copy(), T_ref_w.copy(), T_true, depth)
 
 
+def make_sequence(n_frames=9, width=640, height=480, levels=4, n_patches=300, seed=7, depth=2.0, margin=30,
+                  cam: Camera | None = None, t_max=0.02, w_max=0.01) -> list[AlignScene]:
+    """A chained sequence: a camera moves in small steps in front of a textured plane (z = depth in the frame of
+    frame 0, the world). Frame k is `cur` of pair k - 1 and `ref` of pair k — the list holds the n_frames - 1 pairs
+    as AlignScenes whose ref_pyr of pair k IS (the same object as) cur_pyr of pair k - 1. Features of a reference
+    frame: random pixels, unit bearings, map points where the rays meet the plane; reference poses are the true
+    ones, every current frame is seeded with its reference's pose (src/Tracking.cpp:201)."""
+    cam = cam or Camera.tum(width, height)
+    rng = np.random.default_rng(seed ^ 0x5E9)
+    tex = make_texture(height, width, seed)
+    T = [np.eye(4)]
+    for _ in range(n_frames - 1):
+        T.append(se3_exp(random_xi(rng, t_max, w_max)) @ T[-1])
+    pyrs = [build_pyramid(np.clip(np.rint(tex), 0, 255).astype(np.uint8) if k == 0 else warp_plane(tex, cam, T[k], depth), levels)
+            for k in range(n_frames)]
+    n = np.array([0.0, 0.0, 1.0])
+    out = []
+    for k in range(n_frames - 1):
+        px = np.stack([rng.uniform(margin, width - margin, n_patches),
+                       rng.uniform(margin, height - margin, n_patches)], axis=1).astype(np.float32)
+        bearing = bearing_from_px(cam, px)
+        R, t = T[k][:3, :3], T[k][:3, 3]
+        C = -R.T @ t                                           # camera centre in the world
+        d = bearing @ R                                        # rays in the world: R^T b
+        sdist = (depth - n @ C) / (d @ n)
+        p_world = C + d * sdist[:, None]
+        out.append(AlignScene(cam, pyrs[k], pyrs[k + 1], px, bearing, p_world, np.ones(n_patches, dtype=np.uint8),
+                              T[k][:3].copy(), T[k][:3].copy(), T[k + 1][:3].copy(), depth))
+    return out
+
+
 def random_xi(rng, t_max=0.02, w_max=0.01):
     return np.concatenate([rng.uniform(-t_max, t_max, 3), rng.uniform(-w_max, w_max, 3)])
 

@@ -297,6 +297,22 @@ int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* batc
                                     const dsdtm_camera* cam, const dsdtm_align_params* params,
                                     void* hip_stream);
 
+/* The same batch from HOST memory over several devices (BASELINE config 4: 8192 independent pairs over the 8 GPUs
+ * of a node). Every pointer of `host_batch` is a HOST pointer. The pairs are cut into n_ctx
+ * contiguous blocks — context g takes pairs [lo, hi) of dsdtm_shard_range(n_pairs, n_ctx, g, &lo, &hi), ceil(P/G)
+ * each, the last ones possibly shorter or empty — and every block is processed by its own host thread on its
+ * context's device: upload, one launch, download of T_cur_w / n_tracked / stats, synchronise. No collective, no
+ * peer traffic; pairs are independent, so the results do not depend on n_ctx (bit for bit). The contexts may sit on
+ * different devices (one per GPU: the intended use) or share one. Returns the first non-zero status of any shard
+ * (dsdtm_last_error of that context has the message). The reference has no counterpart: it runs this path on one
+ * thread of one process (src/System.cpp:39-55). Pairs whose chain structure allows it can share frames: the
+ * device-resident entry point above accepts cur_pyr == ref_pyr + pyr_pitch (frame k is `cur` of pair k - 1 and
+ * `ref` of pair k), so a sequence of P + 1 frames is uploaded and built once. */
+int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx, const dsdtm_batch_desc* host_batch,
+                                     const dsdtm_camera* cam, const dsdtm_align_params* params);
+/* Pairs [*lo, *hi) of shard `shard` of `n_shards` over `n_pairs` pairs: contiguous blocks of ceil(n_pairs / n_shards). */
+void dsdtm_shard_range(int n_pairs, int n_shards, int shard, int* lo, int* hi);
+
 /* Result check for callers of the asynchronous batch entry point: waits for `hip_stream`, then reads (and
  * clears) the kernels' hand-over timeout flag. DSDTM_OK, or DSDTM_ERR_HIP when a bounded wait inside a kernel
  * ran out (a workgroup waited for a partner that never became resident): the results of the launches since the

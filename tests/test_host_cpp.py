@@ -45,7 +45,7 @@ def dump_scene(path, sc, params, min_fts, border, patch, px0):
 
 def test_cpp_host_layer_builds_against_the_c_abi():
     assert all(os.path.exists(build_example(n)) for n in ("example_align", "example_search", "example_pose_opt", "example_rgbd",
-                                                          "example_track"))
+                                                          "example_track", "example_batch"))
 
 
 @pytest.mark.gpu

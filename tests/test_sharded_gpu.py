@@ -1,0 +1,168 @@
+"""Independent frame pairs over several contexts / devices behind the C ABI (dsdtm_sparse_align_batch_sharded,
+SURVEY.md §8(b)/(e): contiguous blocks of ceil(P/G) pairs, one host thread and stream per context, no collective),
+and the chained batch (frame k is `cur` of pair k - 1 and `ref` of pair k: cur_pyr == ref_pyr + pyr_pitch)."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from dsdtm_amd import capi, shard, synth
+from tests import helpers as H
+from tests.conftest import cached_scene
+from tests.test_host_cpp import build_example
+
+
+def test_shard_range_is_contiguous_ceil_blocks():
+    """The C entry and the Python helper the bench uses cut the same blocks; together they cover every pair once."""
+    lib = capi.load()
+    for P in (0, 1, 7, 8, 9, 1000, 1024, 8192):
+        for G in (1, 2, 3, 8, 16):
+            seen = []
+            for g in range(G):
+                lo, hi = C.c_int(), C.c_int()
+                lib.dsdtm_shard_range(P, G, g, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard.pair_range(P, g, G)
+                assert hi.value - lo.value <= -(-P // G)
+                seen += list(range(lo.value, hi.value))
+            assert seen == list(range(P))
+    lo, hi = C.c_int(5), C.c_int(5)
+    lib.dsdtm_shard_range(10, 4, 7, C.byref(lo), C.byref(hi))           # a shard index out of range is empty
+    assert lo.value == hi.value
+
+
+def _host_batch(scenes, L, W, Hh):
+    ws, hs, st, offs, nbytes = capi.pyramid_layout(W, Hh, L)
+    pitch = (nbytes + 255) // 256 * 256
+    P, N = len(scenes), len(scenes[0].px)
+    a = dict(ref=np.zeros((P, pitch), np.uint8), cur=np.zeros((P, pitch), np.uint8))
+    for i, sc in enumerate(scenes):
+        for l in range(L):
+            a["ref"][i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.ref_pyr[l].reshape(-1)
+            a["cur"][i, offs[l]:offs[l] + ws[l] * hs[l]] = sc.cur_pyr[l].reshape(-1)
+    a.update(px=np.ascontiguousarray(np.stack([s.px for s in scenes]), np.float32),
+             bear=np.ascontiguousarray(np.stack([s.bearing for s in scenes])),
+             pw=np.ascontiguousarray(np.stack([s.p_world for s in scenes])),
+             ini=np.ascontiguousarray(np.stack([s.initial for s in scenes]), np.uint8),
+             Tr=np.ascontiguousarray(np.stack([s.T_ref_w.reshape(12) for s in scenes])),
+             Tc=np.ascontiguousarray(np.stack([s.T_cur_w_seed.reshape(12) for s in scenes])),
+             nt=np.full(P, -1, np.int32), st=np.zeros(P, capi.STATS_DTYPE))
+    b = capi.BatchDesc()
+    b.n_pairs, b.max_features, b.levels = P, N, L
+    for l in range(L):
+        b.width[l], b.height[l], b.stride[l], b.level_offset[l] = ws[l], hs[l], st[l], offs[l]
+    b.pyr_pitch = pitch
+    b.ref_pyr, b.cur_pyr, b.px_xy, b.bearing, b.p_world = (a[k].ctypes.data for k in ("ref", "cur", "px", "bear", "pw"))
+    b.initial, b.n_features, b.T_ref_w, b.T_cur_w = a["ini"].ctypes.data, None, a["Tr"].ctypes.data, a["Tc"].ctypes.data
+    b.n_tracked, b.stats = a["nt"].ctypes.data, a["st"].ctypes.data
+    return a, b, pitch
+
+
+@pytest.mark.gpu
+def test_two_and_three_contexts_on_one_device_equal_one_context(gpu_ctx, oracle):
+    """The one-GPU rehearsal of the 8-GPU split: the batch over 1, 2 and 3 contexts (all on device 0, each with its
+    own host thread and stream) — identical results bit for bit, and the oracle's."""
+    W, Hh, L = 320, 240, 3
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=150, seed=4100 + i, margin=12) for i in range(11)]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    lib = gpu_ctx.lib
+    results = []
+    for G in (1, 2, 3):
+        ctxs = [capi.Context(0) for _ in range(G)]
+        a, b, _ = _host_batch(scenes, L, W, Hh)
+        arr = (C.c_void_p * G)(*[c.handle for c in ctxs])
+        rc = lib.dsdtm_sparse_align_batch_sharded(arr, G, C.byref(b), C.byref(cam), C.byref(prm))
+        assert rc == 0, ctxs[0].lib.dsdtm_last_error(ctxs[0].handle)
+        results.append((a["Tc"].copy(), a["nt"].copy(), a["st"].copy()))
+        for c in ctxs:
+            c.close()
+    for T, nt, st in results[1:]:
+        assert np.array_equal(T, results[0][0]) and np.array_equal(nt, results[0][1])
+        assert np.array_equal(st["iters"], results[0][2]["iters"]) and np.array_equal(st["chi2"], results[0][2]["chi2"])
+    for i, sc in enumerate(scenes):
+        To, no, so = oracle.sparse_align(sc, L, 0, 10)
+        H.assert_pose_close(results[0][0][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"pair {i}")
+        assert results[0][1][i] == no and list(results[0][2]["iters"][i][:L]) == list(so["iters"][:L])
+    # a context listed twice is refused (a context is single-threaded)
+    c0 = capi.Context(0)
+    a, b, _ = _host_batch(scenes, L, W, Hh)
+    arr = (C.c_void_p * 2)(c0.handle, c0.handle)
+    assert lib.dsdtm_sparse_align_batch_sharded(arr, 2, C.byref(b), C.byref(cam), C.byref(prm)) != 0
+    c0.close()
+
+
+@pytest.mark.gpu
+def test_example_batch_cpp_over_several_contexts(tmp_path, gpu_ctx, oracle):
+    """The C++ caller (dsdtm_amd/host/example_batch.cpp: one process, one context per shard) against the oracle."""
+    exe = build_example("example_batch")
+    W, Hh, L = 320, 240, 3
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=150, seed=4100 + i, margin=12) for i in range(7)]
+    a, b, pitch = _host_batch(scenes, L, W, Hh)
+    path = tmp_path / "batch.bin"
+    cam = scenes[0].cam
+    with open(path, "wb") as f:
+        f.write(struct.pack("<10i", len(scenes), 150, L, W, Hh, L, 0, 10, 15, pitch))
+        f.write(struct.pack("<5f", cam.fx, cam.fy, cam.cx, cam.cy, cam.f))
+        for k in ("ref", "cur", "px", "bear", "pw", "ini", "Tr", "Tc"):
+            f.write(a[k].tobytes())
+    out = subprocess.run([exe, str(path), "3"], capture_output=True, text=True, check=True).stdout.split("\n")
+    shards = [l.split() for l in out if l.startswith("shard")]
+    assert [(int(s[5]), int(s[6])) for s in shards] == [shard.pair_range(7, g, 3) for g in range(3)]
+    rows = [l.split() for l in out if l.startswith("pair")]
+    assert len(rows) == len(scenes)
+    for i, sc in enumerate(scenes):
+        To, no, so = oracle.sparse_align(sc, L, 0, 10)
+        r = rows[i]
+        assert int(r[3]) == no and [int(x) for x in r[5:5 + L]] == list(so["iters"][:L])
+        T = np.array([float(x) for x in r[6 + L:6 + L + 12]]).reshape(3, 4)
+        H.assert_pose_close(T, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"pair {i}")
+
+
+@pytest.mark.gpu
+def test_chained_batch_equals_per_pair_runs(gpu_ctx, oracle):
+    """A sequence of frames as ONE device array of pyramids: ref_pyr = frame 0, cur_pyr = ref_pyr + pyr_pitch, so frame
+    k is `cur` of pair k - 1 and `ref` of pair k and every frame is uploaded (and its pyramid built) once. Bit for bit
+    the results of the same pairs with separate copies of their frames, and the oracle's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N, K = 320, 240, 3, 150, 10
+    seq = synth.make_sequence(n_frames=K, width=W, height=Hh, levels=L, n_patches=N, seed=21, margin=12)
+    a, b, pitch = _host_batch(seq, L, W, Hh)
+    cam = capi.camera_struct(seq[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    P = K - 1
+    # unchained reference run: separate ref / cur arrays
+    t = {k: torch.from_numpy(a[k]).to(dev) for k in ("ref", "cur", "px", "bear", "pw", "ini", "Tr", "Tc")}
+    t["nt"] = torch.zeros(P, dtype=torch.int32, device=dev)
+    t["st"] = torch.zeros((P, capi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    d = capi.BatchDesc.from_buffer_copy(bytes(b))
+    d.ref_pyr, d.cur_pyr, d.px_xy, d.bearing, d.p_world = (t[k].data_ptr() for k in ("ref", "cur", "px", "bear", "pw"))
+    d.initial, d.T_ref_w, d.T_cur_w, d.n_tracked, d.stats = (t[k].data_ptr() for k in ("ini", "Tr", "Tc", "nt", "st"))
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(d), C.byref(cam), C.byref(prm), None))
+    torch.cuda.synchronize()
+    want = (t["Tc"].cpu().numpy().copy(), t["nt"].cpu().numpy().copy(), t["st"].cpu().numpy().copy())
+    # chained: K frames, level 0 uploaded, pyramids built on the device by the library's pyrDown
+    ws, hs, st_, offs, nbytes = capi.pyramid_layout(W, Hh, L)
+    frames = np.zeros((K, pitch), np.uint8)
+    for k in range(K):
+        img = (seq[k].ref_pyr if k < P else seq[P - 1].cur_pyr)[0]
+        frames[k, :W * Hh] = img.reshape(-1)
+    fr = torch.from_numpy(frames).to(dev)
+    wa, ha, sa = (C.c_int * L)(*ws), (C.c_int * L)(*hs), (C.c_int * L)(*st_)
+    oa = (C.c_size_t * L)(*offs)
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_pyrdown_batch_device(gpu_ctx.handle, fr.data_ptr(), pitch, K, L, wa, ha, sa, oa, None))
+    t["Tc"].copy_(torch.from_numpy(a["Tc"]).to(dev)); t["nt"].zero_(); t["st"].zero_()
+    d.ref_pyr, d.cur_pyr = fr.data_ptr(), fr.data_ptr() + pitch
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(d), C.byref(cam), C.byref(prm), None))
+    torch.cuda.synchronize()
+    got = (t["Tc"].cpu().numpy(), t["nt"].cpu().numpy(), t["st"].cpu().numpy())
+    assert np.array_equal(fr.cpu().numpy()[:P], a["ref"])              # the device pyramids are the host ones, byte for byte
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    for i, sc in enumerate(seq):
+        To, no, _ = oracle.sparse_align(sc, L, 0, 10)
+        H.assert_pose_close(got[0][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"chained pair {i}")
+        assert got[1][i] == no
