@@ -129,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "dsdtm_frame_create", "dsdtm_frame_create_from_image", "dsdtm_frame_destroy", "dsdtm_sparse_align_frames",
     "dsdtm_detect_cells", "dsdtm_detect_cells_frame", "dsdtm_match_candidates_frames",
     "dsdtm_pose_optimization", "dsdtm_pose_optimization_batch_device",
-    "dsdtm_sparse_align_batch_sharded", "dsdtm_shard_range",
+    "dsdtm_sparse_align_batch_sharded", "dsdtm_shard_range", "dsdtm_detect_cells_batch_device",
 ]
 
 
@@ -227,6 +227,11 @@ def load():
     lib.dsdtm_detect_cells.argtypes = [C.c_void_p, C.POINTER(Pyramid), u8p, C.POINTER(DetectParams), fp, ip32, ip32, ip32]
     lib.dsdtm_detect_cells_frame.restype = C.c_int
     lib.dsdtm_detect_cells_frame.argtypes = [C.c_void_p, C.c_void_p, u8p, C.POINTER(DetectParams), fp, ip32, ip32, ip32]
+    lib.dsdtm_detect_cells_batch_device.restype = C.c_int
+    lib.dsdtm_detect_cells_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.c_void_p,
+                                                    C.POINTER(DetectParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dsdtm_match_candidates_frames.restype = C.c_int
     lib.dsdtm_match_candidates_frames.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(Camera), dp, dp,
                                                   ip32, fp, ip32, dp, dp, C.c_int, C.c_int, C.c_int, dp, ip32, u8p]

@@ -781,10 +781,11 @@ static int detect_cells_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     memset(&a, 0, sizeof a);
     a.pyr = dev_pyr ? dev_pyr : d + o_pyr; a.score = d + o_score; a.cell_key = (unsigned long long*)(d + o_key);
     a.occupied = d + o_occ;
+    a.pyr_pitch = pitch; a.n_frames = 1; a.levels = prm->levels;
     a.cell_size = prm->cell_size; a.grid_cols = prm->grid_cols; a.grid_rows = prm->grid_rows; a.barrier = prm->barrier;
     a.detection_threshold = prm->detection_threshold;
     for (int l = 0; l < prm->levels; ++l) { a.lv[l].w = pl.w[l]; a.lv[l].h = pl.h[l]; a.lv[l].stride = pl.w[l]; a.lv[l].off = (uint32_t)pl.off[l]; }
-    HIP_TRY(ctx, detect_launch(a, prm->levels, ctx->stream));
+    HIP_TRY(ctx, detect_launch(a, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(h + o_key, d + o_key, G * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const unsigned long long* keys = (const unsigned long long*)(h + o_key);
@@ -816,6 +817,40 @@ extern "C" int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame
     return detect_cells_one(ctx, frame->pl, nullptr, frame->d, grid_occupied, prm, cell_score, cell_x, cell_y, cell_level);
 }
 
+// The image part of Feature_detector::detect for n_frames packed device pyramids in one go (independent sequences,
+// keyframes of an offline run): every pointer is a device pointer, nothing is copied, asynchronous on hip_stream.
+extern "C" int dsdtm_detect_cells_batch_device(dsdtm_ctx* ctx, const uint8_t* pyr, size_t pyr_pitch, int n_frames, int levels,
+                                               const int* width, const int* height, const int* stride, const size_t* level_offset,
+                                               const uint8_t* grid_occupied, const dsdtm_detect_params* prm,
+                                               uint8_t* score_scratch, unsigned long long* key_scratch,
+                                               float* cell_score, int32_t* cell_x, int32_t* cell_y, int32_t* cell_level,
+                                               void* hip_stream) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!pyr || !width || !height || !stride || !level_offset || !prm || !score_scratch || !key_scratch || !cell_score || !cell_x ||
+        !cell_y || !cell_level || n_frames < 0 || levels <= 0 || levels > DSDTM_MAX_LEVELS) { set_err(ctx, "bad argument"); return DSDTM_ERR_INVALID; }
+    if (prm->cell_size <= 0 || prm->grid_cols <= 0 || prm->grid_rows <= 0 || prm->levels <= 0 || prm->levels > levels ||
+        prm->barrier < 0 || prm->barrier > 254 || !(prm->detection_threshold >= 0.0f) ||
+        (long long)prm->grid_cols * prm->grid_rows > (1 << 24)) { set_err(ctx, "bad detector parameters"); return DSDTM_ERR_INVALID; }
+    if (n_frames == 0) return DSDTM_OK;
+    DetectArgs a;
+    memset(&a, 0, sizeof a);
+    for (int l = 0; l < prm->levels; ++l) {
+        if (width[l] <= 0 || height[l] <= 0 || stride[l] < width[l] || width[l] >= (1 << 14) || height[l] >= (1 << 14) ||
+            level_offset[l] + (size_t)stride[l] * height[l] > pyr_pitch) { set_err(ctx, "level %d does not fit", l); return DSDTM_ERR_INVALID; }
+        a.lv[l].w = width[l]; a.lv[l].h = height[l]; a.lv[l].stride = stride[l]; a.lv[l].off = (uint32_t)level_offset[l];
+    }
+    const size_t G = (size_t)prm->grid_cols * prm->grid_rows;
+    a.pyr = pyr; a.score = score_scratch; a.cell_key = key_scratch; a.occupied = grid_occupied;
+    a.cell_score = cell_score; a.cell_x = cell_x; a.cell_y = cell_y; a.cell_level = cell_level;
+    a.pyr_pitch = pyr_pitch; a.n_frames = n_frames; a.levels = prm->levels;
+    a.cell_size = prm->cell_size; a.grid_cols = prm->grid_cols; a.grid_rows = prm->grid_rows; a.barrier = prm->barrier;
+    a.detection_threshold = prm->detection_threshold;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(key_scratch, 0, (size_t)n_frames * G * 8, (hipStream_t)hip_stream));
+    HIP_TRY(ctx, detect_launch(a, (hipStream_t)hip_stream));
+    return DSDTM_OK;
+}
+
 // Diagnostic (tests): the FAST-10 score map and the non-max survivors of ONE 8-bit image, as the detector's
 // two passes produce them on the device. score/keep: width*height bytes each.
 extern "C" int dsdtm_debug_fast10(dsdtm_ctx* ctx, const uint8_t* img, int width, int height, int stride, int barrier,
@@ -834,7 +869,8 @@ extern "C" int dsdtm_debug_fast10(dsdtm_ctx* ctx, const uint8_t* img, int width,
     a.pyr = d; a.score = d + pitch; a.keep = d + 2 * pitch; a.cell_key = (unsigned long long*)(d + 3 * pitch);
     a.cell_size = 1 << 20; a.grid_cols = 1; a.grid_rows = 1; a.barrier = barrier; a.detection_threshold = 3.0e38f;
     a.lv[0].w = width; a.lv[0].h = height; a.lv[0].stride = width; a.lv[0].off = 0;
-    HIP_TRY(ctx, detect_launch(a, 1, ctx->stream));
+    a.pyr_pitch = pitch; a.n_frames = 1; a.levels = 1;
+    HIP_TRY(ctx, detect_launch(a, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(h, d + pitch, 2 * pitch, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(score, h, n);

@@ -185,51 +185,105 @@ __device__ __forceinline__ float shi_tomasi_wave(const uint8_t* __restrict__ img
     return 0.5f * (tr - sqrtf(disc));
 }
 
+// One thread per dword of the score map (4 pixels): almost every dword is zero and leaves at once.
+// (grid: x = dwords of a level-0 row / 64... tasks numbered linearly per level, y = level, z = frame)
 __global__ __launch_bounds__(256) void fast_select_kernel(const DetectArgs a) {
-    const int level = blockIdx.z;
+    const int level = blockIdx.y, frame = blockIdx.z;
     const LevelGeom lg = a.lv[level];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    if (y >= lg.h || (int)(blockIdx.x * blockDim.x) >= lg.w) return;       // whole block outside the level (block-uniform)
-    bool cand = false;
-    int k = 0;
-    if (x >= 3 && x < lg.w - 3 && y >= 3 && y < lg.h - 3) {
-        const uint8_t* __restrict__ sm = a.score + lg.off + (size_t)y * lg.stride + x;
-        const int s = *sm;
-        if (s) {
-            // nonmax_3x3.cpp:47-106: suppressed iff a neighbouring corner scores >= (ties suppress both)
-            const int st = lg.stride;
-            const int n0 = sm[-st - 1], n1 = sm[-st], n2 = sm[-st + 1], n3 = sm[-1], n4 = sm[1], n5 = sm[st - 1], n6 = sm[st], n7 = sm[st + 1];
-            if (imax(imax(imax(n0, n1), imax(n2, n3)), imax(imax(n4, n5), imax(n6, n7))) < s) {
-                if (a.keep) a.keep[lg.off + (size_t)y * lg.stride + x] = 1;
-                const int scale = 1 << level;
-                k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;      // :97-98
-                cand = k >= 0 && k < a.grid_cols * a.grid_rows && !(a.occupied && a.occupied[k]);   // :100
+    const int rowdw = (lg.w + 3) >> 2;                                    // dwords that hold a row's pixels
+    const int task = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)(blockIdx.x * blockDim.x) >= rowdw * lg.h) return;          // whole block outside the level (block-uniform)
+    const int y = task / rowdw, q = task - y * rowdw;
+    const uint8_t* __restrict__ smap = a.score + (size_t)frame * a.pyr_pitch + lg.off;
+    const uint8_t* __restrict__ img = a.pyr + (size_t)frame * a.pyr_pitch + lg.off;
+    const int cells = a.grid_cols * a.grid_rows;
+    unsigned cand = 0;                                                   // bit i: pixel 4 q + i is a surviving corner in a free cell
+    int kcell[4] = {0, 0, 0, 0};
+    if (task < rowdw * lg.h && y >= 3 && y < lg.h - 3) {
+        const uint8_t* __restrict__ srow = smap + (size_t)y * lg.stride + 4 * q;
+        uint32_t four = 0;                                               // the strip's scores (byte-wise where the row is not dword-aligned)
+        if (((lg.stride | lg.off) & 3) == 0) four = *(const uint32_t*)srow;
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (4 * q + i < lg.w) four |= (uint32_t)srow[i] << (8 * i);
+        }
+        if (four) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = 4 * q + i, s = (four >> (8 * i)) & 0xff;
+                if (!s || x < 3 || x >= lg.w - 3) continue;
+                // nonmax_3x3.cpp:47-106: suppressed iff a neighbouring corner scores >= (ties suppress both)
+                const uint8_t* __restrict__ sm = srow + i;
+                const int st = lg.stride;
+                const int n0 = sm[-st - 1], n1 = sm[-st], n2 = sm[-st + 1], n3 = sm[-1], n4 = sm[1], n5 = sm[st - 1], n6 = sm[st], n7 = sm[st + 1];
+                if (imax(imax(imax(n0, n1), imax(n2, n3)), imax(imax(n4, n5), imax(n6, n7))) < s) {
+                    if (a.keep) a.keep[lg.off + (size_t)y * lg.stride + x] = 1;
+                    const int scale = 1 << level;
+                    const int k = ((y * scale) / a.cell_size) * a.grid_cols + (x * scale) / a.cell_size;       // :97-98
+                    if (k >= 0 && k < cells && !(a.occupied && a.occupied[(size_t)frame * cells + k])) {     // :100
+                        cand |= 1u << i; kcell[i] = k;
+                    }
+                }
             }
         }
     }
-    // the survivors of this wave's 64 pixels, one after the other, each scored by all 64 lanes
-    unsigned long long todo = __ballot(cand);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int cx = __builtin_amdgcn_readlane(x, src);
-        const float sc = shi_tomasi_wave(a.pyr + lg.off, lg.w, lg.h, lg.stride, cx, y, lane);   // :103
-        if (lane == src && sc > a.detection_threshold) {                                        // :104 vs the initial score (:74)
-            // max score wins; among equal scores the first in (level, row, column) order, as the sequential
-            // loop's strict '>' leaves it
-            const unsigned order = ((unsigned)level << 28) | ((unsigned)y << 14) | (unsigned)x;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xffffffffu - order);
-            atomicMax(a.cell_key + k, key);
+    // the survivors of this wave's pixels, one after the other, each scored by all 64 lanes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long todo = __ballot((cand >> i) & 1u);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int cx = __builtin_amdgcn_readlane(4 * q + i, src), cy = __builtin_amdgcn_readlane(y, src);
+            const float sc = shi_tomasi_wave(img, lg.w, lg.h, lg.stride, cx, cy, lane);                        // :103
+            if (lane == src && sc > a.detection_threshold) {                                                    // :104 vs the initial score (:74)
+                // max score wins; among equal scores the first in (level, row, column) order, as the sequential
+                // loop's strict '>' leaves it
+                const unsigned order = ((unsigned)level << 28) | ((unsigned)cy << 14) | (unsigned)cx;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xffffffffu - order);
+                atomicMax(a.cell_key + (size_t)frame * cells + kcell[i], key);
+            }
         }
     }
 }
 
-hipError_t detect_launch(const DetectArgs& a, int levels, hipStream_t stream) {
-    const dim3 grid((unsigned)((a.lv[0].w + 255) / 256), (unsigned)a.lv[0].h, (unsigned)levels);
-    hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(fast_select_kernel, grid, dim3(256), 0, stream, a);
+// keys -> the four per-cell arrays the reference's `corners` vector holds (batch entry; the single-frame entries decode on the host)
+__global__ __launch_bounds__(256) void detect_decode_kernel(const DetectArgs a) {
+    const size_t n = (size_t)a.n_frames * a.grid_cols * a.grid_rows;
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const unsigned long long key = a.cell_key[k];
+    if (!key) { a.cell_score[k] = a.detection_threshold; a.cell_x[k] = 0; a.cell_y[k] = 0; a.cell_level[k] = 0; return; }   // :74
+    const uint32_t order = 0xffffffffu - (uint32_t)key;
+    const int L = (int)(order >> 28), y = (int)((order >> 14) & 0x3fffu), x = (int)(order & 0x3fffu);
+    a.cell_score[k] = __uint_as_float((uint32_t)(key >> 32));
+    a.cell_x[k] = x << L; a.cell_y[k] = y << L; a.cell_level[k] = L;                                  // :106
+}
+
+hipError_t detect_launch(const DetectArgs& a, hipStream_t stream) {
+    if (a.n_frames <= 0) return hipSuccess;
+    // levels whose rows are whole dwords take the strip kernel, the others (odd widths) one thread per pixel
+    unsigned strip_mask = 0, pixel_mask = 0;
+    int strip_tasks = 0;
+    for (int l = 0; l < a.levels; ++l) {
+        const bool strip = ((a.lv[l].w | a.lv[l].stride | (int)a.lv[l].off) & 3) == 0 && a.lv[l].w >= 16 && (a.pyr_pitch & 3) == 0;
+        if (strip) { strip_mask |= 1u << l; const int t = (a.lv[l].w >> 2) * ((a.lv[l].h + FS_ROWS - 1) / FS_ROWS); strip_tasks = t > strip_tasks ? t : strip_tasks; }
+        else pixel_mask |= 1u << l;
+    }
+    if (strip_mask)
+        hipLaunchKernelGGL(fast_score_strip_kernel, dim3((unsigned)((strip_tasks + 255) / 256), (unsigned)a.levels, (unsigned)a.n_frames),
+                           dim3(256), 0, stream, a, strip_mask);
+    if (pixel_mask)
+        hipLaunchKernelGGL(fast_score_kernel, dim3((unsigned)((a.lv[0].w + 255) / 256), (unsigned)a.lv[0].h, (unsigned)(a.levels * a.n_frames)),
+                           dim3(256), 0, stream, a, pixel_mask);
+    int sel_tasks = 0;
+    for (int l = 0; l < a.levels; ++l) { const int t = ((a.lv[l].w + 3) >> 2) * a.lv[l].h; sel_tasks = t > sel_tasks ? t : sel_tasks; }
+    hipLaunchKernelGGL(fast_select_kernel, dim3((unsigned)((sel_tasks + 255) / 256), (unsigned)a.levels, (unsigned)a.n_frames), dim3(256), 0, stream, a);
+    if (a.cell_score) {
+        const size_t n = (size_t)a.n_frames * a.grid_cols * a.grid_rows;
+        hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    }
     return hipGetLastError();
 }
 

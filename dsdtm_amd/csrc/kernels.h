@@ -72,18 +72,24 @@ hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t
 int sparse_align_occupancy(int variant);   // occupancy API answer (workgroups per CU)
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream);
 
-// Feature detector (per-cell part): FAST-10 score map, then non-max + Shi-Tomasi + best corner per cell.
+// Feature detector (per-cell part): FAST-10 score map, then non-max + Shi-Tomasi + best corner per cell — for
+// n_frames packed pyramids at once (frame f: pyr + f * pyr_pitch, score + f * pyr_pitch, cell_key / occupied / the
+// outputs + f * cells).
 struct DetectArgs {
-    const uint8_t* pyr;            // packed pyramid (device)
-    uint8_t* score;                // score maps, same layout as the pyramid
-    unsigned long long* cell_key;  // grid_cols*grid_rows keys, zeroed before the launch
-    const uint8_t* occupied;       // grid_cols*grid_rows, may be null
-    uint8_t* keep;                 // diagnostic (dsdtm_debug_fast10): 1 where a corner survives the non-max step; else null
+    const uint8_t* pyr;            // n_frames packed pyramids (device)
+    uint8_t* score;                // score maps, same layout and pitch as the pyramids
+    unsigned long long* cell_key;  // n_frames * cells keys, zeroed before the launch
+    const uint8_t* occupied;       // n_frames * cells, may be null
+    uint8_t* keep;                 // diagnostic (dsdtm_debug_fast10, one frame): 1 where a corner survives the non-max step; else null
+    // optional decoded outputs (batch entry; null: the host decodes the keys): n_frames * cells each
+    float* cell_score; int32_t* cell_x; int32_t* cell_y; int32_t* cell_level;
+    size_t pyr_pitch;
+    int n_frames, levels;
     int cell_size, grid_cols, grid_rows, barrier;
     float detection_threshold;
     LevelGeom lv[DSDTM_MAX_LEVELS];
 };
-hipError_t detect_launch(const DetectArgs& args, int levels, hipStream_t stream);
+hipError_t detect_launch(const DetectArgs& args, hipStream_t stream);
 
 // Align2D: one wavefront per feature.
 struct A2DKernelArgs {

@@ -228,6 +228,19 @@ int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame, const uin
                              const dsdtm_detect_params* params, float* cell_score, int32_t* cell_x,
                              int32_t* cell_y, int32_t* cell_level);
 
+/* The same for n_frames packed DEVICE pyramids at once (frame f at pyr + f * pyr_pitch, geometry as in
+ * dsdtm_pyrdown_batch_device): independent sequences — the config-4 style of use — batch their keyframes' detector
+ * work as they batch Run, pyramids, Align2D and the pose refinement. Every pointer is a device pointer; nothing is
+ * copied; asynchronous on hip_stream. grid_occupied: n_frames * cells bytes or NULL. score_scratch: n_frames * pyr_pitch
+ * bytes, key_scratch: n_frames * cells 64-bit words (both overwritten). Outputs: n_frames * cells entries each, the
+ * meaning of dsdtm_detect_cells' outputs. Replaces the image part of src/Feature_detection.cpp:69-154 per frame. */
+int dsdtm_detect_cells_batch_device(dsdtm_ctx* ctx, const uint8_t* pyr, size_t pyr_pitch, int n_frames, int levels,
+                                    const int* width, const int* height, const int* stride, const size_t* level_offset,
+                                    const uint8_t* grid_occupied, const dsdtm_detect_params* params,
+                                    uint8_t* score_scratch, unsigned long long* key_scratch,
+                                    float* cell_score, int32_t* cell_x, int32_t* cell_y, int32_t* cell_level,
+                                    void* hip_stream);
+
 
 /* ---- Optimizer::PoseOptimization ------------------------------ */
 /*

@@ -15,11 +15,15 @@ def test_algorithmic_bytes_are_the_surveys_figures():
     assert bench.algorithmic_bytes(1280, 960, 4, 2000) == 3378292
 
 
-def test_traffic_lookup_reads_the_committed_pmc_summary():
+def test_traffic_lookup_reads_the_committed_pmc_summary(monkeypatch):
     path = os.path.join(ROOT, bench.PMC_SUMMARY)
     assert os.path.exists(path), "profiles/ must carry the PMC summary bench.py quotes"
     with open(path) as f:
         d = json.load(f)
+    # the summary's numbers are only quoted for the binary they were taken with
+    monkeypatch.setattr(bench, "library_sha", lambda: "0" * 16)
+    assert bench.pmc_traffic("sparse_align_reg_kernel", 1024 * 833392) is None and bench.pmc_summary() == {}
+    monkeypatch.setattr(bench, "library_sha", lambda: d["profile_binary_sha"])
     rows = {(t["case"], int(t["algorithmic_bytes_per_launch"])): t for t in d["hbm_traffic_per_launch"]}
     main = rows[("solo", 1024 * 833392)]
     t = bench.pmc_traffic("sparse_align_reg_kernel", 1024 * 833392)
@@ -35,11 +39,13 @@ def test_usable_cpus_is_positive_and_bounded_by_the_machine():
     assert 1 <= n <= (os.cpu_count() or 1)
 
 
-def test_fp64_block_reads_the_committed_counter_pass():
+def test_fp64_block_reads_the_committed_counter_pass(monkeypatch):
     """The second roofline of the bench line (FP64 vector fraction) comes from the committed
     SQ_INSTS_VALU_*_F64 pass and only for the BASELINE workload."""
     import types
     import bench
+    with open(os.path.join(ROOT, bench.PMC_SUMMARY)) as f:
+        monkeypatch.setattr(bench, "library_sha", lambda sha=json.load(f)["profile_binary_sha"]: sha)
     a = types.SimpleNamespace(pairs=1024, patches=300, width=640, height=480, levels=4, iters=10)
     b = bench.fp64_block(a, 0.2)
     assert b["flops_per_launch"] is not None and 1e9 < b["flops_per_launch"] < 1e10

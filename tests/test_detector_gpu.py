@@ -137,3 +137,53 @@ def test_detect_honours_the_moving_object_mask(gpu_ctx):
     assert out[0] - inside <= out[1]
     extra = out[1] - out[0]
     assert all(200 - 26 <= x < 500 + 26 and 100 - 26 <= y < 300 + 26 for x, y in extra) and len(extra) < 20
+
+
+@pytest.mark.parametrize("size,levels,n", [((640, 480), 5, 6), ((752, 480), 4, 3)])
+def test_batch_entry_equals_the_oracle_frame_by_frame(gpu_ctx, oracle, size, levels, n):
+    """dsdtm_detect_cells_batch_device: n packed device pyramids in one call (strip kernel where the level rows are whole
+    dwords, one thread per pixel where they are not: 752 -> 94 -> 47 columns), every frame with its own occupancy
+    grid, against the oracle's cells frame by frame."""
+    import torch
+    from dsdtm_amd.feature_detection import Feature_detector
+    from dsdtm_amd.frame import Config
+    w, h = size
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(w + n)
+    imgs = [np.clip(np.rint(synth.make_texture(h, w, 300 + i)), 0, 255).astype(np.uint8) for i in range(n)]
+    if size == (752, 480):
+        imgs[0] = np.load(H.golden_path("fast_reference.npz"))["test1"]
+    pyrs = [synth.build_pyramid(im, levels) for im in imgs]
+    ws, hs, ss, offs, nbytes = capi.pyramid_layout(w, h, levels)
+    pitch = (nbytes + 255) // 256 * 256
+    packed = np.zeros((n, pitch), np.uint8)
+    for i, p in enumerate(pyrs):
+        for l in range(levels):
+            packed[i, offs[l]:offs[l] + ws[l] * hs[l]] = p[l].reshape(-1)
+    old = Config.Get("Camera.MaxPyraLevels")
+    Config.Set("Camera.MaxPyraLevels", levels)
+    try:
+        det = Feature_detector(w, h, ctx=gpu_ctx)
+    finally:
+        Config.Set("Camera.MaxPyraLevels", old)
+    G = det.mGrid_cols * det.mGrid_rows
+    occ = (rng.random((n, G)) < 0.1).astype(np.uint8)
+    prm = capi.DetectParams(det.mCell_size, det.mGrid_cols, det.mGrid_rows, levels, 20, 5.0)
+    d_pyr, d_occ = torch.from_numpy(packed).to(dev), torch.from_numpy(occ).to(dev)
+    d_score = torch.empty((n, pitch), dtype=torch.uint8, device=dev)
+    d_key = torch.empty((n, G), dtype=torch.int64, device=dev)
+    d_s = torch.empty((n, G), dtype=torch.float32, device=dev)
+    d_x, d_y, d_l = (torch.empty((n, G), dtype=torch.int32, device=dev) for _ in range(3))
+    wa, ha, sa = (C.c_int * levels)(*ws), (C.c_int * levels)(*hs), (C.c_int * levels)(*ss)
+    oa = (C.c_size_t * levels)(*offs)
+    for rep in range(2):                                        # the scratch is reusable from call to call
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_detect_cells_batch_device(
+            gpu_ctx.handle, d_pyr.data_ptr(), pitch, n, levels, wa, ha, sa, oa, d_occ.data_ptr(), C.byref(prm), d_score.data_ptr(),
+            d_key.data_ptr(), d_s.data_ptr(), d_x.data_ptr(), d_y.data_ptr(), d_l.data_ptr(), None))
+        torch.cuda.synchronize()
+    got = [t.cpu().numpy() for t in (d_s, d_x, d_y, d_l)]
+    for i in range(n):
+        want = oracle.detect_cells(pyrs[i], levels, det.mCell_size, det.mGrid_cols, det.mGrid_rows, occ[i], 5.0)
+        for g, wv, name in zip(got, want, ("score", "x", "y", "level")):
+            assert np.array_equal(g[i], wv), (i, name, np.nonzero(g[i] != wv)[0][:5])
+        assert (got[0][i] > 5.0).sum() > 20

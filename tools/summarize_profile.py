@@ -1,14 +1,16 @@
 """Folds the rocprofv3 output of tools/profile.sh (per case: kernel-trace stats, kernel trace, one --pmc pass per
 counter group) into the summaries kept under profiles/:
-    <out>/r02_kernel_stats.csv     per case and kernel: calls, average / min / max duration
-    <out>/r02_bench_pmc.json       per case and kernel: counters per dispatch + "hbm_traffic_per_launch" entries (what
+    <out>/r03_kernel_stats.csv     per case and kernel: calls, average / min / max duration
+    <out>/r03_bench_pmc.json       "profile_binary_sha": sha256 (16 hex digits) of the libdsdtm_amd.so the passes ran with —
+                                   bench.py reports these numbers only while it loads that same binary;
+                                   per case and kernel: counters per dispatch + "hbm_traffic_per_launch" entries (what
                                    bench.py's roofline.traffic reads): FETCH_SIZE and WRITE_SIZE are KiB per dispatch;
                                    FETCH_SIZE x 2 is the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md
-                                   (128-B requests tallied at 64 B)
-    <out>/r02_overlap.json         case "main" (several launch streams): begin/end of every dispatch of the alignment
-                                   kernel -> launches in flight, union span per launch (= the effective time per step)
+                                   (128-B requests tallied at 64 B);
+                                   "overlap": case "main" (several launch streams): begin/end of every dispatch of the
+                                   alignment kernel -> launches in flight, a launch's own duration, union span per launch
 Usage: python tools/summarize_profile.py gpurun_out/<dir>"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, sys
 
 src = sys.argv[1]
 ALG = {   # case -> (kernel substring, algorithmic bytes per launch, dispatches per launch)
@@ -17,8 +19,11 @@ ALG = {   # case -> (kernel substring, algorithmic bytes per launch, dispatches 
     "n2000": ("sparse_align", 256 * 3378292, 1),
     "kernels": ("pyrdown_kernel", 2048 * 504000, 3),
 }
-stats_rows, pmc = [], {"round": 2, "command": "tools/profile.sh (see the file for every command line)", "cases": {}, "hbm_traffic_per_launch": [],
-                       "fp64_per_launch": []}
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(REPO, "dsdtm_amd", "csrc", "libdsdtm_amd.so"), "rb") as f:
+    sha = hashlib.sha256(f.read()).hexdigest()[:16]
+stats_rows, pmc = [], {"round": 3, "profile_binary_sha": sha, "command": "tools/profile.sh (see the file for every command line)", "cases": {},
+                       "hbm_traffic_per_launch": [], "fp64_per_launch": [], "overlap": {}}
 for case in sorted(os.listdir(src)):
     d = os.path.join(src, case)
     if not os.path.isdir(d):
@@ -27,6 +32,8 @@ for case in sorted(os.listdir(src)):
         for r in csv.DictReader(open(f)):
             if "dsdtm" not in r["Name"]:
                 continue                              # torch's data-generation kernels are not ours to report
+            if case not in ("track", "poseopt", "kernels") and "sparse_align" not in r["Name"]:
+                continue                              # bench cases: the kernel of record only (pyramids there are set-up)
             stats_rows.append(dict(case=case, kernel=r["Name"], calls=r["Calls"], avg_ns=r["AverageNs"], min_ns=r["MinNs"],
                                    max_ns=r["MaxNs"], total_ns=r["TotalDurationNs"], percent=r["Percentage"]))
     ctr = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -60,12 +67,10 @@ for case in sorted(os.listdir(src)):
                     case=case, kernel=k, dispatches_per_launch=nd, algorithmic_bytes_per_launch=alg, fetch_bytes_raw=fetch,
                     fetch_bytes_gfx950_corrected=2.0 * fetch, write_bytes=write,
                     traffic_over_algorithmic=(2.0 * fetch + write) / alg))
-with open(os.path.join(src, "r02_kernel_stats.csv"), "w", newline="") as f:
+with open(os.path.join(src, "r03_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=["case", "kernel", "calls", "avg_ns", "min_ns", "max_ns", "total_ns", "percent"])
     w.writeheader()
     w.writerows(stats_rows)
-json.dump(pmc, open(os.path.join(src, "r02_bench_pmc.json"), "w"), indent=1)
-
 # overlap of consecutive launches on several streams (case main)
 ov = {}
 for f in glob.glob(f"{src}/main/trace/**/*_kernel_trace.csv", recursive=True):
@@ -88,7 +93,8 @@ for f in glob.glob(f"{src}/main/trace/**/*_kernel_trace.csv", recursive=True):
               own_duration_avg_ns=sum(e - s for s, e in zip(st, en)) / len(rows),
               union_span_ns=busy, union_span_per_launch_ns=busy / len(rows), launches_in_flight_avg=weighted / busy,
               first_start=st[0], last_end=max(en), wall_per_launch_ns=(max(en) - st[0]) / len(rows))
-json.dump(ov, open(os.path.join(src, "r02_overlap.json"), "w"), indent=1)
+pmc["overlap"] = ov
+json.dump(pmc, open(os.path.join(src, "r03_bench_pmc.json"), "w"), indent=1)
 print(json.dumps(ov, indent=1))
 print(json.dumps(pmc["hbm_traffic_per_launch"], indent=1))
 for r in stats_rows:
