@@ -421,7 +421,142 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
         "roofline": roofline_block("pyrdown", n_img * b_pyr, ms_avg, ms_min, n_img, b_pyr, "pyramid")})
     del pyr
     torch.cuda.empty_cache()
+    out += tracked_frame_entries(torch, dev, ctx, stream)
+    torch.cuda.empty_cache()
     out.append(streamed_entry(torch, dev, ctx, synth.Camera.tum(args.width, args.height), cam_struct_640, args))
+    return out
+
+
+def tracked_frame_entries(torch, dev, ctx, stream):
+    """The other kernels of a tracked frame, each as a device-resident batch with its own roofline block: Align2D
+    (src/Feature_alignment.cpp:318-417), the pose-only refinement (src/Optimizer.cpp:20-101) and the detector's image
+    work (src/Feature_detection.cpp:69-154). Device time by HIP events on the launch stream. (The warp prelude runs
+    inside dsdtm_match_candidates_frames; its device time is in profiles/r03_kernel_stats.csv, case `track`.)"""
+    from dsdtm_amd import capi, synth
+    from tests import helpers
+    out = []
+
+    def timed(fn, reps=20, warm=3):
+        for _ in range(warm):
+            fn()
+        stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        stream.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    # ---- Align2D: 262144 features on one 1280x960 3-level pyramid (config 5's refinement step, batched)
+    Wa, Ha, La, M, base = 1280, 960, 3, 262144, 4096
+    tex = np.clip(np.rint(synth.make_texture(Ha, Wa, 5)), 0, 255).astype(np.uint8)
+    pyr = synth.build_pyramid(tex, La)
+    ws, hs, ss, offs, nb = capi.pyramid_layout(Wa, Ha, La)
+    packed = np.zeros(nb, np.uint8)
+    for l in range(La):
+        packed[offs[l]:offs[l] + ws[l] * hs[l]] = pyr[l].reshape(-1)
+    rng = np.random.default_rng(0)
+    cs = np.stack([rng.uniform(20, Wa - 20, base), rng.uniform(20, Ha - 20, base)], 1)
+    pb, p = helpers.make_border_patches(pyr[0], cs)
+    rep_ = M // base
+    d_pyr = torch.from_numpy(packed).to(dev)
+    d_pb, d_p = torch.from_numpy(np.tile(pb, (rep_, 1))).to(dev), torch.from_numpy(np.tile(p, (rep_, 1))).to(dev)
+    d_px0 = torch.from_numpy(np.tile(cs, (rep_, 1)) + rng.uniform(-1.5, 1.5, (M, 2))).to(dev)
+    d_px = d_px0.clone()
+    d_lv = torch.zeros(M, dtype=torch.int32, device=dev)
+    d_cv = torch.zeros(M, dtype=torch.uint8, device=dev)
+    img = capi.ImageDesc()
+    img.levels = La
+    for l in range(La):
+        img.width[l], img.height[l], img.stride[l], img.level_offset[l] = ws[l], hs[l], ss[l], offs[l]
+    img.bytes, img.data = nb, d_pyr.data_ptr()
+
+    def a2d():
+        with torch.cuda.stream(stream):
+            d_px.copy_(d_px0, non_blocking=True)
+        ctx.check(ctx.lib.dsdtm_align2d_batch_device(ctx.handle, C.byref(img), d_pb.data_ptr(), d_p.data_ptr(), d_lv.data_ptr(), d_px.data_ptr(),
+                                                     d_cv.data_ptr(), 10, M, stream.cuda_stream))
+    ms = timed(a2d)
+    b_feat = 100 + 64 + 16 + 17                      # bordered patch + patch + pixel in/out + level and flag (SURVEY.md §8d)
+    alg = M * b_feat + ws[0] * hs[0]                 # + the level image the features sit on, once
+    out.append({"workload": f"Feature_Alignment::Align2DGaussNewton: {M} features per call on one {Wa}x{Ha} level, cap 10 iterations "
+                            f"(one wavefront per feature, float sums in the reference's order)",
+                "value": M / (ms * 1e-3), "unit": "features/s", "converged_fraction": float(d_cv.float().mean().item()),
+                "roofline": roofline_block("align2d", alg, ms, None, M, b_feat, "feature",
+                                           {"note": "latency-bound: <= 10 dependent iterations of 64 bilinear samples per wavefront; "
+                                                    "the bytes are 197 per feature + the level image once"})})
+    del d_pb, d_p, d_px0, d_px, d_lv, d_cv
+
+    # ---- pose-only refinement: 4096 frames x 200 features (observations on levels 0..3)
+    F_, N_, nb_ = 4096, 200, 64
+    probs = [synth.make_pose_problem(1000 + k, n=N_, max_level=3) for k in range(nb_)]
+    stack = lambda f: np.concatenate([np.stack([f(q) for q in probs])] * (F_ // nb_))
+    tdev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_b, d_w, d_l, d_u = tdev(stack(lambda q: q.bearing)), tdev(stack(lambda q: q.p_world)), tdev(stack(lambda q: q.level)), tdev(stack(lambda q: q.use))
+    d_T0 = tdev(stack(lambda q: q.T_seed.reshape(12)))
+    d_T = d_T0.clone()
+    d_rn = torch.zeros((F_, N_), dtype=torch.float64, device=dev)
+    d_sm = torch.zeros((F_, C.sizeof(capi.PoseOptSummary)), dtype=torch.uint8, device=dev)
+    pp = capi.PoseOptParams(100, 0)
+    fpo = ctx.lib.dsdtm_pose_optimization_batch_device
+    fpo.restype = C.c_int
+    fpo.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.POINTER(capi.PoseOptParams), C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def po():
+        with torch.cuda.stream(stream):
+            d_T.copy_(d_T0, non_blocking=True)
+        ctx.check(fpo(ctx.handle, F_, N_, None, d_b.data_ptr(), d_w.data_ptr(), d_l.data_ptr(), d_u.data_ptr(), d_T.data_ptr(), C.byref(pp),
+                      d_rn.data_ptr(), d_sm.data_ptr(), stream.cuda_stream))
+    ms = timed(po)
+    sms = [capi.PoseOptSummary.from_buffer_copy(r.tobytes()) for r in d_sm.cpu().numpy()]
+    its = np.array([q.iterations for q in sms])
+    blocks = np.array([q.n_residual_blocks for q in sms])
+    flops = float(((its + 1) * blocks).sum()) * 330.0       # block evaluations x ~330 FP64 flops each (DESIGN.md §3.7)
+    tf = flops / (ms * 1e-3) / 1e12
+    out.append({"workload": f"Optimizer::PoseOptimization: {F_} frames x {N_} features per call (Ceres trust-region LM restated, "
+                            f"{its.mean():.1f} iterations on average), one wavefront per frame",
+                "value": F_ / (ms * 1e-3), "unit": "refinements/s",
+                "roofline": {"bound": "fp64_vector", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "kernel": "pose_opt_kernel", "kernel_ms_avg": ms,
+                             "flops_per_launch": flops,
+                             "note": "~330 FP64 flops per residual-block evaluation x (iterations + 1) x blocks; the features of a frame "
+                                     "(11 KB) stay in L1/L2: bound by the latency of its dependent FP64 chain, not by HBM"}})
+    del d_b, d_w, d_l, d_u, d_T0, d_T, d_rn, d_sm
+
+    # ---- detector image work: 256 frames of 640x480x5 levels per call
+    Wd, Hd, Ld, nfr = 640, 480, 5, 256
+    ws, hs, ss, offs, nb = capi.pyramid_layout(Wd, Hd, Ld)
+    pitch = (nb + 255) // 256 * 256
+    packed = np.zeros((8, pitch), np.uint8)
+    for i in range(8):
+        pyr = synth.build_pyramid(np.clip(np.rint(synth.make_texture(Hd, Wd, 40 + i)), 0, 255).astype(np.uint8), Ld)
+        for l in range(Ld):
+            packed[i, offs[l]:offs[l] + ws[l] * hs[l]] = pyr[l].reshape(-1)
+    cell = 25
+    gc, gr = (Wd + cell - 1) // cell, (Hd + cell - 1) // cell
+    G = gc * gr
+    dp = capi.DetectParams(cell, gc, gr, Ld, 20, 5.0)
+    d_pyr = torch.from_numpy(np.tile(packed, (nfr // 8, 1))).to(dev)
+    d_score = torch.empty((nfr, pitch), dtype=torch.uint8, device=dev)
+    d_key = torch.empty((nfr, G), dtype=torch.int64, device=dev)
+    d_s = torch.empty((nfr, G), dtype=torch.float32, device=dev)
+    d_x, d_y, d_lv = (torch.empty((nfr, G), dtype=torch.int32, device=dev) for _ in range(3))
+    wa, ha, sa, oa = (C.c_int * Ld)(*ws), (C.c_int * Ld)(*hs), (C.c_int * Ld)(*ss), (C.c_size_t * Ld)(*offs)
+
+    def det():
+        ctx.check(ctx.lib.dsdtm_detect_cells_batch_device(ctx.handle, d_pyr.data_ptr(), pitch, nfr, Ld, wa, ha, sa, oa, None, C.byref(dp),
+                                                          d_score.data_ptr(), d_key.data_ptr(), d_s.data_ptr(), d_x.data_ptr(), d_y.data_ptr(),
+                                                          d_lv.data_ptr(), stream.cuda_stream))
+    ms = timed(det)
+    b_fr = 3 * sum(ws[l] * hs[l] for l in range(Ld))     # pyramid read by the score pass, score map written, then read by the select pass
+    out.append({"workload": f"Feature_detector::detect, image part: {nfr} frames of {Wd}x{Hd}x{Ld} levels per call (FAST-10 score map, non-max, "
+                            f"Shi-Tomasi, best corner per {cell}-px cell)",
+                "value": nfr / (ms * 1e-3), "unit": "frames/s", "us_per_frame": ms * 1e3 / nfr,
+                "cells_with_a_corner_per_frame": float((d_s > 5.0).sum().item()) / nfr,
+                "roofline": roofline_block("fast_", nfr * b_fr, ms, None, nfr, b_fr, "frame",
+                                           {"note": "three launches (score, select, decode); the score pass is bound by its min/max network "
+                                                    "(~95 VALU instructions per pixel), the select pass by the serial Shi-Tomasi scoring of a wave's corners"})})
     return out
 
 

@@ -185,33 +185,38 @@ __device__ __forceinline__ float shi_tomasi_wave(const uint8_t* __restrict__ img
     return 0.5f * (tr - sqrtf(disc));
 }
 
-// One thread per dword of the score map (4 pixels): almost every dword is zero and leaves at once.
-// (grid: x = dwords of a level-0 row / 64... tasks numbered linearly per level, y = level, z = frame)
+// PX = 4: one thread per dword of the score map — almost every dword is zero and leaves at once (batches: the pass is
+// bound by the map's bytes). PX = 1: one thread per pixel — a wave then holds a quarter of the candidates, and the
+// serial scoring loop below, which sets the duration of a one-frame launch, is a quarter as long (live tracker).
+// (tasks numbered linearly per level; grid y = level, z = frame)
+template <int PX>
 __global__ __launch_bounds__(256) void fast_select_kernel(const DetectArgs a) {
     const int level = blockIdx.y, frame = blockIdx.z;
     const LevelGeom lg = a.lv[level];
     const int lane = threadIdx.x & 63;
-    const int rowdw = (lg.w + 3) >> 2;                                    // dwords that hold a row's pixels
+    const int rowdw = (lg.w + PX - 1) / PX;                               // tasks per row (PX = 4: the dwords that hold its pixels)
     const int task = blockIdx.x * blockDim.x + threadIdx.x;
     if ((int)(blockIdx.x * blockDim.x) >= rowdw * lg.h) return;          // whole block outside the level (block-uniform)
     const int y = task / rowdw, q = task - y * rowdw;
     const uint8_t* __restrict__ smap = a.score + (size_t)frame * a.pyr_pitch + lg.off;
     const uint8_t* __restrict__ img = a.pyr + (size_t)frame * a.pyr_pitch + lg.off;
     const int cells = a.grid_cols * a.grid_rows;
-    unsigned cand = 0;                                                   // bit i: pixel 4 q + i is a surviving corner in a free cell
-    int kcell[4] = {0, 0, 0, 0};
+    unsigned cand = 0;                                                   // bit i: pixel PX q + i is a surviving corner in a free cell
+    int kcell[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) kcell[i] = 0;
     if (task < rowdw * lg.h && y >= 3 && y < lg.h - 3) {
-        const uint8_t* __restrict__ srow = smap + (size_t)y * lg.stride + 4 * q;
-        uint32_t four = 0;                                               // the strip's scores (byte-wise where the row is not dword-aligned)
-        if (((lg.stride | lg.off) & 3) == 0) four = *(const uint32_t*)srow;
+        const uint8_t* __restrict__ srow = smap + (size_t)y * lg.stride + PX * q;
+        uint32_t four = 0;                                               // the task's scores (byte-wise where the row is not dword-aligned)
+        if (PX == 4 && ((lg.stride | lg.off) & 3) == 0) four = *(const uint32_t*)srow;
         else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (4 * q + i < lg.w) four |= (uint32_t)srow[i] << (8 * i);
+            for (int i = 0; i < PX; ++i) if (PX * q + i < lg.w) four |= (uint32_t)srow[i] << (8 * i);
         }
         if (four) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int x = 4 * q + i, s = (four >> (8 * i)) & 0xff;
+            for (int i = 0; i < PX; ++i) {
+                const int x = PX * q + i, s = (four >> (8 * i)) & 0xff;
                 if (!s || x < 3 || x >= lg.w - 3) continue;
                 // nonmax_3x3.cpp:47-106: suppressed iff a neighbouring corner scores >= (ties suppress both)
                 const uint8_t* __restrict__ sm = srow + i;
@@ -230,12 +235,12 @@ __global__ __launch_bounds__(256) void fast_select_kernel(const DetectArgs a) {
     }
     // the survivors of this wave's pixels, one after the other, each scored by all 64 lanes
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PX; ++i) {
         unsigned long long todo = __ballot((cand >> i) & 1u);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const int cx = __builtin_amdgcn_readlane(4 * q + i, src), cy = __builtin_amdgcn_readlane(y, src);
+            const int cx = __builtin_amdgcn_readlane(PX * q + i, src), cy = __builtin_amdgcn_readlane(y, src);
             const float sc = shi_tomasi_wave(img, lg.w, lg.h, lg.stride, cx, cy, lane);                        // :103
             if (lane == src && sc > a.detection_threshold) {                                                    // :104 vs the initial score (:74)
                 // max score wins; among equal scores the first in (level, row, column) order, as the sequential
@@ -277,9 +282,12 @@ hipError_t detect_launch(const DetectArgs& a, hipStream_t stream) {
     if (pixel_mask)
         hipLaunchKernelGGL(fast_score_kernel, dim3((unsigned)((a.lv[0].w + 255) / 256), (unsigned)a.lv[0].h, (unsigned)(a.levels * a.n_frames)),
                            dim3(256), 0, stream, a, pixel_mask);
+    const int px = a.n_frames >= 8 ? 4 : 1;
     int sel_tasks = 0;
-    for (int l = 0; l < a.levels; ++l) { const int t = ((a.lv[l].w + 3) >> 2) * a.lv[l].h; sel_tasks = t > sel_tasks ? t : sel_tasks; }
-    hipLaunchKernelGGL(fast_select_kernel, dim3((unsigned)((sel_tasks + 255) / 256), (unsigned)a.levels, (unsigned)a.n_frames), dim3(256), 0, stream, a);
+    for (int l = 0; l < a.levels; ++l) { const int t = ((a.lv[l].w + px - 1) / px) * a.lv[l].h; sel_tasks = t > sel_tasks ? t : sel_tasks; }
+    const dim3 sel_grid((unsigned)((sel_tasks + 255) / 256), (unsigned)a.levels, (unsigned)a.n_frames);
+    if (px == 4) hipLaunchKernelGGL(fast_select_kernel<4>, sel_grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(fast_select_kernel<1>, sel_grid, dim3(256), 0, stream, a);
     if (a.cell_score) {
         const size_t n = (size_t)a.n_frames * a.grid_cols * a.grid_rows;
         hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);

@@ -13,6 +13,7 @@ n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 ctx = capi.default_context(0)
 bad = soft = 0
 n_deg = bad_deg = soft_deg = 0
+erase_qr = erase_qr_deg = qr_deg = 0       # kernel vs the QR form: EraseFound decisions (src/Optimizer.cpp:80-92), iterations / termination
 its = []
 t0 = time.time()
 for seed in range(n_cfg):
@@ -36,6 +37,11 @@ for seed in range(n_cfg):
     if not ok:
         bad += 1; bad_deg += deg
         print("MISMATCH vs normal-equation form: seed", seed, kw, ang, dt, {k: (sg[k], sc[k]) for k in ("iterations", "successful_steps", "termination")}, flush=True)
+    thr = 2.0 / 525.0                      # Optimization.LocalBAthreshhold / Camera.f (src/Optimizer.cpp:22-24, Config/default.yaml:61,94)
+    if not np.array_equal(np.asarray(rn) > thr, np.asarray(rq) > thr):
+        erase_qr += 1; erase_qr_deg += deg
+    if deg and not all(sg[k] == sq[k] for k in ("iterations", "successful_steps", "termination")):
+        qr_deg += 1
     aq, dq = synth.pose_error(Tc, Tq)
     if not (all(sq[k] == sc[k] for k in ("iterations", "successful_steps", "termination")) and aq < 1e-8 and dq < 1e-8):
         soft += 1; soft_deg += deg
@@ -44,3 +50,6 @@ print(f"{n_cfg} random problems in {time.time()-t0:.1f} s, iterations mean {np.m
 print(f"  well-posed ({n_cfg - n_deg}): kernel vs normal-equation restatement {bad - bad_deg} mismatches; QR form vs normal-equation form {soft - soft_deg}", flush=True)
 print(f"  collinear map points ({n_deg}, rank-deficient: the iteration wanders along the null space and amplifies rounding): "
       f"kernel vs restatement {bad_deg} differ; the two CPU forms differ on {soft_deg}", flush=True)
+print(f"  kernel vs the QR form (Ceres' arithmetic): EraseFound decisions (residual norm > threshold, src/Optimizer.cpp:80-92) differ on "
+      f"{erase_qr - erase_qr_deg} well-posed and {erase_qr_deg} collinear problems; iterations / termination differ on {qr_deg} collinear ones "
+      f"(the QR form against ITSELF with the features in reversed order: 10 of 100, tools/pose_opt_order_sensitivity.py)", flush=True)
