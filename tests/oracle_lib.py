@@ -51,7 +51,10 @@ def load(native: bool = False):
     name = f"liboracle_native_{_cpu_tag()}.so" if native else "liboracle.so"
     path = os.path.join(_ORACLE_DIR, "_build", name)
     srcs = [os.path.join(_ORACLE_DIR, f) for f in ("dsdtm_oracle.c", "pose_opt_oracle.c", "dsdtm_oracle.h")]
-    if not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
+    override = os.environ.get("DSDTM_ORACLE_LIB")       # the sanitizer job (tests/test_sanitizers_cpu.py) runs the oracle's own
+    if override and not native:                          # CPU tests against an ASan/UBSan build of the same sources
+        path = override
+    elif not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
         build(native)
     lib = C.CDLL(path)
     capi.declare_signatures(lib, "oracle_", with_ctx=False)
