@@ -88,6 +88,7 @@ const OptionKey kOptionKeys[] = {
     {"team_spread_min", "DSDTM_TEAM_SPREAD_MIN", &dsdtm::Options::team_spread_min, false},
     {"ws_from", "DSDTM_WS_FROM", &dsdtm::Options::ws_from, false},
     {"ws_no_windows", "DSDTM_WS_NO_WINDOWS", &dsdtm::Options::ws_no_windows, true},
+    {"ws_no_duo", "DSDTM_WS_NO_DUO", &dsdtm::Options::ws_no_duo, true},
     {"pyr_fused", "DSDTM_PYR_FUSED", &dsdtm::Options::pyr_fused, false},
     {"pyr_band", "DSDTM_PYR_BAND", &dsdtm::Options::pyr_band, false},
     {"no_zero_copy", "DSDTM_NO_ZERO_COPY", &dsdtm::Options::no_zero_copy, true},

@@ -46,6 +46,7 @@ struct Options {
     int team_spread_min = 33;  // DSDTM_TEAM_SPREAD_MIN: team size from which members are spread over all XCDs
     int ws_from = 704;         // DSDTM_WS_FROM: feature counts above this run the workspace kernel in batches
     int ws_no_windows = 0;     // DSDTM_WS_NO_WINDOWS
+    int ws_no_duo = 0;         // DSDTM_WS_NO_DUO: 1025..2048 patches on one compute unit (HBM workspace) instead of two
     int pyr_fused = 1;         // DSDTM_PYR_FUSED: 0 never / 1 up to 32 images / 2 whenever the shape allows
     int pyr_band = 0;          // DSDTM_PYR_BAND: rows of the coarsest level per workgroup of the fused kernel (0: auto)
     int no_zero_copy = 0;      // DSDTM_NO_ZERO_COPY: single-call entry points copy instead of mapping the pinned block

@@ -961,7 +961,7 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
 // Solver wave, after the new R/t/ctrl have been published: the part of the iteration nobody waits for.
 // T_c2r = T_c2r * SE3::exp(x) on the quaternion state (:335), its rotation matrix for the next step,
 // tT_c2rOld and chi2 (:313-314), and the statistics.
-__device__ __forceinline__ void solver_commit(const SAKernelArgs& a, int pair, BlockState& s, int lane, const SolverCarry& c) {
+__device__ __forceinline__ void solver_commit(const SAKernelArgs& a, int pair, BlockState& s, int lane, const SolverCarry& c, bool write_stats = true) {
     if (c.fast) {
         const SE3d dT = se3_exp(c.x);
         __builtin_amdgcn_sched_barrier(0);
@@ -978,7 +978,7 @@ __device__ __forceinline__ void solver_commit(const SAKernelArgs& a, int pair, B
             s.chi2 = c.chi2_new;
         }
     }
-    if (lane == 0 && a.stats && (c.ctrl || c.it == a.max_iters - 1)) {
+    if (lane == 0 && write_stats && a.stats && (c.ctrl || c.it == a.max_iters - 1)) {
         dsdtm_align_stats* st = a.stats + pair;
         st->iters[c.level] = c.it + 1;
         st->n_ref[c.level] = c.n_ref;
@@ -1403,40 +1403,66 @@ __device__ __forceinline__ void ws_patch_regs(const WsPatch& w, const LevelGeom&
 // PARK_LDS: the parked grid inputs (88 B per patch) live in LDS behind the windows instead of the HBM workspace —
 // up to 1024 patches (4 + 60 + 88 KB of dynamic LDS: one workgroup per compute unit), nothing of a pass touches HBM
 // but the pose; without it a pass streams them from the workspace (written once per level, re-read every pass).
-template <int NPW, int WCAP, bool PARK_LDS = false>
+// MEMBERS = 2 (with PARK_LDS, 1025..2048 patches): ONE pair on TWO workgroups = two compute units, each with its half
+// of the patches wholly in its LDS. Per Gauss-Newton iteration the two solving waves exchange their workgroup's partial
+// (30 doubles) through tagged 64-bit words in HBM — the team kernel's exchange: the tag is the iteration number, a
+// reader that finds it holds that iteration's payload, two banks by parity — and both run the same solver_step on the
+// same two partials in the same order: the same pose on both, bit for bit, without a broadcast; member 0 writes the
+// results. Unlike the team kernel's launches these are BATCHES (more workgroups than compute units), so the members
+// of a pair must not wait for each other across the dispatch order: members are blocks b and b + 8 — the same XCD,
+// and consecutive in that XCD's in-order dispatch queue — so at most one pair per XCD is ever split at the leading
+// edge of what is resident, and the complete pairs behind it always finish and free its partner's compute unit.
+// Every wait is bounded (spin limit -> timeout flag -> the pair stops and drains its barriers).
+constexpr int DUO_WPD = sizeof(WavePartial) / sizeof(double);
+constexpr size_t DUO_BYTES = 2 * 2 * DUO_WPD * 2 * sizeof(unsigned long long);      // banks x members x words
+template <int NPW, int WCAP, bool PARK_LDS = false, int MEMBERS = 1>
 __global__ __launch_bounds__(NPW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void sparse_align_ws_kernel(const SAKernelArgs a) {
+    static_assert(MEMBERS == 1 || (MEMBERS == 2 && PARK_LDS), "two members: everything of a half in LDS");
     constexpr int PT = NPW * 64;   // patch threads
     constexpr int SW = NPW - 1;    // the wave that also solves
     __shared__ WavePartial s_part[NPW];
+    __shared__ WavePartial s_mpart[MEMBERS == 2 ? 2 : 1];              // two members: one partial per member, member order
     __shared__ BlockState s;
     extern __shared__ __attribute__((aligned(16))) uint32_t ws_win[];   // [16][WCAP]: 15 window planes + origins
 
-    const int pair = blockIdx.x;
+    int pair = blockIdx.x, member = 0;
+    if constexpr (MEMBERS == 2) {
+        const int r = (int)blockIdx.x & 15;
+        member = r >> 3;
+        pair = ((int)blockIdx.x >> 4) * 8 + (r & 7);
+        if (pair >= a.n_pairs) return;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nf = a.n_features ? a.n_features[pair] : a.max_features;
 
-    if (nf < a.min_fts || a.max_level - 1 < a.min_level) {
-        if (tid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
+    if (nf < a.min_fts || a.max_level - 1 < a.min_level) {             // the same decision in both members
+        if (member == 0 && tid == 0) { a.n_tracked[pair] = 0; stats_clear(a, pair); }
         return;
     }
 
     const bool solves = wave == SW;
     if (solves) {
         solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
-        if (lane == 0) stats_clear(a, pair);
+        if (member == 0 && lane == 0) stats_clear(a, pair);
     }
 
     const uint8_t* __restrict__ ref_base = a.ref_pyr + (size_t)pair * a.pyr_pitch;
     const uint8_t* __restrict__ cur_base = a.cur_pyr + (size_t)pair * a.pyr_pitch;
     const size_t npad = ((size_t)a.max_features + 63) / 64 * 64;
+    // this workgroup's patches [p0, p1); their LDS entries are indexed by p - p0
+    const int half = MEMBERS == 2 ? (int)((npad / 64 + 1) / 2) * 64 : (int)npad;
+    const int p0 = member * half, p1 = (int)npad < p0 + half ? (int)npad : p0 + half;
     const size_t pstride = PARK_LDS ? (size_t)WCAP : npad;                        // dwords between two parked planes
     auto ws = [&]() {
         if constexpr (PARK_LDS) return (LdsU32*)(ws_win + 16 * WCAP);
         else return (uint32_t*)(a.workspace + (size_t)pair * ws_doubles_per_pair(a.max_features));
     }();
+    unsigned long long* const twords = MEMBERS == 2 ? (unsigned long long*)((char*)a.workspace + (size_t)pair * DUO_BYTES) : nullptr;
+    unsigned g_it = 0;                                                 // iterations so far, over all levels (tag of the exchange)
+    bool dead = false;                                                 // a wait for the partner ran out: drain, keep the barriers matched
     __syncthreads();                                                   // B0
 
     for (int level = a.max_level - 1; level >= a.min_level; --level) {
@@ -1453,8 +1479,9 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
         }
         {
             const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
-            for (int p = tid; p < (int)npad; p += PT) {
-                if constexpr (WCAP > 0) ws_win[15 * WCAP + p] = WIN_EMPTY;      // the level's windows are filled by its first pass
+            for (int p = p0 + tid; p < p1; p += PT) {
+                const int lp = p - p0;
+                if constexpr (WCAP > 0) ws_win[15 * WCAP + lp] = WIN_EMPTY;     // the level's windows are filled by its first pass
                 WsPatch w;
                 w.F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + p, p < nf), Cref);
                 const RefGeom g = ref_geom(w.F, lg, level);
@@ -1464,7 +1491,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                     ref_rows_unpack(a, lg, g, rows, w.rlo, w.rhi);
                 }
                 w.F.ok = g.valid;
-                ws_store(ws, pstride, p, w);          // read back only by this same thread
+                ws_store(ws, pstride, PARK_LDS ? lp : p, w);          // read back only by this same thread
                 n_valid_lane += g.valid ? 1 : 0;
             }
         }
@@ -1474,26 +1501,27 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
         // level's first pass and again only when a lane of this wave sees a patch enter or leave the image —
         // the same numbers the reference recomputes every iteration (:289-291), bit for bit.
         unsigned long long vis_old = 0ull;
-        const bool maskable = npad <= (size_t)PT * 64;                 // one bit per patch of this lane
+        const bool maskable = (size_t)(p1 - p0) <= (size_t)PT * 64;    // one bit per patch of this lane
         for (int it = 0; it < a.max_iters; ++it) {
             double b[6] = {0, 0, 0, 0, 0, 0};
             double chi2 = 0.0;
             int cnt = 0;
             unsigned long long vis_new = 0ull, bit = 1ull;
-            for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
+            for (int p = p0 + tid; p < p1; p += PT, bit <<= 1) {
+                const int lp = p - p0;
                 PatchRegs P;
                 {
                     WsPatch w;
-                    ws_load(ws, pstride, p, w);
+                    ws_load(ws, pstride, PARK_LDS ? lp : p, w);
                     ws_patch_regs(w, lg, level, P);
                 }
                 double c2, bp[6];
                 bool vis;
                 if constexpr (WCAP > 0) {
-                    uint32_t worg = ws_win[15 * WCAP + p];
+                    uint32_t worg = ws_win[15 * WCAP + lp];
                     const uint32_t worg0 = worg;
-                    vis = residual_patch<WCAP>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp, (LdsU32*)&ws_win[p], &worg);
-                    if (worg != worg0) ws_win[15 * WCAP + p] = worg;
+                    vis = residual_patch<WCAP>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp, (LdsU32*)&ws_win[lp], &worg);
+                    if (worg != worg0) ws_win[15 * WCAP + lp] = worg;
                 } else {
                     vis = residual_patch<>(a, lg, scale, fs, cur_base, P, s.u.R, s.u.tt, c2, bp);
                 }
@@ -1514,16 +1542,17 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
 #pragma unroll
                 for (int i = 0; i < 21; ++i) H[i] = 0.0;
                 bit = 1ull;
-                for (int p = tid; p < (int)npad; p += PT, bit <<= 1) {
+                for (int p = p0 + tid; p < p1; p += PT, bit <<= 1) {
+                    const int lp = PARK_LDS ? p - p0 : p;
                     PatchRegs P;
                     if (maskable) {
                         if (!(vis_new & bit)) continue;
                         WsPatch w;
-                        ws_load(ws, pstride, p, w);
+                        ws_load(ws, pstride, lp, w);
                         ws_patch_regs(w, lg, level, P);
                     } else {                                           // more patches per lane than mask bits: project again
                         WsPatch w;
-                        ws_load(ws, pstride, p, w);
+                        ws_load(ws, pstride, lp, w);
                         ws_patch_regs(w, lg, level, P);
                         double u, v;
                         if (!P.valid || !project_patch(a, lg, scale, P.X, s.u.R, s.u.tt, u, v)) continue;
@@ -1558,14 +1587,74 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                 const int li = lane < 6 ? lane : 5;
 #pragma unroll
                 for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];
-                (void)solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry);
+                if constexpr (MEMBERS == 2) {
+                    carry.fast = false;
+                    if (dead) {
+                        if (lane == 0) s.ctrl = 1;
+                    } else {
+                        // this workgroup's partial: lane i < WPD folds double i of its wave partials in wave order (doubles 7
+                        // and 8 are the packed counters: cnt | h_changed and n_ref | pad), publishes it as tagged words and
+                        // polls the partner's
+                        const unsigned long long tag = (unsigned long long)(g_it + 1u) << 32;
+                        unsigned long long* const bank = twords + (size_t)(g_it & 1u) * 2 * DUO_WPD * 2;
+                        if (lane < DUO_WPD) {
+                            unsigned long long raw;
+                            if (lane == 7 || lane == 8) {
+                                int lo = 0, hi = 0;
+#pragma unroll
+                                for (int w = 0; w < NPW; ++w) {
+                                    const int* q = (const int*)((const double*)&s_part[w] + lane);
+                                    lo += q[0];
+                                    hi |= (lane == 7) ? q[1] : 0;
+                                }
+                                raw = (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
+                            } else {
+                                double acc = 0.0;
+#pragma unroll
+                                for (int w = 0; w < NPW; ++w) acc += ((const double*)&s_part[w])[lane];
+                                raw = (unsigned long long)__double_as_longlong(acc);
+                            }
+                            ((unsigned long long*)&s_mpart[member])[lane] = raw;
+                            unsigned long long* dst = bank + ((size_t)member * DUO_WPD + lane) * 2;
+                            __hip_atomic_store(dst, (raw & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(dst + 1, (raw >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        // (~1 s of polling: a partner is at most one pair's duration — milliseconds — behind in the dispatch order)
+                        const unsigned spin_limit = a.spin_limit ? a.spin_limit : (1u << 20);
+                        const int other = member ^ 1;
+                        unsigned spins = 0;
+                        for (;;) {
+                            bool pending = false;
+                            if (lane < DUO_WPD) {
+                                const unsigned long long* src = bank + ((size_t)other * DUO_WPD + lane) * 2;
+                                const unsigned long long w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((w0 & 0xffffffff00000000ull) != tag || (w1 & 0xffffffff00000000ull) != tag) pending = true;
+                                else ((unsigned long long*)&s_mpart[other])[lane] = (w0 & 0xffffffffull) | (w1 << 32);
+                            }
+                            if (__ballot(pending) == 0ull) break;
+                            if (++spins >= spin_limit) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        const bool ok = spins < spin_limit;
+                        if (!ok) spin_timeout();
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        (void)solver_step<2>(a, pair, level, it, s_mpart, s, lane, hrow, carry);
+                        if (!ok) { dead = true; carry.fast = false; if (lane == 0) s.ctrl = 1; }
+                    }
+                    ++g_it;
+                } else {
+                    (void)solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry);
+                }
             }
             __syncthreads();                                           // B2
-            if (solves) solver_commit(a, pair, s, lane, carry);
+            if (solves && !(MEMBERS == 2 && dead)) solver_commit(a, pair, s, lane, carry, member == 0);   // member 0 alone writes statistics
             if (s.ctrl) break;
         }
     }
-    if (solves) {
+    if (solves && member == 0) {
         solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
         report_timeout(a, lane);
     }
@@ -1843,6 +1932,7 @@ SAVariant sparse_align_pick_variant(int max_features) {
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
     if (sparse_align_pick_variant(max_features) != SA_WS) return 0;
     if (!options().ws_no_windows && (max_features + 63) / 64 * 64 <= 1024) return 0;     // parked in LDS
+    // (1025..2048 patches: the two-member kernel needs DUO_BYTES per pair, less than the parking space reserved here)
     return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
 }
 
@@ -1904,6 +1994,19 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (attr != hipSuccess) return attr;
                 hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024, true>), grid, dim3(WS_THREADS), lds, stream, args);
+            } else if (ws_windows && npad <= 2048 && !options().ws_no_duo && args.workspace &&
+                       2 * (((npad / 64 + 1) / 2 * 64 + WS_THREADS - 1) / WS_THREADS) <= (npad + WS_THREADS - 1) / WS_THREADS) {
+                // (only where two halves cost no more lane rounds than the whole: 2000 patches = 2 x 2 rounds of 512 lanes
+                // against 4; 1500 patches would be 2 x 2 against 3 — measured 10 % slower on two compute units)
+                // one pair on two compute units, each half wholly in LDS; the exchange words are zeroed per launch
+                constexpr size_t lds = (16 + WS_DWORDS) * 1024 * sizeof(uint32_t);
+                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 1024, true, 2>,
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (attr != hipSuccess) return attr;
+                const hipError_t ez = hipMemsetAsync(args.workspace, 0, (size_t)args.n_pairs * DUO_BYTES, stream);
+                if (ez != hipSuccess) return ez;
+                const dim3 grid2((unsigned)((args.n_pairs + 7) / 8 * 16));
+                hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024, true, 2>), grid2, dim3(WS_THREADS), lds, stream, args);
             } else if (ws_windows && npad <= 2048) {
                 static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 2048>,
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * sizeof(uint32_t));

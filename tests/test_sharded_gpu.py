@@ -166,3 +166,61 @@ def test_chained_batch_equals_per_pair_runs(gpu_ctx, oracle):
         To, no, _ = oracle.sparse_align(sc, L, 0, 10)
         H.assert_pose_close(got[0][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"chained pair {i}")
         assert got[1][i] == no
+
+
+@pytest.mark.gpu
+def test_more_contexts_than_pairs_and_ragged_feature_counts(gpu_ctx, oracle):
+    """Shards may be empty (5 contexts, 3 pairs) and pairs may carry different live feature counts (n_features)."""
+    W, Hh, L = 320, 240, 3
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=150, seed=4100 + i, margin=12) for i in range(3)]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    a, b, _ = _host_batch(scenes, L, W, Hh)
+    nf = np.array([150, 90, 10], np.int32)                       # the last one is below Min_fts: n_tracked 0, pose untouched
+    b.n_features = nf.ctypes.data
+    ctxs = [capi.Context(0) for _ in range(5)]
+    arr = (C.c_void_p * 5)(*[c.handle for c in ctxs])
+    assert gpu_ctx.lib.dsdtm_sparse_align_batch_sharded(arr, 5, C.byref(b), C.byref(cam), C.byref(prm)) == 0
+    for c in ctxs:
+        c.close()
+    import copy
+    for i, sc in enumerate(scenes):
+        s2 = copy.copy(sc)
+        n = int(nf[i])
+        s2.px, s2.bearing, s2.p_world, s2.initial = sc.px[:n], sc.bearing[:n], sc.p_world[:n], sc.initial[:n]
+        To, no, _ = oracle.sparse_align(s2, L, 0, 10)
+        assert a["nt"][i] == no
+        H.assert_pose_close(a["Tc"][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"pair {i}")
+    assert a["nt"][2] == 0 and np.array_equal(a["Tc"][2], scenes[2].T_cur_w_seed.reshape(12))
+
+
+@pytest.mark.gpu
+def test_twenty_streams_through_one_context(gpu_ctx, oracle):
+    """A context keeps launch bookkeeping (pair counters, scratch) for 16 streams; a 17th takes over the entry that has
+    been idle longest once the event behind that entry's last launch has fired. 20 streams in turn, three rounds:
+    every launch gives the oracle's results."""
+    import torch
+    from tests.test_sparse_align_gpu import _device_batch
+    dev = torch.device("cuda", 0)
+    W, Hh, L = 320, 240, 3
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=150, seed=4100 + i, margin=12) for i in range(4)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in scenes]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    ctx = capi.Context(0)                                          # its own context: the table starts empty
+    streams = [torch.cuda.Stream(device=dev) for _ in range(20)]
+    packed = [_device_batch(torch, dev, scenes, L, W, Hh) for _ in streams]
+    seed = torch.from_numpy(np.stack([s.T_cur_w_seed.reshape(12) for s in scenes])).to(dev)
+    for rnd in range(3):
+        for (t, b), st in zip(packed, streams):
+            with torch.cuda.stream(st):
+                t["Tc"].copy_(seed, non_blocking=True)
+            ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+        torch.cuda.synchronize()
+        for k, (t, b) in enumerate(packed):
+            Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+            for i, (To, no, _) in enumerate(want):
+                H.assert_pose_close(Tg[i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"round {rnd} stream {k} pair {i}")
+                assert ntg[i] == no
+    ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, streams[0].cuda_stream))
+    ctx.close()
