@@ -130,6 +130,7 @@ EXPORTED_SYMBOLS = [
     "dsdtm_detect_cells", "dsdtm_detect_cells_frame", "dsdtm_match_candidates_frames",
     "dsdtm_pose_optimization", "dsdtm_pose_optimization_batch_device",
     "dsdtm_sparse_align_batch_sharded", "dsdtm_shard_range", "dsdtm_detect_cells_batch_device",
+    "dsdtm_match_candidates_batch_device", "dsdtm_match_candidates_scratch_bytes",
 ]
 
 
@@ -227,6 +228,12 @@ def load():
     lib.dsdtm_detect_cells.argtypes = [C.c_void_p, C.POINTER(Pyramid), u8p, C.POINTER(DetectParams), fp, ip32, ip32, ip32]
     lib.dsdtm_detect_cells_frame.restype = C.c_int
     lib.dsdtm_detect_cells_frame.argtypes = [C.c_void_p, C.c_void_p, u8p, C.POINTER(DetectParams), fp, ip32, ip32, ip32]
+    lib.dsdtm_match_candidates_batch_device.restype = C.c_int
+    lib.dsdtm_match_candidates_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_int,
+                                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t),
+                                                        C.POINTER(Camera)] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+    lib.dsdtm_match_candidates_scratch_bytes.restype = C.c_size_t
+    lib.dsdtm_match_candidates_scratch_bytes.argtypes = [C.c_int]
     lib.dsdtm_detect_cells_batch_device.restype = C.c_int
     lib.dsdtm_detect_cells_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int),
                                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.c_void_p,

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
         return;
     }
     const LevelGeom lg = a.lv[lvl];
-    const uint8_t* __restrict__ img = a.cur_pyr + lg.off;
+    const uint8_t* __restrict__ img = a.cur_pyr + (a.frame ? (size_t)a.frame[f] * a.pyr_pitch : 0) + lg.off;
     const int img_size = lg.stride * lg.h;
 
     const int r = lane >> 3, c = lane & 7;

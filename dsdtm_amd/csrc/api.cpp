@@ -1178,6 +1178,56 @@ extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* 
     return DSDTM_OK;
 }
 
+// FindMatchDirect for the candidates of MANY current frames in one go (independent sequences): every pointer is a device
+// pointer, nothing is copied, asynchronous on hip_stream.
+extern "C" int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t* cur_pyr, int n_frames, const uint8_t* kf_pyr, int n_kf,
+                                                   size_t pyr_pitch, int levels, const int* width, const int* height, const int* stride,
+                                                   const size_t* level_offset, const dsdtm_camera* cam, const double* T_kf_w,
+                                                   const double* T_cur_w, const int32_t* cand_frame, const int32_t* cand_kf,
+                                                   const float* ref_px, const int32_t* ref_level, const double* ref_bearing,
+                                                   const double* p_world, int max_search_level, int max_iters, int m,
+                                                   uint8_t* scratch, double* px_xy, int32_t* search_level, uint8_t* converged,
+                                                   void* hip_stream) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!cur_pyr || !kf_pyr || n_frames <= 0 || n_kf <= 0 || !width || !height || !stride || !level_offset || !cam || !T_kf_w || !T_cur_w ||
+        levels <= 0 || levels > DSDTM_MAX_LEVELS || m < 0 || (pyr_pitch & 3) ||
+        (m > 0 && (!cand_frame || !cand_kf || !ref_px || !ref_level || !ref_bearing || !p_world || !scratch || !px_xy || !search_level || !converged))) {
+        set_err(ctx, "bad argument"); return DSDTM_ERR_INVALID;
+    }
+    if (max_search_level < 0 || max_search_level >= levels) { set_err(ctx, "max_search_level outside the pyramid"); return DSDTM_ERR_INVALID; }
+    if (m == 0) return DSDTM_OK;
+    const size_t M = (size_t)m;
+    WarpKernelArgs a;
+    memset(&a, 0, sizeof a);
+    for (int l = 0; l < levels; ++l) {
+        if (width[l] <= 0 || height[l] <= 0 || stride[l] < width[l] || level_offset[l] + (size_t)stride[l] * height[l] > pyr_pitch) {
+            set_err(ctx, "level %d does not fit", l); return DSDTM_ERR_INVALID;
+        }
+        a.lv[l].w = width[l]; a.lv[l].h = height[l]; a.lv[l].stride = stride[l]; a.lv[l].off = (uint32_t)level_offset[l];
+    }
+    uint8_t* affine = scratch;                                  // M x 32, then M x 100, then M x 64 (256-byte aligned sections)
+    uint8_t* pb = scratch + align_up(M * 32, 256);
+    uint8_t* pp = pb + align_up(M * 100, 256);
+    a.kf_pyr = kf_pyr; a.kf_pitch = pyr_pitch; a.T_kf_w = T_kf_w; a.T_cur_w_arr = T_cur_w; a.cand_frame = cand_frame;
+    a.cand_kf = cand_kf; a.ref_px = ref_px; a.ref_level = ref_level; a.ref_bearing = ref_bearing; a.p_world = p_world;
+    a.affine = (double*)affine; a.search_level = search_level; a.patch_border = pb; a.patch = pp;
+    a.m = m; a.n_kf = n_kf; a.max_search_level = max_search_level; a.levels = levels;
+    a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, warp_launch(a, (hipStream_t)hip_stream));
+    A2DKernelArgs b;
+    memset(&b, 0, sizeof b);
+    b.cur_pyr = cur_pyr; b.patch_border = pb; b.patch = pp; b.level = search_level; b.px_xy = px_xy; b.converged = converged;
+    b.m = m; b.max_iters = max_iters; b.levels = levels; b.px_level0 = 1; b.frame = cand_frame; b.pyr_pitch = pyr_pitch;
+    for (int l = 0; l < levels; ++l) b.lv[l] = a.lv[l];
+    HIP_TRY(ctx, align2d_launch(b, (hipStream_t)hip_stream));
+    return DSDTM_OK;
+}
+extern "C" size_t dsdtm_match_candidates_scratch_bytes(int m) {
+    const size_t M = m > 0 ? (size_t)m : 0;
+    return align_up(M * 32, 256) + align_up(M * 100, 256) + align_up(M * 64, 256);
+}
+
 // ---- Optimizer::PoseOptimization ---------------------------------------------------------------
 extern "C" int dsdtm_pose_optimization_batch_device(dsdtm_ctx* ctx, int n_frames, int max_features,
                                                     const int32_t* n_features, const double* bearing,

@@ -102,6 +102,8 @@ struct A2DKernelArgs {
     uint8_t* converged;           // M
     int m, max_iters, levels;
     int px_level0;                // 1: px_xy is in level-0 pixels (divided by 2^level on load, multiplied back on store)
+    const int32_t* frame;         // optional, M: feature i sits on the pyramid cur_pyr + frame[i] * pyr_pitch (batches of frames)
+    size_t pyr_pitch;
     LevelGeom lv[DSDTM_MAX_LEVELS];
 };
 hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream);
@@ -131,6 +133,8 @@ struct WarpKernelArgs {
     uint8_t* patch_border;        // M x 100
     uint8_t* patch;               // M x 64
     double T_cur_w[12];
+    const double* T_cur_w_arr;    // optional (batches of current frames): poses, 12 doubles each, indexed by cand_frame
+    const int32_t* cand_frame;    // optional, M: the candidate's current frame
     int m, n_kf, max_search_level, levels;
     float fx, fy, cx, cy;
     LevelGeom lv[DSDTM_MAX_LEVELS];

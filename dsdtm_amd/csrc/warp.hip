@@ -128,7 +128,7 @@ __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
         return;
     }
     // ---- SolveAffineMatrix (:160-190) ----
-    const SE3x Tcur = xse3_from_rt(a.T_cur_w);
+    const SE3x Tcur = xse3_from_rt(a.cand_frame ? a.T_cur_w_arr + 12 * (size_t)a.cand_frame[c] : a.T_cur_w);
     const SE3x Tkf = xse3_from_rt(a.T_kf_w + 12 * (size_t)k);
     const SE3x Tki = xse3_inverse(Tkf);
     const double* P = a.p_world + 3 * (size_t)c;

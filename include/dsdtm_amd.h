@@ -223,6 +223,22 @@ int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* cur, const 
                                   const double* ref_bearing, const double* p_world, int max_search_level,
                                   int max_iters, int m, double* px_xy, int32_t* search_level, uint8_t* converged);
 
+/* The same for the candidates of n_frames CURRENT frames at once (independent sequences batch their reprojection search
+ * as they batch Run): packed DEVICE pyramids (current frames at cur_pyr + f * pyr_pitch, keyframes at kf_pyr + k *
+ * pyr_pitch, one geometry), device arrays throughout, nothing copied, asynchronous on hip_stream. cand_frame[i] is the
+ * current frame of candidate i (T_cur_w: n_frames x 12), cand_kf[i] its reference keyframe. scratch:
+ * dsdtm_match_candidates_scratch_bytes(m) bytes (affine matrices and warped patches; overwritten). px_xy in/out in
+ * level-0 pixels, as above. Replaces FindMatchDirect (src/Feature_alignment.cpp:128-158) per candidate. */
+int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t* cur_pyr, int n_frames, const uint8_t* kf_pyr, int n_kf,
+                                        size_t pyr_pitch, int levels, const int* width, const int* height, const int* stride,
+                                        const size_t* level_offset, const dsdtm_camera* cam, const double* T_kf_w,
+                                        const double* T_cur_w, const int32_t* cand_frame, const int32_t* cand_kf,
+                                        const float* ref_px, const int32_t* ref_level, const double* ref_bearing,
+                                        const double* p_world, int max_search_level, int max_iters, int m,
+                                        uint8_t* scratch, double* px_xy, int32_t* search_level, uint8_t* converged,
+                                        void* hip_stream);
+size_t dsdtm_match_candidates_scratch_bytes(int m);
+
 /* dsdtm_detect_cells on a device-resident frame (keyframe creation detects on the frame that was just tracked) */
 int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame, const uint8_t* grid_occupied,
                              const dsdtm_detect_params* params, float* cell_score, int32_t* cell_x,

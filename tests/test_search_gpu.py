@@ -121,3 +121,73 @@ def test_grid_and_reproject_point():
     assert s.ReprojectPoint(f, mp_in) and not s.ReprojectPoint(f, mp_out)
     px = f.World2Pixel(mp_in.mPose)
     assert len(s.mCells[int(px[1] / 25) * 26 + int(px[0] / 25)]) == 1
+
+
+@pytest.mark.gpu
+def test_match_candidates_batch_device_equals_per_frame_calls(gpu_ctx):
+    """dsdtm_match_candidates_batch_device: the candidates of THREE current frames (three independent worlds, nine
+    keyframes) in one call on packed device pyramids — convergence flags, refined pixels and search levels bit for bit
+    those of dsdtm_match_candidates_frames called once per current frame."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    from dsdtm_amd import feature_alignment as FA
+    Config.Set("Camera.CellSize", 25)
+    Config.Set("Camera.MaxPyraLevels", 5)
+    dev = torch.device("cuda", 0)
+    L, W, Hh = 5, 640, 480
+    ws, hs, ss, offs, nbytes = capi.pyramid_layout(W, Hh, L)
+    pitch = (nbytes + 255) // 256 * 256
+
+    def pack(pyr):
+        out = np.zeros(pitch, np.uint8)
+        for l in range(L):
+            out[offs[l]:offs[l] + ws[l] * hs[l]] = pyr[l].reshape(-1)
+        return out
+
+    per_frame, cols = [], {k: [] for k in ("frame", "kf", "rp", "rl", "rb", "pw", "px")}
+    cur_pack, kf_pack, Tk_all, Tc_all = [], [], [], []
+    for wi, seed in enumerate((11, 12, 13)):
+        cam, kfs, cur, mps = make_world(seed, n_points=300)
+        ck, rp, rl, rb, pw, cpx = [], [], [], [], [], []
+        for mp in mps:
+            if mp.mbBad or not mp.mObservations:
+                continue
+            px = cur.World2Pixel(mp.Get_Pose())
+            if not (20 < px[0] < W - 20 and 20 < px[1] < Hh - 20):
+                continue
+            k, fi = sorted(mp.mObservations.items())[0]
+            ck.append(k); rp.append(kfs[k].px[fi]); rl.append(kfs[k].level[fi]); rb.append(kfs[k].bearing[fi]); pw.append(mp.Get_Pose()); cpx.append(px)
+        ck, rl = np.array(ck, np.int32), np.array(rl, np.int32)
+        rp, rb, pw, cpx = np.array(rp, np.float32), np.array(rb), np.array(pw), np.array(cpx)
+        Tk = np.array([k.Get_Pose() for k in kfs])
+        per_frame.append(FA.match_candidates_frames(cur, kfs, cam, Tk, cur.Get_Pose(), ck, rp, rl, rb, pw, cpx, L - 3, 10, ctx=gpu_ctx))
+        cols["frame"].append(np.full(len(ck), wi, np.int32)); cols["kf"].append(ck + 3 * wi)
+        for k, v in (("rp", rp), ("rl", rl), ("rb", rb), ("pw", pw), ("px", cpx)):
+            cols[k].append(v)
+        cur_pack.append(pack(cur.mvImg_Pyr)); kf_pack += [pack(k.mvImg_Pyr) for k in kfs]
+        Tk_all.append(Tk.reshape(3, 12)); Tc_all.append(np.asarray(cur.Get_Pose()).reshape(12))
+    cat = {k: np.ascontiguousarray(np.concatenate(v)) for k, v in cols.items()}
+    M = len(cat["frame"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_cur, d_kf = t(np.stack(cur_pack)), t(np.stack(kf_pack))
+    d_Tk, d_Tc = t(np.concatenate(Tk_all)), t(np.stack(Tc_all))
+    d = {k: t(v) for k, v in cat.items()}
+    d_px = d["px"].clone()
+    d_sl = torch.zeros(M, dtype=torch.int32, device=dev)
+    d_cv = torch.zeros(M, dtype=torch.uint8, device=dev)
+    d_scr = torch.empty(gpu_ctx.lib.dsdtm_match_candidates_scratch_bytes(M), dtype=torch.uint8, device=dev)
+    wa, ha, sa, oa = (C.c_int * L)(*ws), (C.c_int * L)(*hs), (C.c_int * L)(*ss), (C.c_size_t * L)(*offs)
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_match_candidates_batch_device(
+        gpu_ctx.handle, d_cur.data_ptr(), 3, d_kf.data_ptr(), 9, pitch, L, wa, ha, sa, oa, C.byref(capi.camera_struct(cam)),
+        d_Tk.data_ptr(), d_Tc.data_ptr(), d["frame"].data_ptr(), d["kf"].data_ptr(), d["rp"].data_ptr(), d["rl"].data_ptr(),
+        d["rb"].data_ptr(), d["pw"].data_ptr(), L - 3, 10, M, d_scr.data_ptr(), d_px.data_ptr(), d_sl.data_ptr(), d_cv.data_ptr(), None))
+    torch.cuda.synchronize()
+    conv, px, sl = d_cv.cpu().numpy().astype(bool), d_px.cpu().numpy(), d_sl.cpu().numpy()
+    o = 0
+    for cv_f, px_f, sl_f in per_frame:
+        n = len(cv_f)
+        assert np.array_equal(conv[o:o + n], cv_f) and np.array_equal(sl[o:o + n], sl_f)
+        assert np.array_equal(px[o:o + n], px_f, equal_nan=True)
+        o += n
+    assert o == M and conv.sum() > 100
