@@ -192,3 +192,28 @@ def test_warp_integer_division_quirk(oracle):
     d = np.load(H.golden_path("align2d_pyr_warp.npz"))
     sl, wb = d["out_search_level"], d["out_warp_border"]
     assert ((wb.max(axis=1) == wb.min(axis=1)) == (sl >= 1)).all() or (sl == 0).all()
+
+
+def test_interpolated_reference_intensities_are_exact_in_fp64():
+    """What the kernels rely on when they rebuild the reference grid (workspace kernel, parity across kernel shapes):
+    the bilinear value w00 a + w01 b + w10 c + w11 d of four bytes at a reference-side subpixel position is EXACT in
+    FP64 — the position is a float32 pixel >= 3 * 2^level (border test, src/Sprase_ImageAlign.cpp:95-100) times 2^-level,
+    so each subpixel offset has at most 22 fractional bits — hence the same bits in any order of operations."""
+    from fractions import Fraction
+    rng = np.random.default_rng(5)
+    for level in range(5):
+        scale = np.float64(np.float32(1.0) / np.float32(1 << level))
+        for _ in range(400):
+            px = np.float32(rng.uniform(3 * (1 << level), 640.0))
+            py = np.float32(rng.uniform(3 * (1 << level), 480.0))
+            x, y = np.float64(px) * scale, np.float64(py) * scale
+            su, sv = x - np.floor(x), y - np.floor(y)
+            w = [(1.0 - su) * (1.0 - sv), su * (1.0 - sv), (1.0 - su) * sv, su * sv]
+            exact_w = [Fraction(1 - Fraction(su)) * Fraction(1 - Fraction(sv)), Fraction(su) * (1 - Fraction(sv)),
+                       (1 - Fraction(su)) * Fraction(sv), Fraction(su) * Fraction(sv)]
+            assert all(Fraction(float(a)) == b for a, b in zip(w, exact_w))          # the weights themselves are exact
+            q = rng.integers(0, 256, 4)
+            exact = sum(Fraction(int(q[i])) * exact_w[i] for i in range(4))
+            fwd = ((w[0] * q[0] + w[1] * q[1]) + w[2] * q[2]) + w[3] * q[3]
+            rev = ((w[3] * q[3] + w[2] * q[2]) + w[1] * q[1]) + w[0] * q[0]
+            assert Fraction(float(fwd)) == exact and Fraction(float(rev)) == exact
