@@ -949,6 +949,9 @@ def main():
                                      "rocprofv3 --kernel-trace of this command, committed in " + PMC_SUMMARY + " (null when that "
                                      "summary was taken with another build of the library)",
                    "kernel_ms_solo": k_solo,
+                   "frac_solo": args.pairs * algorithmic_bytes(args.width, args.height, args.levels, args.patches) / (k_solo * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "frac_note": "frac = algorithmic bytes / span per step (what the GPU delivers with launches overlapping at their "
+                                "edges); frac_solo = algorithmic bytes / kernel_ms_solo (the kernel alone, what rocprofv3 reports)",
                    "kernel_ms_solo_note": f"mean of {solo_n - 5} launches on ONE stream after the timed region (HIP events around each): "
                                           "the kernel's duration as rocprofv3 --kernel-trace reports it for a one-stream run"}
         k_basis = (f"kernel_ms_avg = HIP-event span of the timed region / steps ({n_streams} launch streams: consecutive launches "
