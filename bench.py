@@ -734,7 +734,9 @@ def fp64_block(args, kernel_ms):
     flops = pmc_fp64_flops("sparse_align_reg_kernel") if (args.pairs, args.patches, args.width, args.height, args.levels, args.iters) == (1024, 300, 640, 480, 4, 10) else None
     out = {"bound": "fp64_vector", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "flops_per_launch": flops,
            "note": "executed FP64 vector flops per launch = 64 x (ADD + MUL + 2 FMA + TRANS) wave instructions, rocprofv3 "
-                   "SQ_INSTS_VALU_*_F64 (" + PMC_SUMMARY + "); divided by this run's kernel time"}
+                   "SQ_INSTS_VALU_*_F64 (" + PMC_SUMMARY + "); divided by this run's roofline.kernel_ms_avg — with several launch "
+                   "streams that is the span per step, so `achieved` is then the rate the GPU delivers across overlapping launches, "
+                   "not the rate inside one kernel (kernel_time_basis of the roofline block)"}
     if flops is not None:
         out["flops_per_alignment"] = flops / args.pairs
         out["achieved"] = flops / (kernel_ms * 1e-3) / 1e12

@@ -815,3 +815,54 @@ def test_more_streams_than_a_context_tracks(gpu_ctx, oracle):
             for i, (To, no, _) in enumerate(want):
                 H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"stream {k} pair {i}")
                 assert ntg[i] == no
+
+
+def test_two_member_pairs_ragged_counts_determinism_and_the_one_unit_path(gpu_ctx, oracle):
+    """1025..2048 patches in batches: one pair on TWO compute units (halves wholly in LDS, partials exchanged through
+    tagged words). A pair count that is not a multiple of 8, ragged live counts — a member whose half holds no live
+    patch, a pair below Min_fts — statistics from member 0, bit-identical results from launch to launch, and the same
+    results (to rounding: other summation order) on one compute unit with the HBM workspace (option ws_no_duo)."""
+    import ctypes as C
+    import copy
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N, P = 320, 240, 3, 2000, 19
+    base = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=2300 + i, margin=12) for i in range(3)]
+    scs = [base[i % 3] for i in range(P)]
+    nf = np.array([2000, 1500, 1100, 900, 10] + [2000 - 37 * i for i in range(P - 5)], np.int32)
+    want = []
+    for i in range(P):
+        s2 = copy.copy(scs[i]); n = int(nf[i])
+        s2.px, s2.bearing, s2.p_world, s2.initial = s2.px[:n], s2.bearing[:n], s2.p_world[:n], s2.initial[:n]
+        want.append(oracle.sparse_align(s2, L, 0, 10))
+    t, b = _device_batch(torch, dev, scs, L, W, Hh)
+    t["nf"] = torch.from_numpy(nf).to(dev)
+    t["st"] = torch.zeros((P, capi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    b.n_features, b.stats = t["nf"].data_ptr(), t["st"].data_ptr()
+    cam = capi.camera_struct(base[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    seed = torch.from_numpy(np.stack([s.T_cur_w_seed.reshape(12) for s in scs])).to(dev)
+
+    def run():
+        t["Tc"].copy_(seed); t["nt"].zero_(); t["st"].zero_()
+        torch.cuda.synchronize()
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), None))
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, None))
+        st = np.frombuffer(t["st"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
+        return t["Tc"].cpu().numpy().copy(), t["nt"].cpu().numpy().copy(), st.copy()
+
+    T1, n1, s1 = run()
+    for i, (To, no, so) in enumerate(want):
+        assert n1[i] == no, i
+        if nf[i] < 15:
+            assert np.array_equal(T1[i], scs[i].T_cur_w_seed.reshape(12))      # Min_fts rule: pose untouched
+            continue
+        H.assert_pose_close(T1[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"two members, pair {i}")
+        assert list(s1["iters"][i][:L]) == list(so["iters"][:L]) and list(s1["exit_code"][i][:L]) == list(so["exit_code"][:L])
+    for _ in range(3):
+        T2, n2, s2 = run()
+        assert np.array_equal(T1, T2) and np.array_equal(n1, n2) and np.array_equal(s1["chi2"], s2["chi2"])
+    with capi.debug_options(ws_no_duo=1):
+        T3, n3, s3 = run()
+    assert np.array_equal(n1, n3) and np.array_equal(s1["iters"], s3["iters"]) and np.abs(T1 - T3).max() < 1e-12
