@@ -59,14 +59,30 @@ def library_sha():
         return None
 
 
+def library_source_sha():
+    """sha256 over the sources + flags the in-tree library is built from (dsdtm_amd/csrc/build.py: source_sha), valid as
+    an identity of the LOADED library only when that library is up to date with them."""
+    try:
+        from dsdtm_amd.csrc import build as hip_build
+        return None if hip_build.needs_build() else hip_build.source_sha()
+    except Exception:
+        return None
+
+
 def pmc_summary(path=PMC_SUMMARY):
-    """The committed counter summary, or {} when it is missing or describes another binary than the loaded one."""
+    """The committed counter summary, or {} when it is missing or describes another build of the library than the loaded
+    one: the binary's hash must match, or — hipcc's output is not reproducible byte for byte — the hash of the sources and
+    flags it was built from, with the loaded library up to date with those sources."""
     try:
         with open(os.path.join(ROOT, path)) as f:
             d = json.load(f)
     except Exception:
         return {}
-    return d if d.get("profile_binary_sha") and d.get("profile_binary_sha") == library_sha() else {}
+    if d.get("profile_binary_sha") and d.get("profile_binary_sha") == library_sha():
+        return d
+    if d.get("profile_source_sha") and d.get("profile_source_sha") == library_source_sha():
+        return d
+    return {}
 
 
 def pmc_traffic(kernel_substr, algorithmic_bytes_per_launch, path=PMC_SUMMARY):

@@ -36,6 +36,16 @@ def _obj(src, flags):
     return os.path.join(OBJ_DIR, f"{os.path.splitext(src)[0]}.{_tag(flags)}.o")
 
 
+def source_sha(extra=()):
+    """sha256 (16 hex digits) over the library's sources, headers and compiler flags: what a profile is tied to besides
+    the hash of the binary it ran with (hipcc's objects are not reproducible byte for byte, the sources are)."""
+    h = hashlib.sha256(" ".join(_flags(list(extra))).encode())
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _linked_tag():
     try:
         with open(TAG) as f:

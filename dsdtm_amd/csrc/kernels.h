@@ -56,8 +56,6 @@ struct Options {
 Options& options();
 
 constexpr int SA_PPW = 2;      // pair slots per workgroup of the <= 320-feature register kernel (see sparse_align.hip)
-#define DSDTM_STR2(x) #x
-#define DSDTM_STR(x) DSDTM_STR2(x)
 enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2, SA_REG128 = 3, SA_REG192 = 4, SA_REG256 = 5, SA_REG704 = 6 };
 SAVariant sparse_align_pick_variant(int max_features);
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features);

@@ -1326,8 +1326,9 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // Generic kernel for any feature count: each lane of the NPW patch waves loops over patches
-// p = tid, tid + NPW*64, ...; the per-patch state is parked in an HBM workspace laid out
-// [slot][patch] so that the lanes of a wave read consecutive doubles (coalesced 512-B rows).
+// p = tid, tid + NPW*64, ...; the per-patch state is parked — in LDS up to 1024 patches per workgroup (one
+// pair per compute unit, or one pair on two compute units up to 2048: MEMBERS below), else in an HBM
+// workspace laid out [plane][patch] so that the lanes of a wave read consecutive dwords.
 // ---------------------------------------------------------------------------------------------
 // What is parked per patch is the INPUT of the grid, not the grid: the 7x7 u8 reference footprint as unpacked
 // row words (14 dwords), the feature's pixel (2 floats) and its 3-D point (3 doubles) — 88 bytes instead of the

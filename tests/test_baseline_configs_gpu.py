@@ -72,6 +72,68 @@ def test_config4_share_1024_pairs_in_one_launch(gpu_ctx, oracle):
         torch.cuda.synchronize()
 
 
+def test_config4_share_size_independent_properties(gpu_ctx):
+    """The same 1024-pair launch held to properties that need no oracle (they hold for the reference's algorithm at any
+    size): (1) GAUGE — moving the world frame (T_ref_w <- T_ref_w G, seeds likewise, map points <- G^-1 P) moves every
+    result by exactly G (the path only ever uses T_cur T_ref^-1 and |P_w - C_ref|); (2) the ORDER of a pair's features
+    does not matter beyond summation rounding; (3) RESTART — aligning again from the result leaves it in place: every
+    level ends on its second residual evaluation at the latest (chi2 can only have gone up by rounding or the step is
+    below 1e-8), and the pose moves by less than the last accepted step."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    cam = synth.Camera.tum(640, 480)
+    P, N = 1024, 300
+    d = bench.build_batch(torch, dev, gpu_ctx, cam, P, 640, 480, 4, N, seed=0xD5D7, stream=stream)
+    cs = capi.camera_struct(cam)
+    prm = capi.AlignParams(4, 0, 10, 15)
+
+    def run():
+        torch.cuda.synchronize()
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(d["desc"]), C.byref(cs), C.byref(prm), stream.cuda_stream))
+        gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, stream.cuda_stream))
+        st = np.frombuffer(d["stats"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE).copy()
+        return d["T_cur_w"].cpu().numpy().copy(), d["n_tracked"].cpu().numpy().copy(), st
+
+    d["T_cur_w"].copy_(d["T_seed"])
+    T0, n0, s0 = run()
+    to44 = lambda T: np.concatenate([T.reshape(-1, 3, 4), np.tile(np.array([[[0.0, 0, 0, 1]]]), (len(T), 1, 1))], axis=1)
+    # (1) gauge: one random rigid motion G per pair
+    rng = np.random.default_rng(44)
+    G = np.stack([np.vstack([synth.random_pose(rng, 2.0, 1.0), [0, 0, 0, 1]]) for _ in range(P)])
+    Gi = np.linalg.inv(G)
+    keep = {k: d[k].clone() for k in ("T_ref_w", "T_seed", "p_world")}
+    Tref, Tseed = to44(keep["T_ref_w"].cpu().numpy()), to44(keep["T_seed"].cpu().numpy())
+    pw = keep["p_world"].cpu().numpy()
+    d["T_ref_w"].copy_(torch.from_numpy(np.ascontiguousarray((Tref @ G)[:, :3, :].reshape(P, 12))))
+    d["T_cur_w"].copy_(torch.from_numpy(np.ascontiguousarray((Tseed @ G)[:, :3, :].reshape(P, 12))))
+    d["p_world"].copy_(torch.from_numpy(np.ascontiguousarray(np.einsum("nij,npj->npi", Gi[:, :3, :3], pw) + Gi[:, None, :3, 3])))
+    T1, n1, s1 = run()
+    want = (to44(T0) @ G)[:, :3, :]
+    dl = np.array([synth.pose_error(T1[i], want[i]) for i in range(P)])
+    assert dl[:, 0].max() < 1e-9 and dl[:, 1].max() < 1e-8, dl.max(axis=0)
+    assert np.array_equal(n1, n0) and (s1["iters"] == s0["iters"]).mean() > 0.99      # rounding may move a rare borderline decision
+    for k, v in keep.items():
+        d[k].copy_(v)
+    # (2) feature order: reverse every pair's feature columns
+    cols = {k: d[k].clone() for k in ("px", "bearing", "p_world", "initial")}
+    for k, v in cols.items():
+        d[k].copy_(torch.flip(v, dims=[1]))
+    d["T_cur_w"].copy_(d["T_seed"])
+    T2, n2, s2 = run()
+    dl = np.array([synth.pose_error(T2[i], T0[i]) for i in range(P)])
+    assert dl[:, 0].max() < 1e-9 and dl[:, 1].max() < 1e-8 and np.array_equal(n2, n0), dl.max(axis=0)
+    for k, v in cols.items():
+        d[k].copy_(v)
+    # (3) restart from the result
+    d["T_cur_w"].copy_(torch.from_numpy(T0))
+    T3, n3, s3 = run()
+    assert (s3["iters"][:, :4] <= 2).mean() > 0.98 and np.array_equal(n3, n0)
+    dl = np.array([synth.pose_error(T3[i], T0[i]) for i in range(P)])
+    assert np.median(dl[:, 0]) < 2e-6 and np.median(dl[:, 1]) < 5e-6 and dl[:, 0].max() < 2e-4, (np.median(dl, axis=0), dl.max(axis=0))
+
+
 def test_config5_1280x960_2000_patches_then_align2d(gpu_ctx, oracle):
     """BASELINE config 5: 1280x960 pyramid, 4 levels, 2000 patches (one pair over a team of 8 compute units),
     then the per-feature Align2D refinement of all 2000 features on the same current frame (10x10 / 8x8

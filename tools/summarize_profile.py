@@ -22,7 +22,9 @@ ALG = {   # case -> (kernel substring, algorithmic bytes per launch, dispatches 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with open(os.path.join(REPO, "dsdtm_amd", "csrc", "libdsdtm_amd.so"), "rb") as f:
     sha = hashlib.sha256(f.read()).hexdigest()[:16]
-stats_rows, pmc = [], {"round": 3, "profile_binary_sha": sha, "command": "tools/profile.sh (see the file for every command line)", "cases": {},
+sys.path.insert(0, REPO)
+from dsdtm_amd.csrc import build as hip_build
+stats_rows, pmc = [], {"round": 3, "profile_binary_sha": sha, "profile_source_sha": hip_build.source_sha(), "command": "tools/profile.sh (see the file for every command line)", "cases": {},
                        "hbm_traffic_per_launch": [], "fp64_per_launch": [], "overlap": {}}
 for case in sorted(os.listdir(src)):
     d = os.path.join(src, case)
