@@ -20,9 +20,15 @@ def test_traffic_lookup_reads_the_committed_pmc_summary(monkeypatch):
     assert os.path.exists(path), "profiles/ must carry the PMC summary bench.py quotes"
     with open(path) as f:
         d = json.load(f)
-    # the summary's numbers are only quoted for the binary they were taken with
+    # the summary's numbers are only quoted for the build they were taken with: the binary's hash, or (hipcc's objects
+    # are not reproducible byte for byte) the hash of the sources and flags of an up-to-date library
     monkeypatch.setattr(bench, "library_sha", lambda: "0" * 16)
+    monkeypatch.setattr(bench, "library_source_sha", lambda: "1" * 16)
     assert bench.pmc_traffic("sparse_align_reg_kernel", 1024 * 833392) is None and bench.pmc_summary() == {}
+    monkeypatch.setattr(bench, "library_source_sha", lambda: d["profile_source_sha"])
+    assert bench.pmc_traffic("sparse_align_reg_kernel", 1024 * 833392) is not None
+    monkeypatch.setattr(bench, "library_source_sha", lambda: None)              # library stale against its sources
+    assert bench.pmc_summary() == {}
     monkeypatch.setattr(bench, "library_sha", lambda: d["profile_binary_sha"])
     rows = {(t["case"], int(t["algorithmic_bytes_per_launch"])): t for t in d["hbm_traffic_per_launch"]}
     main = rows[("solo", 1024 * 833392)]
