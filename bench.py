@@ -399,6 +399,31 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
         t = [a.elapsed_time(b) for a, b in ev]
         ms_avg, ms_min = float(np.mean(t)), float(np.min(t))
         b_alg = algorithmic_bytes(width, height, args.levels, n_patches)
+        # the same launches issued on four streams in turn, as the main line issues its steps (each launch in flight has
+        # its own pose / count buffers; the statistics buffer is shared and not read here)
+        ns, nl = 4, 24
+        sts = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        bufs = [(d["T_seed"].clone(), torch.zeros_like(d["n_tracked"])) for _ in range(nl)]
+        dks = []
+        for Tb, nb in bufs:
+            dk = capi.BatchDesc.from_buffer_copy(bytes(desc))
+            dk.T_cur_w, dk.n_tracked, dk.stats = Tb.data_ptr(), nb.data_ptr(), None
+            dks.append(dk)
+        torch.cuda.synchronize()
+        for k in range(ns):                                  # per-stream scratch and counters are set up by a first launch
+            ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(dks[k]), C.byref(cs), C.byref(prm), sts[k].cuda_stream))
+        torch.cuda.synchronize()
+        for Tb, _ in bufs:
+            Tb.copy_(d["T_seed"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(nl):
+            ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(dks[k]), C.byref(cs), C.byref(prm), sts[k % ns].cuda_stream))
+        torch.cuda.synchronize()
+        span_ms = (time.perf_counter() - t0) * 1e3 / nl
+        for s_ in sts:
+            ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, s_.cuda_stream))
+        same = all(torch.equal(Tb, bufs[0][0]) for Tb, _ in bufs) and torch.equal(bufs[0][0], d["T_cur_w"])
         sample = 32
         hb = HostBatch(d, sample)
         cpu_rate, _ = hb.run(lib, cs, prm, usable_cpus())
@@ -408,6 +433,10 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
         out.append({
             "workload": f"{n_pairs} independent pairs per launch, {name}",
             "value": n_pairs / (ms_avg * 1e-3), "unit": "alignments/s",
+            "value_note": "one launch at a time (HIP events around every launch)",
+            "value_four_streams": n_pairs / (span_ms * 1e-3),
+            "four_streams_note": f"{nl} launches on {ns} streams in turn, wall time / launches = {span_ms:.4f} ms per launch; results of all "
+                                 f"launches bit-identical to the one-stream launch: {bool(same)}",
             "roofline": roofline_block(d.get("kernel_name", "sparse_align"), n_pairs * b_alg, ms_avg, ms_min, n_pairs, b_alg, "alignment"),
             "pose_delta_vs_cpu": {"max_rad": float(dl[:, 0].max()), "max_m": float(dl[:, 1].max()), "pairs_checked": sample,
                                   "n_tracked_equal": bool(np.array_equal(d["n_tracked"][:sample].cpu().numpy(), hb.nt)),
