@@ -323,9 +323,7 @@ __device__ __forceinline__ double gradient_max_norm(const SE3d& Tx, const double
 
 }  // namespace
 
-#ifndef PO_WAVES_PER_EU
-#define PO_WAVES_PER_EU 2
-#endif
+constexpr int PO_WAVES_PER_EU = 2;
 template <int NW, int FPL>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? PO_WAVES_PER_EU : 1, NW == 1 ? PO_WAVES_PER_EU : 2)))
 void pose_opt_kernel(PoseOptArgs a) {

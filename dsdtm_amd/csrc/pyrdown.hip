@@ -42,10 +42,7 @@ struct PyrDownArgs {
 // ~45 instructions per output row. Threads are numbered linearly over (strip, row chunk), so waves
 // are full whatever the level width (640 px = 80 strips used to leave the second block column at 16
 // of 64 lanes).
-#ifndef SA_PD_ROWS
-#define SA_PD_ROWS 4
-#endif
-constexpr int PD_ROWS = SA_PD_ROWS;
+constexpr int PD_ROWS = 4;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u16x2 pk(uint32_t lo, uint32_t hi) {
@@ -275,12 +272,7 @@ struct PyrFusedArgs {
 // ROWS = output rows per thread: 8 for the level-0 stage (every input row loaded and filtered once per 2..3 outputs,
 // as in the per-level kernel), fewer for the stages that read LDS — those are short, and what matters is that a
 // workgroup gets through them quickly (more, shorter tasks), because it issues no HBM loads meanwhile.
-#ifndef SA_PF_ROWS_G
-#define SA_PF_ROWS_G 8
-#endif
-#ifndef SA_PF_ROWS_L
-#define SA_PF_ROWS_L 2
-#endif
+constexpr int PF_ROWS_G = 8, PF_ROWS_L = 2;   // output rows per task: level-0 stage (from HBM) / LDS stages
 template <bool SRC_LDS, bool DST_LDS, int ROWS>
 __device__ __forceinline__ void pf_stage(const uint8_t* __restrict__ src, int sstride, int s_row0, int sw, int sh,
                                          int d_lo, int d_hi, int dw, uint8_t* __restrict__ ldst, int lstride,
@@ -310,16 +302,16 @@ __global__ __launch_bounds__(256) void pyrdown_fused_kernel(const PyrFusedArgs a
     }
     uint8_t* __restrict__ base = a.pyr + (size_t)img * a.pyr_pitch;
     // level 0 (HBM) -> level 1 (LDS + owned rows)
-    pf_stage<false, true, SA_PF_ROWS_G>(base + a.off[0], a.stride[0], 0, a.w[0], a.h[0], lo[1], hi[1], a.w[1],
+    pf_stage<false, true, PF_ROWS_G>(base + a.off[0], a.stride[0], 0, a.w[0], a.h[0], lo[1], hi[1], a.w[1],
                           pf_lds + a.lds_off[1], a.lds_stride[1], base + a.off[1], a.stride[1], olo[1], ohi[1]);
     __syncthreads();
 #pragma unroll
     for (int l = 2; l < K; ++l) {
-        pf_stage<true, true, SA_PF_ROWS_L>(pf_lds + a.lds_off[l - 1], a.lds_stride[l - 1], lo[l - 1], a.w[l - 1], a.h[l - 1], lo[l], hi[l], a.w[l],
+        pf_stage<true, true, PF_ROWS_L>(pf_lds + a.lds_off[l - 1], a.lds_stride[l - 1], lo[l - 1], a.w[l - 1], a.h[l - 1], lo[l], hi[l], a.w[l],
                              pf_lds + a.lds_off[l], a.lds_stride[l], base + a.off[l], a.stride[l], olo[l], ohi[l]);
         __syncthreads();
     }
-    pf_stage<true, false, SA_PF_ROWS_L>(pf_lds + a.lds_off[K - 1], a.lds_stride[K - 1], lo[K - 1], a.w[K - 1], a.h[K - 1], lo[K], hi[K], a.w[K],
+    pf_stage<true, false, PF_ROWS_L>(pf_lds + a.lds_off[K - 1], a.lds_stride[K - 1], lo[K - 1], a.w[K - 1], a.h[K - 1], lo[K], hi[K], a.w[K],
                           nullptr, 0, base + a.off[K], a.stride[K], olo[K], ohi[K]);
 }
 
