@@ -832,6 +832,10 @@ def main():
                     help="HIP streams the steps are issued on in turn (default 8 = two per HIP hardware queue): the workgroups "
                          "of step k+1 take the compute units the tail of step k leaves idle (same launches, same "
                          "results); 1 = strictly one launch at a time, with HIP events around every launch")
+    ap.add_argument("--preroll", type=int, default=300,
+                    help="untimed launches of the same step BEFORE the W warm-up steps, reported in the line as 'preroll': the GPU "
+                         "comes out of idle over ~40 ms of load (tools/warmup_sweep.sh: the same 20 timed steps run 7 %% faster "
+                         "behind 200 launches than behind 5); 0 = none")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline entries (other shapes, pyrDown)")
@@ -928,6 +932,27 @@ def main():
     def step(k):
         ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(descs[k]), C.byref(cam_struct), C.byref(prm),
                                                           streams[k % n_streams].cuda_stream))
+
+    # Pre-roll: the same launches on pose buffers of their own, so that the W warm-up steps and the K timed steps run on
+    # a GPU that is out of its idle clocks whatever W is (reported in the line; never part of the timed region)
+    preroll_ms = 0.0
+    if args.preroll > 0:
+        T_pre = d["T_seed"].unsqueeze(0).repeat(n_streams, 1, 1).contiguous()
+        pre = []
+        for i in range(n_streams):
+            dk = capi.BatchDesc.from_buffer_copy(bytes(desc))
+            dk.T_cur_w = T_pre[i].data_ptr()
+            pre.append(dk)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for k in range(args.preroll):
+            i = k % n_streams
+            with torch.cuda.stream(streams[i]):
+                T_pre[i].copy_(d["T_seed"], non_blocking=True)
+            ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(pre[i]), C.byref(cam_struct), C.byref(prm),
+                                                              streams[i].cuda_stream))
+        torch.cuda.synchronize()
+        preroll_ms = (time.perf_counter() - tp) * 1e3
 
     for k in range(args.warmup):
         step(k)
@@ -1035,6 +1060,10 @@ def main():
             "n_tracked_mean": float(ntg.mean()),
             "err_vs_ground_truth_median": {"rad": float(np.median(err[:, 0])), "m": float(np.median(err[:, 1]))},
             "library": ctx.lib.dsdtm_version().decode(),
+            "preroll": {"launches": args.preroll, "ms": preroll_ms,
+                        "note": "untimed launches of the same step before the 'warmup' steps, on pose buffers of their own: the GPU "
+                                "leaves its idle clocks over ~40 ms of load (tools/warmup_sweep.sh, profiles/r03_warmup_sweep.txt); "
+                                "--preroll 0 measures from idle"},
         }
         if not args.no_cpu and world == 1:
             sample = min(args.cpu_sample, args.pairs)
