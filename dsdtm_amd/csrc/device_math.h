@@ -128,12 +128,16 @@ __device__ inline SE3d se3_inverse(const SE3d& a) {
 //   (th-sin th)/th^3  = sum (-1)^k th^2k / (2k+3)!
 // (truncation < 1e-19 relative; <= 2 ulp vs libm). Larger angles use the closed forms with one
 // sincos(th/2). Sophus' own th < 1e-10 branch (V = R) is kept.
-__device__ inline SE3d se3_exp(const double* x) {
+// SMALL = the caller knows theta^2 < 0.01 (a Gauss-Newton step that was accepted on the series path): the closed-form arm
+// with its sincos — ~150 instructions and two dozen 64-bit constants that the compiler would otherwise materialise in
+// registers ahead of the caller's loops — is not compiled in. Same arithmetic, same bits.
+template <bool SMALL = false>
+__device__ __forceinline__ SE3d se3_exp_impl(const double* x) {
     const double ux = x[0], uy = x[1], uz = x[2];
     const double wx = x[3], wy = x[4], wz = x[5];
     const double theta_sq = wx * wx + wy * wy + wz * wz;
     double ch, imag_factor, a, b;
-    if (theta_sq < 0.01) {               // |omega| < 0.1 rad: every Gauss-Newton step in practice
+    if (SMALL || theta_sq < 0.01) {      // |omega| < 0.1 rad: every Gauss-Newton step in practice
         const double h2 = 0.25 * theta_sq;
         // Horner in h2 / theta_sq, six terms each: truncation < 1e-19 for theta_sq < 0.01
         ch = 1.0 + h2 * (-1.0 / 2 + h2 * (1.0 / 24 + h2 * (-1.0 / 720 + h2 * (1.0 / 40320 + h2 * (-1.0 / 3628800)))));
@@ -179,6 +183,13 @@ __device__ inline SE3d se3_exp(const double* x) {
     o.ty = V[3] * ux + V[4] * uy + V[5] * uz;
     o.tz = V[6] * ux + V[7] * uy + V[8] * uz;
     return o;
+}
+__device__ inline SE3d se3_exp(const double* x) { return se3_exp_impl<false>(x); }
+__device__ __forceinline__ SE3d se3_exp_small(const double* x) { return se3_exp_impl<true>(x); }
+// out of line (by value: nothing of the caller goes through memory): for callers that only take it on a rare path
+__device__ __attribute__((noinline)) SE3d se3_exp_call(double x0, double x1, double x2, double x3, double x4, double x5) {
+    const double x[6] = {x0, x1, x2, x3, x4, x5};
+    return se3_exp_impl<false>(x);
 }
 
 // exp of a small twist x = [upsilon, omega] (theta^2 = |omega|^2 < 0.01) in MATRIX form:

@@ -807,8 +807,8 @@ struct SolverCarry {
 // on: new R/t and the control word are in LDS when it returns (the caller publishes them), the rest of the
 // iteration follows in solver_commit. Executed uniformly by all 64 lanes of the solver wave (same cost as one
 // lane); lane 0 stores. Returns ctrl.
-template <int NP>   // NP = number of partial slots (rows or waves)
-__device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int level, int it,
+template <int NP, class Args>   // NP = number of partial slots (rows or waves); Args: SAKernelArgs or SolverArgs
+__device__ __forceinline__ int solver_step(const Args& a, int pair, int level, int it,
                                            const WavePartial* s_part, BlockState& s, int lane,
                                            double* hrow /* lane i < 6: row i of H^+ */, SolverCarry& c,
                                            unsigned long long* tacc = nullptr /* diagnostic build only */) {
@@ -928,8 +928,8 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
                 s.u.tt[0] = tn[0]; s.u.tt[1] = tn[1]; s.u.tt[2] = tn[2];
             }
             c.fast = true;
-        } else {                                           // a large rotation step: the closed forms, state first
-            const SE3d dT = se3_exp(x);
+        } else {                                           // a large rotation step: the closed forms (out of line), state first
+            const SE3d dT = se3_exp_call(x[0], x[1], x[2], x[3], x[4], x[5]);
             const SE3d Tcur = load_se3(s.u.q, s.u.t);
             const SE3d Tn = se3_mul(Tcur, dT);             // :335 right-multiply
             double Rn[9];
@@ -961,9 +961,10 @@ __device__ __forceinline__ int solver_step(const SAKernelArgs& a, int pair, int 
 // Solver wave, after the new R/t/ctrl have been published: the part of the iteration nobody waits for.
 // T_c2r = T_c2r * SE3::exp(x) on the quaternion state (:335), its rotation matrix for the next step,
 // tT_c2rOld and chi2 (:313-314), and the statistics.
-__device__ __forceinline__ void solver_commit(const SAKernelArgs& a, int pair, BlockState& s, int lane, const SolverCarry& c, bool write_stats = true) {
-    if (c.fast) {
-        const SE3d dT = se3_exp(c.x);
+template <class Args>
+__device__ __forceinline__ void solver_commit(const Args& a, int pair, BlockState& s, int lane, const SolverCarry& c, bool write_stats = true) {
+    if (c.fast) {                                          // the step went out on the series path: |omega|^2 < 0.01
+        const SE3d dT = se3_exp_small(c.x);
         __builtin_amdgcn_sched_barrier(0);
         const SE3d Tcur = load_se3(s.u.q, s.u.t);
         const SE3d Tn = se3_mul(Tcur, dT);
@@ -1004,6 +1005,40 @@ __device__ __attribute__((noinline)) void solver_finish(double* T_cur_w_pair, in
         out[8] = R[6]; out[9] = R[7]; out[10] = R[8]; out[11] = To.tz;
         *n_tracked_pair = s.n_vis;
     }
+}
+
+// The workspace kernel's solving wave is also a patch wave: with the solver inlined, its temporaries and the two dozen
+// 64-bit constants of the series (which the compiler materialises in VGPRs ahead of the kernel's loops) share the
+// register file with the pass. In the two-member kernel, with the exchange on top, they were spilled at 256 VGPRs and
+// reloaded from scratch one by one inside the solve (188 B of scratch per lane): out of line the solver has its own
+// allocation, +7 % (256 x 2000 patches 0.420 -> 0.448 M alignments/s). The one-member kernel keeps the solver inline (out
+// of line: -1..2 %, the call and the carry through LDS sit on the iteration's critical path). Everything goes in and out
+// through LDS (pointers qualified as such: a generic pointer would turn every access into a flat load).
+struct SolverArgs {               // what solver_step / solver_commit read of the kernel arguments
+    dsdtm_align_stats* stats;     // null: no statistics from this workgroup
+    int max_iters;
+};
+template <int NP>
+__device__ __attribute__((noinline)) void ws_solver_step(const LdsWavePartial* part, LdsBlockState* sp,
+                                                         __attribute__((address_space(3))) SolverCarry* cp,
+                                                         int pair, int level, int it, int lane) {
+    BlockState& s = *(BlockState*)sp;
+    // row of H^+ from LDS at every step (refresh_hinv_to_lds parks it there): nothing of the solver is live across the pass
+    double hrow[6];
+    const int li = lane < 6 ? lane : 5;
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];
+    const SolverArgs al{nullptr, 0};
+    SolverCarry c;
+    (void)solver_step<NP>(al, pair, level, it, (const WavePartial*)part, s, lane, hrow, c);
+    if (lane == 0) *(SolverCarry*)cp = c;
+}
+__device__ __attribute__((noinline)) void ws_solver_commit(LdsBlockState* sp, const __attribute__((address_space(3))) SolverCarry* cp,
+                                                           dsdtm_align_stats* stats, int max_iters, int pair, int lane) {
+    BlockState& s = *(BlockState*)sp;
+    const SolverCarry c = *(const SolverCarry*)cp;
+    const SolverArgs al{stats, max_iters};
+    solver_commit(al, pair, s, lane, c, true);
 }
 
 // Hand-over protocol of the register kernel (pair-local counters, see pair_signal_arrive & co.):
@@ -1425,6 +1460,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
     __shared__ WavePartial s_part[NPW];
     __shared__ WavePartial s_mpart[MEMBERS == 2 ? 2 : 1];              // two members: one partial per member, member order
     __shared__ BlockState s;
+    __shared__ SolverCarry s_carry;                                    // two members: solver_step -> solver_commit, both out of line
     extern __shared__ __attribute__((aligned(16))) uint32_t ws_win[];   // [16][WCAP]: 15 window planes + origins
 
     int pair = blockIdx.x, member = 0;
@@ -1580,16 +1616,10 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                 s_part[wave].h_changed = h_new ? 1 : 0;
             }
             __syncthreads();                                           // B1
-            SolverCarry carry;
+            SolverCarry carry1;                                        // one member: solver inline, the carry in registers
             if (solves) {
-                // row of H^+ from LDS at every step (refresh_hinv_to_lds parks it there): nothing of the solver
-                // is live in registers across the pass
-                double hrow[6];
-                const int li = lane < 6 ? lane : 5;
-#pragma unroll
-                for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];
+                auto* const carry = (__attribute__((address_space(3))) SolverCarry*)&s_carry;
                 if constexpr (MEMBERS == 2) {
-                    carry.fast = false;
                     if (dead) {
                         if (lane == 0) s.ctrl = 1;
                     } else {
@@ -1642,16 +1672,28 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        (void)solver_step<2>(a, pair, level, it, s_mpart, s, lane, hrow, carry);
-                        if (!ok) { dead = true; carry.fast = false; if (lane == 0) s.ctrl = 1; }
+                        ws_solver_step<2>((const LdsWavePartial*)s_mpart, (LdsBlockState*)&s, carry, pair, level, it, lane);
+                        if (!ok) { dead = true; if (lane == 0) s.ctrl = 1; }
                     }
                     ++g_it;
                 } else {
-                    (void)solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry);
+                    // row of H^+ from LDS at every step (refresh_hinv_to_lds parks it there): nothing of the solver
+                    // is live in registers across the pass
+                    double hrow[6];
+                    const int li = lane < 6 ? lane : 5;
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj) hrow[jj] = s.Hinv[jj * 6 + li];
+                    (void)solver_step<NPW>(a, pair, level, it, s_part, s, lane, hrow, carry1);
                 }
             }
             __syncthreads();                                           // B2
-            if (solves && !(MEMBERS == 2 && dead)) solver_commit(a, pair, s, lane, carry, member == 0);   // member 0 alone writes statistics
+            if constexpr (MEMBERS == 2) {
+                if (solves && !dead)                                   // member 0 alone writes statistics
+                    ws_solver_commit((LdsBlockState*)&s, (const __attribute__((address_space(3))) SolverCarry*)&s_carry,
+                                     member == 0 ? a.stats : nullptr, a.max_iters, pair, lane);
+            } else {
+                if (solves) solver_commit(a, pair, s, lane, carry1);
+            }
             if (s.ctrl) break;
         }
     }
