@@ -866,3 +866,56 @@ def test_two_member_pairs_ragged_counts_determinism_and_the_one_unit_path(gpu_ct
     with capi.debug_options(ws_no_duo=1):
         T3, n3, s3 = run()
     assert np.array_equal(n1, n3) and np.array_equal(s1["iters"], s3["iters"]) and np.abs(T1 - T3).max() < 1e-12
+
+
+def _roll_scene(theta, radius, n, seed, width=640, height=480, levels=4):
+    """Features inside a disc around the principal point and a roll of `theta` rad between the frames: small pixel
+    motion for a large angle, so the first Gauss-Newton step at the coarsest level is a rotation of ~theta."""
+    import dataclasses
+    sc = synth.make_scene(width=width, height=height, levels=levels, n_patches=n, seed=seed, xi=(0, 0, 0, 0, 0, theta), depth=2.0)
+    rng = np.random.default_rng(seed)
+    ang, r = rng.uniform(0, 2 * np.pi, n), radius * np.sqrt(rng.uniform(0, 1, n))
+    px = np.stack([sc.cam.cx + r * np.cos(ang), sc.cam.cy + r * np.sin(ang)], axis=1).astype(np.float32)
+    bearing = synth.bearing_from_px(sc.cam, px)
+    return dataclasses.replace(sc, px=px, bearing=bearing, p_world=bearing * (sc.depth / bearing[:, 2:3]))
+
+
+@pytest.mark.parametrize("n,batch", [(60, 0), (300, 0), (1000, 0), (800, 66), (1500, 66)])
+def test_rotation_steps_beyond_a_tenth_of_a_radian(gpu_ctx, oracle, n, batch):
+    """SE3::exp of a step with |omega|^2 >= 0.01 leaves the power series for the closed forms (sincos), which the
+    kernels keep out of line: a roll of 0.15 / 0.25 rad seen by features near the principal point makes the first step
+    at the coarsest level that large (checked on the oracle). One pair on the register kernels (60, 300 features) and on
+    a team (1000); batches of 66 pairs (more teams than fit at once) on the workspace kernel (800) and on two compute
+    units per pair (1500)."""
+    import ctypes as C
+    cases = [(0.15, 80.0), (0.25, 80.0)]
+    scs = [_roll_scene(th, rad, n, seed=31 + k) for k, (th, rad) in enumerate(cases)]
+    for sc, (th, rad) in zip(scs, cases):
+        T1, _, _ = oracle.sparse_align(sc, 4, 3, 1)                  # the first step alone
+        assert synth.pose_error(T1, sc.T_cur_w_seed)[0] > 0.1, "the scene does not produce a large step"
+    want = [oracle.sparse_align(sc, 4, 0, 10) for sc in scs]
+    if batch == 0:
+        for sc, (To, no, so) in zip(scs, want):
+            Tg, ng, sg = H.gpu_sparse_align(sc, 4, 0, 10, ctx=gpu_ctx)
+            H.assert_pose_close(Tg, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"n {n}")
+            assert ng == no and sg["iters"] == so["iters"] and sg["exit_code"] == so["exit_code"]
+            assert synth.pose_error(Tg, sc.T_cur_w_true)[0] < 0.2 * abs(np.arccos((np.trace(sc.T_cur_w_true[:, :3]) - 1) / 2))   # and it converges
+        return
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    group = [scs[i % 2] for i in range(batch)]
+    t, b = _device_batch(torch, dev, group, 4, 640, 480)
+    t["st"] = torch.zeros((batch, capi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    b.stats = t["st"].data_ptr()
+    cam = capi.camera_struct(scs[0].cam)
+    prm = capi.AlignParams(4, 0, 10, 15)
+    torch.cuda.synchronize()
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), None))
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, None))
+    Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+    st = np.frombuffer(t["st"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
+    for i in range(batch):
+        To, no, so = want[i % 2]
+        H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"n {n} pair {i}")
+        assert ntg[i] == no and list(st["iters"][i][:4]) == list(so["iters"][:4]) and list(st["exit_code"][i][:4]) == list(so["exit_code"][:4])
