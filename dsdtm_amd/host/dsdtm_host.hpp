@@ -152,25 +152,48 @@ public:
         std::vector<uint8_t> ini((size_t)n);
         for (int i = 0; i < n; ++i) {
             px[2 * i] = f[i].mpx_x; px[2 * i + 1] = f[i].mpx_y; ini[i] = f[i].mbInitial ? 1 : 0;
-            // :93 mvFeatures[i]->Mpt->Get_Pose(), snapshotted once per Run (features without a MapPoint object
-            // carry the position themselves)
-            const std::array<double, 3>& P = f[i].Mpt ? map_point_pose(f[i].Mpt) : f[i].mMptPose;
-            for (int k = 0; k < 3; ++k) { bearing[3 * i + k] = f[i].mNormal[k]; pw[3 * i + k] = P[k]; }
+            for (int k = 0; k < 3; ++k) bearing[3 * i + k] = f[i].mNormal[k];
         }
+        // :93 mvFeatures[i]->Mpt->Get_Pose() (features without a MapPoint object carry the position themselves)
+        auto snapshot = [&]() {
+            for (int i = 0; i < n; ++i) {
+                const std::array<double, 3>& P = f[i].Mpt ? map_point_pose(f[i].Mpt) : f[i].mMptPose;
+                for (int k = 0; k < 3; ++k) pw[3 * i + k] = P[k];
+            }
+        };
         const Camera& c = *tRefFrame->mCamera;
         const dsdtm_camera cam{c.mfx, c.mfy, c.mcx, c.mcy, c.mf, c.mwidth, c.mheight};
         const dsdtm_pyramid ref = detail::to_pyr(tRefFrame->mvImg_Pyr), cur = detail::to_pyr(tCurFrame->mvImg_Pyr);
         SE3 Tc = tCurFrame->Get_Pose();
-        const dsdtm_align_params prm{mnMaxLevel, mnMinLevel, mnMaxIterators, mnMinfts};
         int n_tracked = 0;
-        const int rc = (tRefFrame->mDev && tCurFrame->mDev)
-            ? dsdtm_sparse_align_frames(detail::ctx(), tRefFrame->mDev, tCurFrame->mDev, &cam, px.data(), bearing.data(),
-                                        pw.data(), ini.data(), n, tRefFrame->Get_Pose().m.data(), Tc.m.data(), &prm,
-                                        &n_tracked, &last_stats)
-            : dsdtm_sparse_align(detail::ctx(), &ref, &cur, &cam, px.data(), bearing.data(), pw.data(),
-                                 ini.data(), n, tRefFrame->Get_Pose().m.data(), Tc.m.data(), &prm,
-                                 &n_tracked, &last_stats);
-        if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_sparse_align: ") + dsdtm_last_error(detail::ctx()));
+        auto levels = [&](int max_level, int min_level, dsdtm_align_stats* st) {
+            const dsdtm_align_params prm{max_level, min_level, mnMaxIterators, mnMinfts};
+            const int rc = (tRefFrame->mDev && tCurFrame->mDev)
+                ? dsdtm_sparse_align_frames(detail::ctx(), tRefFrame->mDev, tCurFrame->mDev, &cam, px.data(), bearing.data(),
+                                            pw.data(), ini.data(), n, tRefFrame->Get_Pose().m.data(), Tc.m.data(), &prm,
+                                            &n_tracked, st)
+                : dsdtm_sparse_align(detail::ctx(), &ref, &cur, &cam, px.data(), bearing.data(), pw.data(),
+                                     ini.data(), n, tRefFrame->Get_Pose().m.data(), Tc.m.data(), &prm,
+                                     &n_tracked, st);
+            if (rc != DSDTM_OK) throw std::runtime_error(std::string("dsdtm_sparse_align: ") + dsdtm_last_error(detail::ctx()));
+        };
+        if (!mbSnapshotPerLevel) {
+            snapshot();                                          // once per Run: the whole Run is one device launch
+            levels(mnMaxLevel, mnMinLevel, &last_stats);
+        } else {
+            // The reference reads Mpt->Get_Pose() at the top of EVERY level (src/Sprase_ImageAlign.cpp:84-103), so a
+            // local-BA update of the map can land between two levels of one Run. This mode keeps that: one launch per
+            // level, the map points read before each (the pose carried from level to level is the same SE(3) element up
+            // to the rounding of T_c2r * T_ref and back: ~1e-16, same iterations).
+            last_stats = dsdtm_align_stats{};
+            for (int l = mnMaxLevel - 1; l >= mnMinLevel; --l) {
+                dsdtm_align_stats st{};
+                snapshot();
+                levels(l + 1, l, &st);
+                last_stats.iters[l] = st.iters[l]; last_stats.n_ref[l] = st.n_ref[l]; last_stats.n_vis[l] = st.n_vis[l];
+                last_stats.exit_code[l] = st.exit_code[l]; last_stats.chi2[l] = st.chi2[l];
+            }
+        }
         if (n < mnMinfts) {                                  // src/Sprase_ImageAlign.cpp:34-38
             std::fprintf(stderr, "Too few features to track\n");
             return 0;                                        // pose untouched
@@ -179,6 +202,7 @@ public:
         return n_tracked;                                    // :59
     }
 
+    bool mbSnapshotPerLevel = false;   // true: map points re-read before every level, one launch per level (see Run)
     dsdtm_align_stats last_stats{};
 
 protected:

@@ -75,6 +75,18 @@ int main(int argc, char** argv) {
     std::printf("resident %d\npose_resident", n_resident);
     for (double v : cur->Get_Pose().m) std::printf(" %.17g", v);
     std::printf("\n");
+    // the same Run with the map points re-read before every level, as the reference does (one launch per level)
+    {
+        cur->Set_Pose(Tc);
+        align.mbSnapshotPerLevel = true;
+        const int n_lv = align.Run(cur, ref);
+        align.mbSnapshotPerLevel = false;
+        std::printf("per_level %d\npose_per_level", n_lv);
+        for (double v : cur->Get_Pose().m) std::printf(" %.17g", v);
+        std::printf("\niters_per_level");
+        for (int l = 0; l < levels; ++l) std::printf(" %d", align.last_stats.iters[l]);
+        std::printf("\n");
+    }
     // keyframe creation (src/Tracking.cpp:416): detect new features on the current frame, which holds none yet
     Config::MaxPyraLevels() = levels;
     Feature_detector detector(hdr[6], hdr[7]);

@@ -73,6 +73,12 @@ def test_cpp_driver_matches_oracle(tmp_path, oracle):
     assert int(out[4].split()[1]) == n
     Tres = np.array([float(v) for v in out[5].split()[1:]]).reshape(3, 4)
     assert np.array_equal(Tres, T)
+    # the third Run re-read the map points before every level (one launch per level, as the reference's per-level
+    # Get_Pose, src/Sprase_ImageAlign.cpp:84-103): same count and iterations, the pose to the rounding of the hand-over
+    assert int(out[6].split()[1]) == n
+    Tlv = np.array([float(v) for v in out[7].split()[1:]]).reshape(3, 4)
+    assert [int(v) for v in out[8].split()[1:]] == iters
+    assert np.abs(Tlv - T).max() < 1e-12
     # Feature_detector::detect of the C++ layer on the (feature-less) current frame vs the sequential restatement
     from tests import detector_restatement as R
     import math
@@ -80,7 +86,7 @@ def test_cpp_driver_matches_oracle(tmp_path, oracle):
     cols, rows = math.ceil(320 / cell), math.ceil(240 / cell)
     cells = oracle.detect_cells(sc.cur_pyr, 3, cell, cols, rows, None, 5.0)
     want_det = R.detect(cells, 320, 240, cell, 200, [], [], 30)
-    det = [int(v) for v in out[6].split()[1:]]
+    det = [int(v) for v in out[9].split()[1:]]
     assert det[0] == len(want_det) and det[0] > 10
     assert [tuple(det[1 + 3 * i:4 + 3 * i]) for i in range(det[0])] == want_det
 
