@@ -124,3 +124,54 @@ def test_warp_patches_match_oracle(gpu_ctx, oracle):
     if lv.any():
         assert (pbo[lv].max(axis=1) == pbo[lv].min(axis=1)).all()
         assert (pbg[lv].max(axis=1) == pbg[lv].min(axis=1)).all()
+
+
+def test_device_entry_equals_the_host_entry(gpu_ctx, oracle):
+    """dsdtm_align2d_batch_device (patches, pixels and the packed pyramid already in HBM, launch on the caller's
+    stream) against the oracle: flags and pixels bit for bit, NaN write-backs included, mixed levels."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    pyr = _texture_pyr(seed=6, levels=3)
+    m = 900
+    level = rng.integers(0, 3, m).astype(np.int32)
+    pbs, ps, px0 = [], [], []
+    for i in range(m):
+        img = pyr[level[i]]
+        h, w = img.shape
+        c = (rng.uniform(12, w - 12), rng.uniform(12, h - 12))
+        pb, p = H.make_border_patches(img, [c])
+        if i % 97 == 0:
+            pb[0][:] = 77; p[0][:] = 77                                # constant patch: singular H, NaN written back (A2)
+        pbs.append(pb[0]); ps.append(p[0])
+        px0.append([c[0] + rng.uniform(-1.5, 1.5), c[1] + rng.uniform(-1.5, 1.5)])
+    px0 = np.array(px0)
+    co, pxo = oracle.align2d_batch(pyr, pbs, ps, level, px0, 10)
+    ws, hs, ss, offs, nb = capi.pyramid_layout(pyr[0].shape[1], pyr[0].shape[0], 3)
+    packed = np.zeros(nb, np.uint8)
+    for l in range(3):
+        packed[offs[l]:offs[l] + ws[l] * hs[l]] = pyr[l].reshape(-1)
+    d_pyr = torch.from_numpy(packed).to(dev)
+    d_pb, d_p = torch.from_numpy(np.stack(pbs).reshape(m, 100)).to(dev), torch.from_numpy(np.stack(ps).reshape(m, 64)).to(dev)
+    d_px, d_lv = torch.from_numpy(px0.copy()).to(dev), torch.from_numpy(level).to(dev)
+    d_cv = torch.zeros(m, dtype=torch.uint8, device=dev)
+    img = capi.ImageDesc()
+    img.levels = 3
+    for l in range(3):
+        img.width[l], img.height[l], img.stride[l], img.level_offset[l] = ws[l], hs[l], ss[l], offs[l]
+    img.bytes, img.data = nb, d_pyr.data_ptr()
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_align2d_batch_device(gpu_ctx.handle, C.byref(img), d_pb.data_ptr(), d_p.data_ptr(), d_lv.data_ptr(),
+                                                         d_px.data_ptr(), d_cv.data_ptr(), 10, m, st.cuda_stream))
+    st.synchronize()
+    assert np.array_equal(d_cv.cpu().numpy().astype(bool), co)
+    assert np.array_equal(d_px.cpu().numpy(), pxo, equal_nan=True)
+    assert np.isnan(pxo).any() and co.mean() > 0.8
+    # argument checks of the device entry: no features is not an error, a missing pointer is
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_align2d_batch_device(gpu_ctx.handle, C.byref(img), d_pb.data_ptr(), d_p.data_ptr(), d_lv.data_ptr(),
+                                                         d_px.data_ptr(), d_cv.data_ptr(), 10, 0, st.cuda_stream))
+    assert gpu_ctx.lib.dsdtm_align2d_batch_device(gpu_ctx.handle, C.byref(img), None, d_p.data_ptr(), d_lv.data_ptr(),
+                                                  d_px.data_ptr(), d_cv.data_ptr(), 10, m, st.cuda_stream) == capi.ERR_INVALID

@@ -919,3 +919,59 @@ def test_rotation_steps_beyond_a_tenth_of_a_radian(gpu_ctx, oracle, n, batch):
         To, no, so = want[i % 2]
         H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"n {n} pair {i}")
         assert ntg[i] == no and list(st["iters"][i][:4]) == list(so["iters"][:4]) and list(st["exit_code"][i][:4]) == list(so["exit_code"][:4])
+
+
+@pytest.mark.parametrize("N", [800, 1500, 2000])
+def test_workspace_launches_are_graph_capturable_after_reserve(gpu_ctx, oracle, N):
+    """Batches of large pairs inside a hipGraph: up to 1024 patches everything is in LDS (nothing to reserve); beyond,
+    a live launch grows its stream's workspace on demand, which a captured launch cannot — it is refused with a message
+    until dsdtm_reserve(dsdtm_sparse_align_workspace_bytes(batch)) has run, and then uses the context's reserved
+    workspace: 1500 patches park their grid inputs there, 2000 run on two compute units per pair and keep their
+    exchange words there (zeroed by a memset node of the graph at every replay)."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, P = 320, 240, 3, 66
+    base = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=2500 + i, margin=12) for i in range(3)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in base]
+    scs = [base[i % 3] for i in range(P)]
+    t, b = _device_batch(torch, dev, scs, L, W, Hh)
+    seed = t["Tc"].clone()
+    cam = capi.camera_struct(base[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    ctx = capi.Context(0)                                        # a context of its own: nothing reserved yet
+    need = ctx.lib.dsdtm_sparse_align_workspace_bytes(C.byref(b))
+    assert (need == 0) == (N <= 1024)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    if need:
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0, stream=side):
+            t["Tc"].copy_(seed)
+            rc = ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm),
+                                                         torch.cuda.current_stream().cuda_stream)
+        assert rc == capi.ERR_INVALID and b"dsdtm_reserve" in ctx.lib.dsdtm_last_error(ctx.handle)
+        del g0
+        ctx.check(ctx.lib.dsdtm_reserve(ctx.handle, need))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        t["Tc"].copy_(seed)
+        ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm),
+                                                          torch.cuda.current_stream().cuda_stream))
+    first = None
+    for rep in range(3):
+        t["Tc"].zero_(); t["nt"].zero_()
+        g.replay()
+        ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, None))
+        torch.cuda.synchronize()
+        Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+        for i in range(P):
+            To, no, _ = want[i % 3]
+            H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"N {N} replay {rep} pair {i}")
+            assert ntg[i] == no
+        if first is None:
+            first = Tg.copy()
+        assert np.array_equal(first, Tg)
+    del g
+    ctx.close()
