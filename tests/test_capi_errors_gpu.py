@@ -145,3 +145,89 @@ def test_align2d_pyramid_and_shard_entries(gpu_ctx):
     assert got == [(0, 4), (4, 8), (8, 10)]
     lib.dsdtm_shard_range(2, 3, 2, C.byref(lo), C.byref(hi))
     assert lo.value == hi.value
+
+
+def test_detector_pyramid_pose_and_sharded_entries(gpu_ctx):
+    from dsdtm_amd import synth
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    tex = np.clip(np.rint(synth.make_texture(120, 160, 9)), 0, 255).astype(np.uint8)
+    pyr = synth.build_pyramid(tex, 3)
+    ps, keep = capi.pyramid_struct(pyr)
+    G = 7 * 5
+    occ = np.zeros(G, np.uint8)
+    score = np.zeros(G, np.float32)
+    cx, cy, cl = (np.zeros(G, np.int32) for _ in range(3))
+    ip, fp, dp = C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double)
+
+    def det(prm, scorep=score):
+        return lib.dsdtm_detect_cells(h, C.byref(ps), occ.ctypes.data_as(capi.u8p), C.byref(prm),
+                                      scorep.ctypes.data_as(fp) if scorep is not None else None, cx.ctypes.data_as(ip), cy.ctypes.data_as(ip),
+                                      cl.ctypes.data_as(ip))
+
+    good = capi.DetectParams(25, 7, 5, 3, 20, 5.0)
+    for bad in [capi.DetectParams(0, 7, 5, 3, 20, 5.0), capi.DetectParams(25, 0, 5, 3, 20, 5.0), capi.DetectParams(25, 7, 5, 4, 20, 5.0),
+                capi.DetectParams(25, 7, 5, 3, 255, 5.0), capi.DetectParams(25, 7, 5, 3, 20, float("nan")),
+                capi.DetectParams(25, 7, 5, 3, 20, -1.0), capi.DetectParams(25, 1 << 13, 1 << 13, 3, 20, 5.0)]:
+        _refused(gpu_ctx, det(bad), "detector parameters")
+    _refused(gpu_ctx, det(good, scorep=None), "NULL")
+    gpu_ctx.check(det(good))
+    assert (score > 0).any()
+
+    # cv::pyrDown chain: geometry that is not a pyramid, missing outputs
+    lv = [np.zeros((60, 80), np.uint8), np.zeros((30, 40), np.uint8)]
+    outs = (C.c_void_p * 3)(None, lv[0].ctypes.data, lv[1].ctypes.data)
+    strides = (C.c_int * 3)(160, 80, 40)
+    l0 = tex.ctypes.data_as(capi.u8p)
+    _refused(gpu_ctx, lib.dsdtm_pyrdown(h, l0, 160, 120, 100, 3, outs, strides), "bad argument")          # stride < width
+    _refused(gpu_ctx, lib.dsdtm_pyrdown(h, l0, 160, 120, 160, 9, outs, strides), "bad argument")          # more than DSDTM_MAX_LEVELS
+    _refused(gpu_ctx, lib.dsdtm_pyrdown(h, None, 160, 120, 160, 3, outs, strides), "bad argument")
+    _refused(gpu_ctx, lib.dsdtm_pyrdown(h, l0, 160, 120, 160, 3, None, strides), "bad argument")
+    short = (C.c_int * 3)(160, 80, 39)
+    _refused(gpu_ctx, lib.dsdtm_pyrdown(h, l0, 160, 120, 160, 3, outs, short), "output level 2")
+    gpu_ctx.check(lib.dsdtm_pyrdown(h, l0, 160, 120, 160, 3, outs, strides))
+    assert np.array_equal(lv[0], pyr[1]) and np.array_equal(lv[1], pyr[2])
+    import torch
+    d = torch.zeros(40000, dtype=torch.uint8, device="cuda:0")
+    w3, h3, s3 = (C.c_int * 3)(160, 80, 41), (C.c_int * 3)(120, 60, 30), (C.c_int * 3)(160, 80, 41)
+    off = (C.c_size_t * 3)(0, 19200, 24000)
+    _refused(gpu_ctx, lib.dsdtm_pyrdown_batch_device(h, d.data_ptr(), 40000, 1, 3, w3, h3, s3, off, None), "is not ((w+1)/2")
+    w3[2] = s3[2] = 40
+    _refused(gpu_ctx, lib.dsdtm_pyrdown_batch_device(h, d.data_ptr(), 25000, 1, 3, w3, h3, s3, off, None), "does not fit")
+    _refused(gpu_ctx, lib.dsdtm_pyrdown_batch_device(h, None, 40000, 1, 3, w3, h3, s3, off, None), "bad argument")
+    gpu_ctx.check(lib.dsdtm_pyrdown_batch_device(h, d.data_ptr(), 40000, 1, 3, w3, h3, s3, off, None))
+    torch.cuda.synchronize()
+
+    # pose refinement: a used feature on a level the pyramid cannot have; NULL outputs
+    n = 30
+    bear, pw = np.zeros((n, 3)), np.ones((n, 3))
+    bear[:, 2] = 1.0
+    level, use = np.zeros(n, np.int32), np.ones(n, np.uint8)
+    T = np.ascontiguousarray(np.eye(4)[:3].reshape(12))
+    norms = np.zeros(n)
+    summ = capi.PoseOptSummary()
+    prm = capi.PoseOptParams(5, 0)
+
+    lib.dsdtm_pose_optimization.restype = C.c_int
+    lib.dsdtm_pose_optimization.argtypes = [C.c_void_p, dp, dp, ip, capi.u8p, C.c_int, dp, C.POINTER(capi.PoseOptParams), dp,
+                                            C.POINTER(capi.PoseOptSummary)]
+
+    def po(lvl=level, Tp=T, sm=summ):
+        return lib.dsdtm_pose_optimization(h, bear.ctypes.data_as(dp), pw.ctypes.data_as(dp), lvl.ctypes.data_as(ip), use.ctypes.data_as(capi.u8p), n,
+                                           Tp.ctypes.data_as(dp) if Tp is not None else None, C.byref(prm), norms.ctypes.data_as(dp),
+                                           C.byref(sm) if sm is not None else None)
+
+    lv_bad = level.copy(); lv_bad[7] = capi.MAX_LEVELS
+    _refused(gpu_ctx, po(lvl=lv_bad), "feature 7")
+    _refused(gpu_ctx, po(Tp=None), "NULL")
+    _refused(gpu_ctx, po(sm=None), "NULL")
+
+    # the sharded entry wants one context per shard and host pointers
+    sc = cached_scene(width=320, height=240, levels=3, n_patches=60, seed=5, margin=12)
+    hb = capi.BatchDesc()                                                # all pointers NULL
+    hb.n_pairs, hb.max_features, hb.levels = 1, 60, 3
+    cam = capi.camera_struct(sc.cam)
+    ap = capi.AlignParams(3, 0, 10, 15)
+    two = (C.c_void_p * 2)(h, h)
+    _refused(gpu_ctx, lib.dsdtm_sparse_align_batch_sharded(two, 1, C.byref(hb), C.byref(cam), C.byref(ap)), "NULL host pointers")
+    assert lib.dsdtm_sparse_align_batch_sharded(two, 0, C.byref(hb), C.byref(cam), C.byref(ap)) == capi.ERR_INVALID
+    assert lib.dsdtm_sparse_align_batch_sharded(None, 2, C.byref(hb), C.byref(cam), C.byref(ap)) == capi.ERR_INVALID
