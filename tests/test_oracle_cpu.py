@@ -217,3 +217,49 @@ def test_interpolated_reference_intensities_are_exact_in_fp64():
             fwd = ((w[0] * q[0] + w[1] * q[1]) + w[2] * q[2]) + w[3] * q[3]
             rev = ((w[3] * q[3] + w[2] * q[2]) + w[1] * q[1]) + w[0] * q[0]
             assert Fraction(float(fwd)) == exact and Fraction(float(rev)) == exact
+
+
+def test_restated_third_party_arithmetic_against_scipy(oracle):
+    """The third-party pieces of the path are not under /root/reference (Sophus, Eigen, OpenCV) and are
+    restated in the oracle from their published definitions. Independent implementations to hold them against: scipy's
+    matrix exponential of the 4x4 twist (SE3::exp), scipy's Rotation (quaternion -> matrix, composition), LAPACK through
+    numpy (H x = b), and scipy.ndimage's separable correlation with mirrored borders (cv::pyrDown = [1 4 6 4 1]^2 / 256,
+    BORDER_REFLECT_101, rounded half up, every second pixel)."""
+    from scipy.linalg import expm
+    from scipy.ndimage import correlate1d
+    from scipy.spatial.transform import Rotation
+    lib = oracle.load()
+    rng = np.random.default_rng(42)
+    for i in range(40):
+        xi = rng.standard_normal(6) * (1e-9 if i % 8 == 0 else (0.05 if i % 2 else 1.5))
+        u, w = xi[:3], xi[3:]
+        tw = np.zeros((4, 4))
+        tw[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+        tw[:3, 3] = u
+        E = oracle.OracleSE3()
+        lib.oracle_se3_exp(_arr(xi).ctypes.data_as(dp), C.byref(E))
+        T = np.zeros(12)
+        lib.oracle_se3_to_rt(C.byref(E), T.ctypes.data_as(dp))
+        assert np.allclose(T.reshape(3, 4), expm(tw)[:3], atol=1e-12)
+        q = np.array(list(E.q))                                                        # (w, x, y, z)
+        assert np.allclose(Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix(), T.reshape(3, 4)[:, :3], atol=1e-13)
+        xj = rng.standard_normal(6) * 0.3
+        Ej, Ek = oracle.OracleSE3(), oracle.OracleSE3()
+        lib.oracle_se3_exp(_arr(xj).ctypes.data_as(dp), C.byref(Ej))
+        lib.oracle_se3_mul(C.byref(E), C.byref(Ej), C.byref(Ek))
+        Tk = np.zeros(12)
+        lib.oracle_se3_to_rt(C.byref(Ek), Tk.ctypes.data_as(dp))
+        twj = np.zeros((4, 4))
+        twj[:3, :3] = [[0, -xj[5], xj[4]], [xj[5], 0, -xj[3]], [-xj[4], xj[3], 0]]
+        twj[:3, 3] = xj[:3]
+        assert np.allclose(Tk.reshape(3, 4), (expm(tw) @ expm(twj))[:3], atol=1e-12)
+        J = rng.standard_normal((40, 6)) * np.array([20, 20, 20, 90, 90, 90])
+        Hm, b, x = J.T @ J, rng.standard_normal(6), np.zeros(6)
+        lib.oracle_ldlt6_solve(_arr(Hm.reshape(36)).ctypes.data_as(dp), _arr(b).ctypes.data_as(dp), x.ctypes.data_as(dp))
+        assert np.allclose(x, np.linalg.solve(Hm, b), rtol=1e-7, atol=1e-12)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    for shape in [(48, 64), (37, 53), (9, 9), (5, 12)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        acc = correlate1d(correlate1d(img.astype(np.int64), k, axis=0, mode="mirror"), k, axis=1, mode="mirror")
+        want = ((acc + 128) >> 8)[::2, ::2].astype(np.uint8)
+        assert np.array_equal(oracle.pyrdown(img), want)
