@@ -933,6 +933,25 @@ def main():
         ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(descs[k]), C.byref(cam_struct), C.byref(prm),
                                                           streams[k % n_streams].cuda_stream))
 
+    # For the record, the same W + K steps BEFORE the pre-roll, i.e. on a GPU that sat idle while the host prepared the
+    # batch: 'value_from_idle' in the line (wall clock around the K steps, max over ranks; the pose slots are re-seeded)
+    elapsed_idle = None
+    if args.preroll > 0:
+        for k in range(args.warmup):
+            step(k)
+        torch.cuda.synchronize()
+        barrier()
+        ti = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed_idle = time.perf_counter() - ti
+        if world > 1:
+            elapsed_idle = shard.max_over_ranks(elapsed_idle, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
+        d["T_steps"].copy_(d["T_seed"].unsqueeze(0).expand(n_slots, -1, -1))
+        torch.cuda.synchronize()
+
     # Pre-roll: the same launches on pose buffers of their own, so that the W warm-up steps and the K timed steps run on
     # a GPU that is out of its idle clocks whatever W is (reported in the line; never part of the timed region)
     preroll_ms = 0.0
@@ -1060,10 +1079,12 @@ def main():
             "n_tracked_mean": float(ntg.mean()),
             "err_vs_ground_truth_median": {"rad": float(np.median(err[:, 0])), "m": float(np.median(err[:, 1]))},
             "library": ctx.lib.dsdtm_version().decode(),
+            "value_from_idle": (n_total / elapsed_idle) if elapsed_idle else None,
             "preroll": {"launches": args.preroll, "ms": preroll_ms,
                         "note": "untimed launches of the same step before the 'warmup' steps, on pose buffers of their own: the GPU "
                                 "leaves its idle clocks over ~40 ms of load (tools/warmup_sweep.sh, profiles/r03_warmup_sweep.txt); "
-                                "--preroll 0 measures from idle"},
+                                "value_from_idle = the same W + K steps timed before the pre-roll, in this process; "
+                                "--preroll 0 makes that the value"},
         }
         if not args.no_cpu and world == 1:
             sample = min(args.cpu_sample, args.pairs)
