@@ -933,22 +933,53 @@ def main():
         ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(descs[k]), C.byref(cam_struct), C.byref(prm),
                                                           streams[k % n_streams].cuda_stream))
 
-    # For the record, the same W + K steps BEFORE the pre-roll, i.e. on a GPU that sat idle while the host prepared the
-    # batch: 'value_from_idle' in the line (wall clock around the K steps, max over ranks; the pose slots are re-seeded)
-    elapsed_idle = None
-    if args.preroll > 0:
+    per_kernel = n_streams == 1
+
+    def timed_region():
+        """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides.
+        One stream: HIP events around every launch. Several streams: one pair around the whole timed region (its span is
+        what a step costs the GPU; events around every launch were tried — they cost 4 % and, with other streams' kernels
+        in flight, do not bracket the kernel). Returns (wall seconds, max over ranks; per-launch ms list or None; span ms)."""
         for k in range(args.warmup):
             step(k)
+        for s in streams:
+            s.synchronize()
         torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_kernel else 0)]
+        span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        join = [torch.cuda.Event() for _ in streams]
         barrier()
-        ti = time.perf_counter()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if not per_kernel:
+            span[0].record(streams[0])            # span of the whole timed region on the launch streams
+            for s in streams[1:]:
+                s.wait_event(span[0])
         for k in range(args.steps):
+            if per_kernel:
+                ev[k][0].record(stream)           # HIP events on the stream the kernel is launched on
             step(args.warmup + k)
+            if per_kernel:
+                ev[k][1].record(stream)
+        if not per_kernel:
+            for i, s in enumerate(streams[1:], 1):
+                join[i].record(s)
+                streams[0].wait_event(join[i])
+            span[1].record(streams[0])
+        for s in streams:
+            s.synchronize()
         torch.cuda.synchronize()
         barrier()
-        elapsed_idle = time.perf_counter() - ti
+        el = time.perf_counter() - t0
         if world > 1:
-            elapsed_idle = shard.max_over_ranks(elapsed_idle, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
+            el = shard.max_over_ranks(el, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
+        return el, ([x.elapsed_time(y) for x, y in ev] if per_kernel else None), (None if per_kernel else span[0].elapsed_time(span[1]))
+
+    # For the record, the same W + K steps BEFORE the pre-roll, i.e. on a GPU that sat idle while the host prepared the
+    # batch and through streams in their first use: 'value_from_idle' in the line (what --preroll 0 reports as the value)
+    elapsed_idle = None
+    if args.preroll > 0:
+        elapsed_idle = timed_region()[0]
         d["T_steps"].copy_(d["T_seed"].unsqueeze(0).expand(n_slots, -1, -1))
         torch.cuda.synchronize()
 
@@ -973,52 +1004,14 @@ def main():
         torch.cuda.synchronize()
         preroll_ms = (time.perf_counter() - tp) * 1e3
 
-    for k in range(args.warmup):
-        step(k)
-    for s in streams:
-        s.synchronize()
-    torch.cuda.synchronize()
-
-    per_kernel = n_streams == 1
-    # One stream: HIP events around every launch. Several streams: one pair around the whole timed region (its span is
-    # what a step costs the GPU; events around every launch were tried — they cost 4 % and, with other streams' kernels
-    # in flight, do not bracket the kernel)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_kernel else 0)]
-    span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    join = [torch.cuda.Event() for _ in streams]
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if not per_kernel:
-        span[0].record(streams[0])            # span of the whole timed region on the launch streams
-        for s in streams[1:]:
-            s.wait_event(span[0])
-    for k in range(args.steps):
-        if per_kernel:
-            ev[k][0].record(stream)           # HIP events on the stream the kernel is launched on
-        step(args.warmup + k)
-        if per_kernel:
-            ev[k][1].record(stream)
-    if not per_kernel:
-        for i, s in enumerate(streams[1:], 1):
-            join[i].record(s)
-            streams[0].wait_event(join[i])
-        span[1].record(streams[0])
-    for s in streams:
-        s.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        elapsed = shard.max_over_ranks(elapsed, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
+    elapsed, kernel_ms, span_ms = timed_region()
     ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, stream.cuda_stream))   # no hand-over wait timed out in any launch
     d["T_cur_w"] = d["T_steps"][n_slots - 1].clone()  # the last step's results are the ones checked below
     if per_kernel:
-        kernel_ms = [a.elapsed_time(b) for a, b in ev]
         k_avg, k_min, k_extra = float(np.mean(kernel_ms)), float(np.min(kernel_ms)), {}
         k_basis = "HIP events around every launch on the launch stream (one stream: launches do not overlap)"
     else:
-        k_avg = span[0].elapsed_time(span[1]) / args.steps
+        k_avg = span_ms / args.steps
         k_min = None
         # a short one-stream burst OUTSIDE the timed region: the duration of the kernel when nothing overlaps it
         solo_n = min(30, args.warmup + args.steps)
