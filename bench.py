@@ -475,8 +475,8 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
 def tracked_frame_entries(torch, dev, ctx, stream):
     """The other kernels of a tracked frame, each as a device-resident batch with its own roofline block: Align2D
     (src/Feature_alignment.cpp:318-417), the pose-only refinement (src/Optimizer.cpp:20-101) and the detector's image
-    work (src/Feature_detection.cpp:69-154). Device time by HIP events on the launch stream. (The warp prelude runs
-    inside dsdtm_match_candidates_frames; its device time is in profiles/r03_kernel_stats.csv, case `track`.)"""
+    work (src/Feature_detection.cpp:69-154), and FindMatchDirect = warp prelude + Align2D for the candidates of many current
+    frames in one call (src/Feature_alignment.cpp:128-275). Device time by HIP events on the launch stream."""
     from dsdtm_amd import capi, synth
     from tests import helpers
     out = []
@@ -568,6 +568,57 @@ def tracked_frame_entries(torch, dev, ctx, stream):
                              "note": "~330 FP64 flops per residual-block evaluation x (iterations + 1) x blocks; the features of a frame "
                                      "(11 KB) stay in L1/L2: bound by the latency of its dependent FP64 chain, not by HBM"}})
     del d_b, d_w, d_l, d_u, d_T0, d_T, d_rn, d_sm
+
+    # ---- FindMatchDirect for many current frames: warp prelude (affine, search level, 10x10 warp, 8x8 cut) + Align2D
+    Wm, Hm, Lm, nfm, ncand = 640, 480, 5, 64, 800
+    ws, hs, ss, offs, nb = capi.pyramid_layout(Wm, Hm, Lm)
+    pitch = (nb + 255) // 256 * 256
+    cur_pack, kf_pack, cols = np.zeros((8, pitch), np.uint8), np.zeros((8, pitch), np.uint8), []
+    Tk8, Tc8 = np.zeros((8, 12)), np.zeros((8, 12))
+    for i in range(8):
+        scn = synth.make_scene(width=Wm, height=Hm, levels=Lm, n_patches=ncand, seed=900 + i, margin=30)
+        for l in range(Lm):
+            kf_pack[i, offs[l]:offs[l] + ws[l] * hs[l]] = scn.ref_pyr[l].reshape(-1)
+            cur_pack[i, offs[l]:offs[l] + ws[l] * hs[l]] = scn.cur_pyr[l].reshape(-1)
+        Tk8[i], Tc8[i] = scn.T_ref_w.reshape(12), scn.T_cur_w_true.reshape(12)
+        Xc = scn.p_world @ scn.T_cur_w_true[:, :3].T + scn.T_cur_w_true[:, 3]
+        pxc = np.stack([scn.cam.fx * Xc[:, 0] / Xc[:, 2] + scn.cam.cx, scn.cam.fy * Xc[:, 1] / Xc[:, 2] + scn.cam.cy], 1)
+        cols.append((scn.px, scn.bearing, scn.p_world, pxc + np.random.default_rng(i).uniform(-1.0, 1.0, pxc.shape)))
+    cam_m = capi.camera_struct(scn.cam)
+    rep_ = nfm // 8
+    Mm = nfm * ncand
+    d_cur, d_kf = tdev(np.tile(cur_pack, (rep_, 1))), tdev(np.tile(kf_pack, (rep_, 1)))
+    d_Tk, d_Tc = tdev(np.tile(Tk8, (rep_, 1))), tdev(np.tile(Tc8, (rep_, 1)))
+    fr_idx = np.repeat(np.arange(nfm, dtype=np.int32), ncand)
+    d_fr, d_kfi = tdev(fr_idx), tdev(fr_idx.copy())                       # candidate -> its current frame / its keyframe (one each)
+    d_rp = tdev(np.tile(np.concatenate([c[0] for c in cols]), (rep_, 1)).astype(np.float32))
+    d_rl = torch.zeros(Mm, dtype=torch.int32, device=dev)
+    d_rb, d_pw = tdev(np.tile(np.concatenate([c[1] for c in cols]), (rep_, 1))), tdev(np.tile(np.concatenate([c[2] for c in cols]), (rep_, 1)))
+    d_px0 = tdev(np.tile(np.concatenate([c[3] for c in cols]), (rep_, 1)))
+    d_px = d_px0.clone()
+    d_sl, d_cv = torch.zeros(Mm, dtype=torch.int32, device=dev), torch.zeros(Mm, dtype=torch.uint8, device=dev)
+    d_scr = torch.empty(ctx.lib.dsdtm_match_candidates_scratch_bytes(Mm), dtype=torch.uint8, device=dev)
+    wa, ha, sa, oa = (C.c_int * Lm)(*ws), (C.c_int * Lm)(*hs), (C.c_int * Lm)(*ss), (C.c_size_t * Lm)(*offs)
+
+    def fmd():
+        with torch.cuda.stream(stream):
+            d_px.copy_(d_px0, non_blocking=True)
+        ctx.check(ctx.lib.dsdtm_match_candidates_batch_device(
+            ctx.handle, d_cur.data_ptr(), nfm, d_kf.data_ptr(), nfm, pitch, Lm, wa, ha, sa, oa, C.byref(cam_m), d_Tk.data_ptr(), d_Tc.data_ptr(),
+            d_fr.data_ptr(), d_kfi.data_ptr(), d_rp.data_ptr(), d_rl.data_ptr(), d_rb.data_ptr(), d_pw.data_ptr(), Lm - 3, 10, Mm,
+            d_scr.data_ptr(), d_px.data_ptr(), d_sl.data_ptr(), d_cv.data_ptr(), stream.cuda_stream))
+    ms = timed(fmd)
+    b_cand = 4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1 + 2 * (100 + 64)   # candidate columns in, pixel in/out, level + flag out, patches through scratch
+    alg = Mm * b_cand + 2 * nfm * ws[0] * hs[0]                            # + level 0 of every keyframe and current frame once
+    out.append({"workload": f"Feature_Alignment::FindMatchDirect: {Mm} candidates of {nfm} current frames per call ({ncand} each, {Wm}x{Hm}): "
+                            f"SolveAffineMatrix, GetBestSearchLevel, WarpAffine, GetPatchNoBoarder, Align2DGaussNewton (cap 10)",
+                "value": Mm / (ms * 1e-3), "unit": "candidates/s", "us_per_frame": ms * 1e3 / nfm,
+                "matched_fraction": float(d_cv.float().mean().item()),
+                "roofline": roofline_block("warp", alg, ms, None, Mm, b_cand, "candidate",
+                                           {"note": "two launches (warp prelude: one thread per candidate, FP64 chain in the reference's operation "
+                                                    "order; Align2D: one wavefront per candidate); latency-bound, the bytes are 433 per candidate "
+                                                    "+ the level-0 images once"})})
+    del d_cur, d_kf, d_rp, d_rb, d_pw, d_px0, d_px, d_scr
 
     # ---- detector image work: 256 frames of 640x480x5 levels per call
     Wd, Hd, Ld, nfr = 640, 480, 5, 256
