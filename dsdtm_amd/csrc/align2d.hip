@@ -74,12 +74,13 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
     float* const prod = s_prod[threadIdx.x >> 6];
     if (f >= a.m) return;
     const int lvl = a.level[f];
-    if (lvl < 0 || lvl >= a.levels) {                    // invalid level: report "not converged"
+    const int fr = a.frame ? a.frame[f] : 0;
+    if (lvl < 0 || lvl >= a.levels || fr < 0 || (a.frame && fr >= a.n_frames)) {   // invalid level / frame: report "not converged"
         if (lane == 0) a.converged[f] = 0;
         return;
     }
     const LevelGeom lg = a.lv[lvl];
-    const uint8_t* __restrict__ img = a.cur_pyr + (a.frame ? (size_t)a.frame[f] * a.pyr_pitch : 0) + lg.off;
+    const uint8_t* __restrict__ img = a.cur_pyr + (size_t)fr * a.pyr_pitch + lg.off;
     const int img_size = lg.stride * lg.h;
 
     const int r = lane >> 3, c = lane & 7;

@@ -54,7 +54,34 @@ struct dsdtm_ctx {
     hipEvent_t team_event = nullptr;      // recorded behind the last team launch that ran on a caller's stream
     hipStream_t team_last_stream = nullptr;
     bool team_any = false;
-    unsigned* d_timeout_flag = nullptr;   // device address of the kernel's hand-over timeout flag
+    // Hand-over timeout words: host-mapped pinned memory of THIS context (a wave whose bounded wait ran out stores 1;
+    // the host reads the word once the launch's stream has drained — no copy, no device-global state):
+    //   [0, MAX_STREAMS)            one per stream ring: the one-CU launches of that stream
+    //   FLAG_GRAPH                  launches captured into hipGraphs
+    //   FLAG_SINGLE                 the synchronous single-pair entry points
+    //   FLAG_RECOVER + slot         one per multi-CU launch (team / two-member kernels) that has not been settled yet
+    static constexpr int RECOVER_SLOTS = 64;
+    static constexpr int FLAG_GRAPH = MAX_STREAMS, FLAG_SINGLE = MAX_STREAMS + 1, FLAG_RECOVER = MAX_STREAMS + 2,
+                         N_FLAGS = FLAG_RECOVER + RECOVER_SLOTS;
+    volatile unsigned* h_flags = nullptr;
+    unsigned* d_flags = nullptr;
+    // Multi-CU launches wait on partner workgroups, i.e. on the GPU's dispatch: a wait that runs out (a foreign load on
+    // the device, another partition mode) must not fail the caller. Every such launch leaves what a re-run needs —
+    // descriptor, a copy of its seed poses, an event — and is settled by dsdtm_sparse_align_check (or when its slot is
+    // needed again): timeout word clear -> forgotten; set -> poses re-seeded, the same batch relaunched on the one-CU
+    // kernels, which cannot wait for anything outside their own workgroup.
+    struct Recover {
+        bool used = false;
+        dsdtm_batch_desc b; dsdtm_camera cam; dsdtm_align_params prm;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        void* d_seed = nullptr; size_t seed_cap = 0;
+        unsigned long long order = 0;
+    };
+    Recover rec[RECOVER_SLOTS];
+    unsigned long long rec_tick = 0;
+    unsigned long long recovered = 0;     // launches re-run on the one-CU kernels so far (dsdtm_debug_recovered_launches)
+    bool multi_cu_ok = true;              // the dispatch assumptions of the multi-CU kernels hold on this device
     int num_cus = 256;
 };
 
@@ -94,6 +121,7 @@ const OptionKey kOptionKeys[] = {
     {"no_zero_copy", "DSDTM_NO_ZERO_COPY", &dsdtm::Options::no_zero_copy, true},
     {"po_no_cache", "DSDTM_PO_NO_CACHE", &dsdtm::Options::po_no_cache, true},
     {"a2d_tree", "DSDTM_A2D_TREE", &dsdtm::Options::a2d_tree, true},
+    {"no_recover", "DSDTM_NO_RECOVER", &dsdtm::Options::no_recover, true},
 };
 std::once_flag g_options_once;
 void options_from_env() {
@@ -154,12 +182,29 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
         return DSDTM_ERR_HIP;
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        // The team / two-member kernels place the members of a pair on one XCD by workgroup number (b, b + 8, ...) and
+        // rely on all 256 CUs being one partition: anything else (CPX/DPX/QPX modes, fewer XCDs) runs the one-CU kernels.
+        int xccs = 0;
+        if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device) != hipSuccess) xccs = 0;
+        ctx->multi_cu_ok = (xccs == 8 && ctx->num_cus == 256);
+    }
     const size_t counter_bytes = sizeof(unsigned) * (dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + dsdtm_ctx::GRAPH_COUNTERS);
-    if (hipMalloc((void**)&ctx->d_counter, counter_bytes) != hipSuccess ||
+    void* hf = nullptr;
+    void* hfd = nullptr;
+    if (hipHostMalloc(&hf, sizeof(unsigned) * dsdtm_ctx::N_FLAGS, hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer(&hfd, hf, 0) == hipSuccess) {
+        memset(hf, 0, sizeof(unsigned) * dsdtm_ctx::N_FLAGS);
+        ctx->h_flags = (volatile unsigned*)hf; ctx->d_flags = (unsigned*)hfd;
+    }
+    if (!ctx->d_flags ||
+        hipMalloc((void**)&ctx->d_counter, counter_bytes) != hipSuccess ||
         hipMalloc((void**)&ctx->d_team, 8 * sparse_align_team_bytes(64)) != hipSuccess ||
         hipMemset(ctx->d_counter, 0, counter_bytes) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->team_event, hipEventDisableTiming) != hipSuccess) {
         if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+        if (ctx->d_team) (void)hipFree(ctx->d_team);
+        if (hf) (void)hipHostFree(hf);
         set_err(nullptr, "hipMalloc failed on device %d", device);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -195,6 +240,8 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->d_team) (void)hipFree(ctx->d_team);
     if (ctx->team_event) (void)hipEventDestroy(ctx->team_event);
+    for (auto& r : ctx->rec) { if (r.d_seed) (void)hipFree(r.d_seed); if (r.done) (void)hipEventDestroy(r.done); }
+    if (ctx->h_flags) (void)hipHostFree((void*)ctx->h_flags);
     delete ctx;
 }
 
@@ -257,11 +304,60 @@ static int ring_mark_launch(dsdtm_ctx* ctx, int ring, hipStream_t stream) {
 }
 
 static thread_local void* g_stamp_out = nullptr;   // device buffer, set only by the stamps debug entry
-static thread_local unsigned* g_timeout_out = nullptr;   // host-mapped word, set by the single-pair entry points
 static thread_local int g_team_drop_members = 0;         // set only by dsdtm_debug_sparse_align_short_team
+
+// How a launch is accounted for (see dsdtm_ctx::h_flags / Recover)
+struct LaunchMode {
+    bool one_cu = false;        // never a team / two-member kernel (re-runs after a timeout, captured launches)
+    bool single = false;        // synchronous single-pair entry: its own timeout word, settled by the caller itself
+};
+static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam, const dsdtm_align_params* prm,
+                        void* hip_stream, const LaunchMode& mode, bool* multi_cu_used);
+static int recover_settle(dsdtm_ctx* ctx, int slot, hipStream_t rerun_stream);
 
 extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam,
                                                const dsdtm_align_params* prm, void* hip_stream) {
+    return launch_batch(ctx, b, cam, prm, hip_stream, LaunchMode{}, nullptr);
+}
+
+// A free recovery slot. When all are taken, the oldest launch is settled first (its event is waited for; a launch
+// that timed out is re-run on the context's stream): at most RECOVER_SLOTS unchecked multi-CU launches are in flight.
+static int recover_acquire(dsdtm_ctx* ctx, int* slot_out) {
+    int oldest = -1;
+    for (int i = 0; i < dsdtm_ctx::RECOVER_SLOTS; ++i) {
+        if (!ctx->rec[i].used) { *slot_out = i; return DSDTM_OK; }
+        if (oldest < 0 || ctx->rec[i].order < ctx->rec[oldest].order) oldest = i;
+    }
+    HIP_TRY(ctx, hipEventSynchronize(ctx->rec[oldest].done));
+    if (int rc = recover_settle(ctx, oldest, ctx->stream)) return rc;
+    *slot_out = oldest;
+    return DSDTM_OK;
+}
+
+// Settles slot `slot` (its launch has finished): forgotten when its timeout word is clear; otherwise the batch is
+// re-seeded and re-run on the one-CU kernels on `rerun_stream`, which is then waited for.
+static int recover_settle(dsdtm_ctx* ctx, int slot, hipStream_t rerun_stream) {
+    dsdtm_ctx::Recover& r = ctx->rec[slot];
+    if (!r.used) return DSDTM_OK;
+    r.used = false;
+    volatile unsigned* flag = ctx->h_flags + dsdtm_ctx::FLAG_RECOVER + slot;
+    if (!*flag) return DSDTM_OK;
+    *flag = 0;
+    if (options().no_recover) {
+        set_err(ctx, "sparse-align kernel: a wait for a partner workgroup timed out (re-run disabled: no_recover)");
+        return DSDTM_ERR_HIP;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(r.b.T_cur_w, r.d_seed, (size_t)r.b.n_pairs * 96, hipMemcpyDeviceToDevice, rerun_stream));
+    LaunchMode m;
+    m.one_cu = true;
+    if (int rc = launch_batch(ctx, &r.b, &r.cam, &r.prm, rerun_stream, m, nullptr)) return rc;
+    ctx->recovered += 1;
+    return dsdtm_sparse_align_check(ctx, rerun_stream);
+}
+
+static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam, const dsdtm_align_params* prm,
+                        void* hip_stream, const LaunchMode& mode, bool* multi_cu_used) {
+    if (multi_cu_used) *multi_cu_used = false;
     if (!ctx) return DSDTM_ERR_INVALID;
     if (!b || !cam) { set_err(ctx, "batch/cam is NULL"); return DSDTM_ERR_INVALID; }
     if (int rc = validate_params(ctx, prm, b->levels)) return rc;
@@ -307,6 +403,7 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         }
         a.pair_counter = ctx->d_counter + dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + ctx->graph_counters_used++;
         HIP_TRY(ctx, hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned), stream));   // memset node: replays heal themselves
+        a.timeout_flag = ctx->d_flags + dsdtm_ctx::FLAG_GRAPH;
     } else {
         int ri = -1;
         for (int i = 0; i < dsdtm_ctx::MAX_STREAMS && ri < 0; ++i)
@@ -337,8 +434,9 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
         ctx->rings[ri].last_use = ++ctx->ring_tick;
         a.pair_counter = ctx->d_counter + ri * dsdtm_ctx::COUNTERS_PER_STREAM + (ctx->rings[ri].seq++ % dsdtm_ctx::COUNTERS_PER_STREAM);
         ring = ri;
+        a.timeout_flag = ctx->d_flags + ri;
     }
-    a.timeout_out = g_timeout_out;
+    if (mode.single) a.timeout_flag = ctx->d_flags + dsdtm_ctx::FLAG_SINGLE;
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
         if (b->max_features > 320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
         a.workspace = (double*)g_stamp_out;
@@ -352,26 +450,63 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
     // of OTHER kinds on other streams can still delay a member: such a wait ends when their workgroups drain; a
     // wait that does not end raises the timeout flag, see dsdtm_sparse_align_check). Not used while capturing
     // (a graph replay could not be ordered against live team launches): those shapes take the one-CU kernels.
-    const bool no_team = options().no_team != 0;
-    if (const int k = (b->n_pairs <= 64 && !no_team && !capturing) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0) {
+    // Multi-CU kernels only where their dispatch assumptions hold, never in a re-run, never while capturing (a graph
+    // replay could neither be ordered against live team launches nor be re-run after a timeout).
+    const bool multi_cu = ctx->multi_cu_ok && !mode.one_cu && !capturing;
+    const int team_k = (multi_cu && b->n_pairs <= 64 && !options().no_team) ? sparse_align_team_size(b->n_pairs, b->max_features, ctx->num_cus) : 0;
+    const SAVariant v = sparse_align_pick_variant(b->max_features);
+    const size_t ws = sparse_align_workspace_bytes(b->n_pairs, b->max_features);
+    const bool duo = !team_k && multi_cu && sparse_align_uses_duo(b->max_features, ws != 0);
+    int slot = -1;
+    if ((team_k || duo) && !mode.single) {
+        // what a re-run needs, should a wait for a partner workgroup run out (dsdtm_ctx::Recover)
+        if (int rc = recover_acquire(ctx, &slot)) return rc;
+        dsdtm_ctx::Recover& r = ctx->rec[slot];
+        const size_t seed_bytes = (size_t)b->n_pairs * 96;
+        if (seed_bytes > r.seed_cap) {
+            if (r.d_seed) (void)hipFree(r.d_seed);     // (the slot is free: nothing in flight uses its buffer)
+            r.d_seed = nullptr; r.seed_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&r.d_seed, align_up(seed_bytes, 4096)));
+            r.seed_cap = align_up(seed_bytes, 4096);
+        }
+        if (!r.done) HIP_TRY(ctx, hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipMemcpyAsync(r.d_seed, b->T_cur_w, seed_bytes, hipMemcpyDeviceToDevice, stream));
+        r.b = *b; r.cam = *cam; r.prm = *prm; r.stream = stream; r.order = ++ctx->rec_tick;
+        ctx->h_flags[dsdtm_ctx::FLAG_RECOVER + slot] = 0;
+        a.timeout_flag = ctx->d_flags + dsdtm_ctx::FLAG_RECOVER + slot;
+    }
+    if (multi_cu_used) *multi_cu_used = team_k || duo;
+    auto launched_multi_cu = [&]() -> int {
+        if (slot < 0) return DSDTM_OK;
+        HIP_TRY(ctx, hipEventRecord(ctx->rec[slot].done, stream));
+        ctx->rec[slot].used = true;
+        return DSDTM_OK;
+    };
+    // Few pairs of more than 448 features: one pair over K compute units. The members of a team spin on each
+    // other, so all of a launch's workgroups must be resident together: sparse_align_team_size admits a launch
+    // only when it fills at most half the CUs, and the team launches of a context are totally ordered — one on
+    // another stream first waits for the previous one's event — so two of them never compete for CUs (kernels
+    // of OTHER kinds on other streams can still delay a member: such a wait ends when their workgroups drain; a
+    // wait that does not end raises the launch's timeout word and the batch is re-run on the one-CU kernels, see
+    // recover_settle).
+    if (const int k = team_k) {
         if (ctx->team_any && ctx->team_last_stream != stream) {
             // the context's own stream is alive as long as the context: its event is recorded on demand;
             // launches on a caller's stream left theirs behind (that stream may be gone by now)
             if (ctx->team_last_stream == ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->team_event, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->team_event, 0));
         }
-        uint8_t* slot = ctx->d_team + (size_t)(ctx->team_seq++ & 7u) * sparse_align_team_bytes(64);
-        a.workspace = (double*)slot;
-        HIP_TRY(ctx, hipMemsetAsync(slot, 0, sparse_align_team_bytes(b->n_pairs), stream));
+        uint8_t* tslot = ctx->d_team + (size_t)(ctx->team_seq++ & 7u) * sparse_align_team_bytes(64);
+        a.workspace = (double*)tslot;
+        HIP_TRY(ctx, hipMemsetAsync(tslot, 0, sparse_align_team_bytes(b->n_pairs), stream));
         if (g_team_drop_members) a.spin_limit = 1u << 12;      // the test's waits give up after ~4 k polls
         HIP_TRY(ctx, sparse_align_launch_team(a, k, stream, g_team_drop_members));
+        if (int rc = launched_multi_cu()) return rc;
         if (int rc = ring_mark_launch(ctx, ring, stream)) return rc;
         if (stream != ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->team_event, stream));
         ctx->team_any = true; ctx->team_last_stream = stream;
         return DSDTM_OK;
     }
-    const SAVariant v = sparse_align_pick_variant(b->max_features);
-    const size_t ws = sparse_align_workspace_bytes(b->n_pairs, b->max_features);
     if (ws) {
         // Scratch of the workspace kernel. A live launch uses its STREAM's workspace (the stream runs its launches
         // in order, so launches on different streams never share scratch; grown on demand, which synchronises that
@@ -393,32 +528,52 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
             a.workspace = (double*)r.d_ws;
         }
     }
-    HIP_TRY(ctx, sparse_align_launch(a, v, ctx->num_cus, stream));
+    if (duo && g_team_drop_members) { a.spin_limit = 1u << 12; a.debug_drop = 1; }    // tests: member 1 of every pair stays away
+    HIP_TRY(ctx, sparse_align_launch(a, v, ctx->num_cus, stream, duo));
+    if (int rc = launched_multi_cu()) return rc;
     return ring_mark_launch(ctx, ring, stream);
 }
 
-// Result check for callers of the asynchronous batch entry point: waits for `hip_stream`, then reads (and clears)
-// the kernels' hand-over timeout flag. DSDTM_OK, or DSDTM_ERR_HIP when a wait inside a kernel ran out — the
-// results of the launches since the last check are then not to be trusted. (The single-pair host entry points
-// do this themselves.)
+// Result check for callers of the asynchronous batch entry point: waits for `hip_stream`, then settles the launches
+// issued on it since the last check. Multi-CU launches (team / two-member kernels) whose wait for a partner workgroup
+// ran out are re-run on the one-CU kernels here — the caller sees DSDTM_OK and the results the reference's Run would
+// have produced. DSDTM_ERR_HIP remains for a hand-over that failed INSIDE one workgroup (a broken protocol, never
+// observed) or a re-run that failed too; the results of this stream's launches since the last check are then not to
+// be trusted. Everything read here belongs to this context: no device-wide synchronisation, no device-global state.
 extern "C" int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream) {
     if (!ctx) return DSDTM_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)hip_stream));
-    if (!ctx->d_timeout_flag) HIP_TRY(ctx, sparse_align_timeout_flag_address(&ctx->d_timeout_flag));
-    unsigned flag = 0;
-    HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_timeout_flag, sizeof flag, hipMemcpyDeviceToHost));
-    if (flag) {
-        // the rare path: launches of this context may still be in flight on other streams (each owns live counter
-        // words), and the flag is device-global — wait for the whole device before anything is reset
-        (void)hipDeviceSynchronize();
-        (void)sparse_align_clear_timeout_flag();
-        (void)hipMemset(ctx->d_counter, 0, sizeof(unsigned) * (dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + dsdtm_ctx::GRAPH_COUNTERS));
-        set_err(ctx, "sparse-align kernel: a hand-over wait timed out (results since the last check are invalid)");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    // this stream's multi-CU launches, in launch order (a re-run may feed a later launch of the same stream: the caller
+    // sees final results only after this function returns)
+    for (;;) {
+        int next = -1;
+        for (int i = 0; i < dsdtm_ctx::RECOVER_SLOTS; ++i)
+            if (ctx->rec[i].used && ctx->rec[i].stream == stream && (next < 0 || ctx->rec[i].order < ctx->rec[next].order)) next = i;
+        if (next < 0) break;
+        if (int rc = recover_settle(ctx, next, stream)) return rc;
+    }
+    int ring = -1;
+    for (int i = 0; i < dsdtm_ctx::MAX_STREAMS; ++i)
+        if (ctx->rings[i].used && ctx->rings[i].stream == stream) ring = i;
+    bool bad = false;
+    if (ring >= 0 && ctx->h_flags[ring]) {
+        ctx->h_flags[ring] = 0;
+        // a pair that was stopped may have left its counter word behind: this stream's words (it has drained)
+        (void)hipMemsetAsync(ctx->d_counter + ring * dsdtm_ctx::COUNTERS_PER_STREAM, 0, sizeof(unsigned) * dsdtm_ctx::COUNTERS_PER_STREAM, stream);
+        (void)hipStreamSynchronize(stream);
+        bad = true;
+    }
+    if (ctx->h_flags[dsdtm_ctx::FLAG_GRAPH]) { ctx->h_flags[dsdtm_ctx::FLAG_GRAPH] = 0; bad = true; }   // (graph launches zero their own counters)
+    if (bad) {
+        set_err(ctx, "sparse-align kernel: a hand-over wait inside a workgroup timed out (results of this stream since the last check are invalid)");
         return DSDTM_ERR_HIP;
     }
     return DSDTM_OK;
 }
+
+extern "C" long long dsdtm_debug_recovered_launches(dsdtm_ctx* ctx) { return ctx ? (long long)ctx->recovered : -1; }
 
 // ---- the batch from host memory over several contexts / devices ------------------------------
 extern "C" void dsdtm_shard_range(int n_pairs, int n_shards, int shard, int* lo, int* hi) {
@@ -491,14 +646,35 @@ extern "C" int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx
     for (int g = 0; g < n_ctx; ++g)
         for (int h = g + 1; h < n_ctx; ++h)
             if (ctx[g] == ctx[h]) { set_err(ctx[0], "sharded batch: a context appears twice (one context per shard)"); return DSDTM_ERR_INVALID; }
+    // the descriptor is checked BEFORE any shard sizes its staging from it or a thread is started
+    if (hb->max_features < 0 || hb->max_features > 32767 || hb->levels <= 0 || hb->levels > DSDTM_MAX_LEVELS ||
+        hb->pyr_pitch == 0 || (hb->pyr_pitch & 3) || hb->pyr_pitch > 0xffffffffull) {
+        set_err(ctx[0], "sharded batch: bad geometry (max_features 0..32767, levels 1..%d, pyr_pitch a non-zero multiple of 4 below 4 GiB)",
+                DSDTM_MAX_LEVELS);
+        return DSDTM_ERR_INVALID;
+    }
+    if (int rc0 = validate_params(ctx[0], prm, hb->levels)) return rc0;
+    for (int l = 0; l < hb->levels; ++l) {
+        const size_t end = hb->level_offset[l] + (size_t)hb->stride[l] * hb->height[l];
+        if (hb->width[l] <= 0 || hb->height[l] <= 0 || hb->stride[l] < hb->width[l] || end > hb->pyr_pitch) {
+            set_err(ctx[0], "sharded batch: level %d does not fit inside pyr_pitch", l); return DSDTM_ERR_INVALID;
+        }
+    }
     std::vector<int> rc(n_ctx, DSDTM_OK);
     std::vector<std::thread> th;
-    for (int g = 1; g < n_ctx; ++g) {
+    bool spawn_failed = false;
+    for (int g = 1; g < n_ctx && !spawn_failed; ++g) {
         int lo, hi;
         dsdtm_shard_range(hb->n_pairs, n_ctx, g, &lo, &hi);
-        th.emplace_back([=, &rc]() { rc[g] = sharded_one(ctx[g], hb, cam, prm, lo, hi); });
+        try {
+            th.emplace_back([=, &rc]() { rc[g] = sharded_one(ctx[g], hb, cam, prm, lo, hi); });
+        } catch (...) {           // no exception crosses the C boundary: the shards already started are joined below
+            spawn_failed = true;
+            rc[g] = DSDTM_ERR_NOMEM;
+            set_err(ctx[g], "sharded batch: could not start the host thread of shard %d", g);
+        }
     }
-    {
+    if (!spawn_failed) {
         int lo, hi;
         dsdtm_shard_range(hb->n_pairs, n_ctx, 0, &lo, &hi);
         rc[0] = sharded_one(ctx[0], hb, cam, prm, lo, hi);      // the calling thread takes the first shard
@@ -570,7 +746,7 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     const size_t o_nt = o; o += 256;
     const size_t o_st = o; o += align_up(sizeof(dsdtm_align_stats), 256);
     const size_t total = o;
-    if (int rc = ensure_stage(ctx, total + 256)) return rc;
+    if (int rc = ensure_stage(ctx, total)) return rc;
     uint8_t* h = (uint8_t*)ctx->h_pinned;
     uint8_t* d = (uint8_t*)ctx->d_stage;
     if (staged_pyr) {
@@ -606,24 +782,34 @@ static int sparse_align_one(dsdtm_ctx* ctx, const PackedPyr& pl, const dsdtm_pyr
     b.bearing = (const double*)(d + o_bear); b.p_world = (const double*)(d + o_pw); b.initial = d + o_ini;
     b.n_features = nullptr; b.T_ref_w = (const double*)(d + o_tr); b.T_cur_w = (double*)(d + o_tc);
     b.n_tracked = (int32_t*)(d + o_nt); b.stats = (dsdtm_align_stats*)(d + o_st);
-    unsigned* h_flag = (unsigned*)(h + total);
+    // Synchronous single-pair entry: its own timeout word, settled right here. A team launch whose wait for a partner
+    // workgroup ran out (a foreign load on the device) is re-run on the one-CU kernels from the seed pose, which is
+    // still in the pinned block: Run never fails for scheduling reasons (src/Sprase_ImageAlign.cpp:29-60).
+    volatile unsigned* h_flag = ctx->h_flags + dsdtm_ctx::FLAG_SINGLE;
     *h_flag = 0;
-    g_timeout_out = zero_copy ? (unsigned*)(d + total) : nullptr;        // the kernel writes the flag itself
-    const int rc_launch = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, ctx->stream);
-    g_timeout_out = nullptr;
-    if (rc_launch) return rc_launch;
-    if (!zero_copy) {
-        HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
-        // the kernel's hand-over timeout flag travels back with the results (no extra round trip)
-        if (!ctx->d_timeout_flag) HIP_TRY(ctx, sparse_align_timeout_flag_address(&ctx->d_timeout_flag));
-        HIP_TRY(ctx, hipMemcpyAsync(h_flag, ctx->d_timeout_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (*h_flag) {
-        (void)sparse_align_clear_timeout_flag();
-        (void)hipMemset(ctx->d_counter, 0, sizeof(unsigned) * (dsdtm_ctx::MAX_STREAMS * dsdtm_ctx::COUNTERS_PER_STREAM + dsdtm_ctx::GRAPH_COUNTERS));   // a pair that was stopped may have left its counter behind
-        set_err(ctx, "sparse-align kernel: intra-workgroup hand-over timed out");
-        return DSDTM_ERR_HIP;
+    LaunchMode mode;
+    mode.single = true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool multi_cu = false;
+        if (int rc_launch = launch_batch(ctx, &b, cam, prm, ctx->stream, mode, &multi_cu)) return rc_launch;
+        if (!zero_copy) HIP_TRY(ctx, hipMemcpyAsync(h + o_tc, d + o_tc, total - o_tc, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!*h_flag) break;
+        *h_flag = 0;
+        if (!multi_cu || attempt == 1 || options().no_recover) {
+            // (a pair that was stopped may have left its counter behind: the context stream's words)
+            for (int i = 0; i < dsdtm_ctx::MAX_STREAMS; ++i)
+                if (ctx->rings[i].used && ctx->rings[i].stream == ctx->stream)
+                    (void)hipMemset(ctx->d_counter + i * dsdtm_ctx::COUNTERS_PER_STREAM, 0, sizeof(unsigned) * dsdtm_ctx::COUNTERS_PER_STREAM);
+            set_err(ctx, multi_cu ? "sparse-align kernel: a wait for a partner workgroup timed out (re-run disabled: no_recover)"
+                                  : "sparse-align kernel: intra-workgroup hand-over timed out");
+            return DSDTM_ERR_HIP;
+        }
+        memcpy(h + o_tc, T_cur_w, 96);                      // the seed again
+        if (zero_copy) memset(h + o_nt, 0, total - o_nt);
+        else HIP_TRY(ctx, hipMemcpyAsync(d + o_tc, h + o_tc, 96, hipMemcpyHostToDevice, ctx->stream));
+        mode.one_cu = true;
+        ctx->recovered += 1;
     }
     memcpy(T_cur_w, h + o_tc, 96);
     *n_tracked = *(const int32_t*)(h + o_nt);
@@ -832,6 +1018,15 @@ extern "C" int dsdtm_detect_cells_batch_device(dsdtm_ctx* ctx, const uint8_t* py
     if (prm->cell_size <= 0 || prm->grid_cols <= 0 || prm->grid_rows <= 0 || prm->levels <= 0 || prm->levels > levels ||
         prm->barrier < 0 || prm->barrier > 254 || !(prm->detection_threshold >= 0.0f) ||
         (long long)prm->grid_cols * prm->grid_rows > (1 << 24)) { set_err(ctx, "bad detector parameters"); return DSDTM_ERR_INVALID; }
+    // the kernels fetch pyramid and score rows as dwords and index frames through the grid's z dimension
+    if ((pyr_pitch & 3) || (((size_t)pyr) & 3) || (((size_t)score_scratch) & 3)) {
+        set_err(ctx, "detector batch: pyramid base, score scratch and pyr_pitch must be 4-byte aligned"); return DSDTM_ERR_INVALID;
+    }
+    if ((long long)n_frames * prm->levels > 65535) {
+        set_err(ctx, "detector batch: n_frames * levels = %lld exceeds 65535 (one launch indexes frames through grid.z): split the batch",
+                (long long)n_frames * prm->levels);
+        return DSDTM_ERR_INVALID;
+    }
     if (n_frames == 0) return DSDTM_OK;
     DetectArgs a;
     memset(&a, 0, sizeof a);
@@ -1211,14 +1406,14 @@ extern "C" int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t
     a.kf_pyr = kf_pyr; a.kf_pitch = pyr_pitch; a.T_kf_w = T_kf_w; a.T_cur_w_arr = T_cur_w; a.cand_frame = cand_frame;
     a.cand_kf = cand_kf; a.ref_px = ref_px; a.ref_level = ref_level; a.ref_bearing = ref_bearing; a.p_world = p_world;
     a.affine = (double*)affine; a.search_level = search_level; a.patch_border = pb; a.patch = pp;
-    a.m = m; a.n_kf = n_kf; a.max_search_level = max_search_level; a.levels = levels;
+    a.m = m; a.n_kf = n_kf; a.max_search_level = max_search_level; a.levels = levels; a.n_frames = n_frames;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, warp_launch(a, (hipStream_t)hip_stream));
     A2DKernelArgs b;
     memset(&b, 0, sizeof b);
     b.cur_pyr = cur_pyr; b.patch_border = pb; b.patch = pp; b.level = search_level; b.px_xy = px_xy; b.converged = converged;
-    b.m = m; b.max_iters = max_iters; b.levels = levels; b.px_level0 = 1; b.frame = cand_frame; b.pyr_pitch = pyr_pitch;
+    b.m = m; b.max_iters = max_iters; b.levels = levels; b.px_level0 = 1; b.frame = cand_frame; b.n_frames = n_frames; b.pyr_pitch = pyr_pitch;
     for (int l = 0; l < levels; ++l) b.lv[l] = a.lv[l];
     HIP_TRY(ctx, align2d_launch(b, (hipStream_t)hip_stream));
     return DSDTM_OK;
@@ -1352,6 +1547,9 @@ extern "C" int dsdtm_debug_sparse_align_short_team(dsdtm_ctx* ctx, const dsdtm_b
     g_team_drop_members = 0;
     return rc;
 }
+
+// tests: every team / two-member launch of the calling thread loses its last member until this is called with 0
+extern "C" void dsdtm_debug_drop_team_members(int n) { g_team_drop_members = n > 0 ? 1 : 0; }
 
 extern "C" int dsdtm_debug_occupancy(dsdtm_ctx* ctx, int variant) {
     if (!ctx) return DSDTM_ERR_INVALID;

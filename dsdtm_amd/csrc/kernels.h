@@ -28,8 +28,10 @@ struct SAKernelArgs {
     dsdtm_align_stats* stats;
     double* workspace;
     unsigned* pair_counter;     // device word, zeroed before each launch: next pair index for the persistent slots
-    unsigned* timeout_out;      // optional (host-mapped) word: receives the hand-over timeout flag when a pair ends
+    unsigned* timeout_flag;     // host-mapped word of the launching context (multi-CU launches: a word of their own): set
+                                // to 1 by a wave whose bounded wait ran out; read by the host once the stream has drained
     unsigned spin_limit;        // team kernel: polls before a wait gives up (0 = the default, 2^24); tests shorten it
+    int debug_drop;             // tests only: member 1 of every two-member pair exits at once (its partner's waits run out)
     unsigned long long pyr_pitch;
     int n_pairs, max_features;
     int max_level, min_level, max_iters, min_fts;
@@ -52,6 +54,7 @@ struct Options {
     int no_zero_copy = 0;      // DSDTM_NO_ZERO_COPY: single-call entry points copy instead of mapping the pinned block
     int po_no_cache = 0;       // DSDTM_PO_NO_CACHE: pose refinement without features in registers
     int a2d_tree = 0;          // DSDTM_A2D_TREE: Align2D with DPP tree sums (cost comparison only; not bit-identical)
+    int no_recover = 0;        // DSDTM_NO_RECOVER: a multi-CU launch that timed out is reported, not re-run (tests)
 };
 Options& options();
 
@@ -59,10 +62,10 @@ constexpr int SA_PPW = 2;      // pair slots per workgroup of the <= 320-feature
 enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2, SA_REG128 = 3, SA_REG192 = 4, SA_REG256 = 5, SA_REG704 = 6 };
 SAVariant sparse_align_pick_variant(int max_features);
 size_t sparse_align_workspace_bytes(int n_pairs, int max_features);
-hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream);
-// diagnostic (in-kernel stamps) instantiation of the 5+1-wave register kernel; workspace = n_pairs*8 u64
-hipError_t sparse_align_timeout_flag_address(unsigned** addr);   // device-side hand-over timeout flag (should never be set)
-hipError_t sparse_align_clear_timeout_flag();
+// allow_multi_cu == false: shapes that would run one pair on two compute units take the one-CU kernel instead
+hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream, bool allow_multi_cu = true);
+// true when sparse_align_launch (with allow_multi_cu) would run this feature count as pairs on two compute units
+bool sparse_align_uses_duo(int max_features, bool have_workspace);
 // team kernel (one pair over K workgroups, 704 < N <= 4096, few pairs): K or 0; bytes of the zeroed team buffers
 int sparse_align_team_size(int n_pairs, int max_features, int num_cus);
 size_t sparse_align_team_bytes(int n_pairs);
@@ -101,6 +104,7 @@ struct A2DKernelArgs {
     int m, max_iters, levels;
     int px_level0;                // 1: px_xy is in level-0 pixels (divided by 2^level on load, multiplied back on store)
     const int32_t* frame;         // optional, M: feature i sits on the pyramid cur_pyr + frame[i] * pyr_pitch (batches of frames)
+    int n_frames;                 // with `frame`: indices outside [0, n_frames) are reported as not converged, never dereferenced
     size_t pyr_pitch;
     LevelGeom lv[DSDTM_MAX_LEVELS];
 };
@@ -133,6 +137,7 @@ struct WarpKernelArgs {
     double T_cur_w[12];
     const double* T_cur_w_arr;    // optional (batches of current frames): poses, 12 doubles each, indexed by cand_frame
     const int32_t* cand_frame;    // optional, M: the candidate's current frame
+    int n_frames;                 // with cand_frame: indices outside [0, n_frames) are rejected like an invalid cand_kf
     int m, n_kf, max_search_level, levels;
     float fx, fy, cx, cy;
     LevelGeom lv[DSDTM_MAX_LEVELS];

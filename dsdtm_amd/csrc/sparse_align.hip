@@ -46,6 +46,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "../../include/dsdtm_amd.h"
 #include "device_math.h"
 #include "kernels.h"
@@ -112,35 +114,34 @@ constexpr unsigned SPIN_LIMIT = 1u << 24;
 // s_sleep units between two polls: the solver waiting for the patch waves (and for acknowledgements) / the patch
 // waves waiting for the solver (polling less often leaves issue slots and LDS to the others: +1 %)
 constexpr int SLEEP_ARRIVE = 1, SLEEP_SEQ = 4;
-// A spin that runs out means the protocol is broken: the wave leaves the wait (so the kernel always
-// terminates) and raises this device-global flag, which the host entry points turn into an error.
-__device__ unsigned g_handover_timeout = 0;
-__device__ __forceinline__ void spin_timeout() { atomicOr(&g_handover_timeout, 1u); }
-// single-pair host calls read the flag from a host-mapped word instead of copying the symbol back
-__device__ __forceinline__ void report_timeout(const SAKernelArgs& a, int lane) {
-    if (a.timeout_out && lane == 0) *a.timeout_out = __hip_atomic_load(&g_handover_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// A spin that runs out means the protocol is broken (or, in the multi-CU kernels, that a partner workgroup is not
+// resident): the wave leaves the wait (so the kernel always terminates) and raises the launch's timeout word — a
+// host-mapped word owned by the launching CONTEXT (SAKernelArgs::timeout_flag; multi-CU launches get a word of their
+// own), which the host reads after the stream has drained: no device-global state, nothing shared between contexts.
+__device__ __forceinline__ void spin_timeout(unsigned* flag) {
+    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ void pair_signal_arrive(unsigned* counter, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS stores first
     if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void pair_wait_arrive(unsigned* counter, unsigned target) {
+__device__ __forceinline__ void pair_wait_arrive(unsigned* counter, unsigned target, unsigned* tflag) {
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < SPIN_LIMIT)
         __builtin_amdgcn_s_sleep(SLEEP_ARRIVE);
-    if (spins >= SPIN_LIMIT) spin_timeout();
+    if (spins >= SPIN_LIMIT) spin_timeout(tflag);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void pair_publish(BlockState& s, unsigned seq, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_store(&s.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void pair_wait_seq(BlockState& s, unsigned seq) {
+__device__ __forceinline__ void pair_wait_seq(BlockState& s, unsigned seq, unsigned* tflag) {
     unsigned spins = 0;
     while (__hip_atomic_load(&s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq && ++spins < SPIN_LIMIT)
         __builtin_amdgcn_s_sleep(SLEEP_SEQ);
-    if (spins >= SPIN_LIMIT) spin_timeout();
+    if (spins >= SPIN_LIMIT) spin_timeout(tflag);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -283,6 +284,9 @@ __device__ __forceinline__ RefGeom ref_geom(const FeatureRegs& F, const LevelGeo
     return g;
 }
 __device__ __forceinline__ uint32_t ref_row_offset(const LevelGeom& lg, const RefGeom& g, int r) {
+#ifdef DSDTM_EXP_NOGATHER   // experiment (tools/ws_cap.py): every lane fetches the level's first bytes — the cost of a level start WITHOUT its gathers
+    return lg.off;
+#endif
     return g.valid ? lg.off + (uint32_t)(g.fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(g.fu - 3) : lg.off;
 }
 // 7x7 u8 footprint rows fv-3..fv+3, cols fu-3..fu+3, fetched as aligned dwords. All seven row gathers
@@ -507,7 +511,11 @@ __device__ __forceinline__ void window_issue(const SAKernelArgs& a, const LevelG
     // precompute_patch)
 #pragma unroll
     for (int r = 0; r < WIN_ROWS; ++r) {
+#ifdef DSDTM_EXP_NOGATHER
+        const uint32_t o = lg.off;
+#else
         const uint32_t o = lg.off + (uint32_t)(v_i - HR + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 3);
+#endif
         f.w[r] = gather_x3(img32 + min(o >> 2, last_dw - 2u));
     }
 }
@@ -1137,7 +1145,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
         unsigned acks = 0;                                             // acknowledgements expected so far
         while (true) {
             // every patch wave has finished reading the previous pair's state (pair/run, final ctrl)
-            pair_wait_arrive(&s.ack, acks);
+            pair_wait_arrive(&s.ack, acks, a.timeout_flag);
             const bool have = pair < a.n_pairs;
             const int nf = have ? (a.n_features ? a.n_features[pair] : a.max_features) : 0;
             // Run(): "Too few features to track" (:34-38) -> return 0, pose untouched
@@ -1172,7 +1180,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
                 // speculative: the patch waves publish the all-visible H partials right after the
                 // level's precompute; sum + factorise them here while they run the first pass
                 expected_h += NPW;
-                pair_wait_arrive(&s.arrive_h, expected_h);             // BH
+                pair_wait_arrive(&s.arrive_h, expected_h, a.timeout_flag);             // BH
                 double hrow[6];
                 unsigned long long tr0 = 0;
                 if (STAMPS) tr0 = __builtin_amdgcn_s_memtime();
@@ -1182,7 +1190,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
                     unsigned long long t0 = 0, t1 = 0, t2 = 0;
                     if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
                     expected += NPW;
-                    pair_wait_arrive(&s.arrive, expected);             // B1
+                    pair_wait_arrive(&s.arrive, expected, a.timeout_flag);             // B1
                     if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
                     SolverCarry carry;
                     const int ctrl = solver_step<NP>(a, pair, level, it, s_part, s, lane, hrow, carry, STAMPS ? t_sub : nullptr);
@@ -1211,7 +1219,6 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
                 }
             }
             solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
-            report_timeout(a, lane);
             if (STAMPS && lane == 0 && a.workspace) {
                 unsigned long long* o = (unsigned long long*)a.workspace + (size_t)pair * 8;
                 o[0] = t_first; o[1] = t_wait; o[2] = t_solve; o[3] = n_it;
@@ -1232,7 +1239,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
     const bool row_writer = (lane & 15) == 15;
     WavePartial& my_part = s_part[wave * 4 + row];
     while (true) {
-        pair_wait_seq(s, ++seen);                                      // B0 of the slot's next pair
+        pair_wait_seq(s, ++seen, a.timeout_flag);                                      // B0 of the slot's next pair
         const int pair = __builtin_amdgcn_readfirstlane(s.pair);
         if (pair >= a.n_pairs) break;                                  // batch exhausted
         if (!s.run) {                                                  // Min_fts rule handled by the solver
@@ -1325,7 +1332,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
                 if (STAMPS) { tq2 = __builtin_amdgcn_s_memtime(); st_h += tq2 - tq1; }
                 ++seen;
                 pair_signal_arrive(&s.arrive, lane);                   // B1
-                pair_wait_seq(s, seen);                                // B2
+                pair_wait_seq(s, seen, a.timeout_flag);                                // B2
                 if (STAMPS) {
                     const unsigned long long dtb = __builtin_amdgcn_s_memtime() - tq2;
                     st_bar += dtb;
@@ -1468,7 +1475,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
         const int r = (int)blockIdx.x & 15;
         member = r >> 3;
         pair = ((int)blockIdx.x >> 4) * 8 + (r & 7);
-        if (pair >= a.n_pairs) return;
+        if (pair >= a.n_pairs || (member == 1 && a.debug_drop)) return;
     }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1668,7 +1675,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                             __builtin_amdgcn_s_sleep(1);
                         }
                         const bool ok = spins < spin_limit;
-                        if (!ok) spin_timeout();
+                        if (!ok) spin_timeout(a.timeout_flag);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1699,7 +1706,6 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
     }
     if (solves && member == 0) {
         solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
-        report_timeout(a, lane);
     }
 }
 
@@ -1826,7 +1832,7 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
                         __builtin_amdgcn_s_sleep(1);
                     }
                     const bool ok = spins < spin_limit;
-                    if (!ok) spin_timeout();
+                    if (!ok) spin_timeout(a.timeout_flag);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1846,7 +1852,6 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
         }
         if (member == 0) {
             solver_finish(a.T_cur_w + 12 * (size_t)pair, a.n_tracked + pair, (LdsBlockState*)&s, lane);
-            report_timeout(a, lane);
         }
         return;
     }
@@ -1979,17 +1984,6 @@ size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
     return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
 }
 
-// Device address of the hand-over timeout flag of the current device: the host entry points copy it
-// back together with their results (one D2H on the stream, no extra synchronisation) and clear it with
-// sparse_align_clear_timeout_flag in the rare case it is set.
-hipError_t sparse_align_timeout_flag_address(unsigned** addr) {
-    return hipGetSymbolAddress((void**)addr, HIP_SYMBOL(g_handover_timeout));
-}
-hipError_t sparse_align_clear_timeout_flag() {
-    const unsigned zero = 0;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_handover_timeout), &zero, sizeof(unsigned));
-}
-
 int sparse_align_occupancy(int variant) {
     int nb = -1;
     if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_PPW, false>, SA_PPW * 6 * 64, 0);
@@ -2017,7 +2011,35 @@ hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hip
     return launch_reg<5, SA_PPW, true>(args, num_cus, stream);
 }
 
-hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream) {
+// More than 64 KB of dynamic LDS is an opt-in per kernel AND per device (the sharded entry launches from one
+// process on up to eight devices): set once for every (instantiation, device) pair, on the calling thread's device.
+template <auto Kernel>
+static hipError_t optin_dynamic_lds(size_t bytes) {
+    static std::mutex m;
+    static bool done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    std::lock_guard<std::mutex> g(m);
+    if (!done[dev]) {
+        e = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        done[dev] = true;
+    }
+    return hipSuccess;
+}
+
+bool sparse_align_uses_duo(int max_features, bool have_workspace) {
+    if (sparse_align_pick_variant(max_features) != SA_WS) return false;
+    const int npad = (max_features + 63) / 64 * 64;
+    // (only where two halves cost no more lane rounds than the whole: 2000 patches = 2 x 2 rounds of 512 lanes
+    // against 4; 1500 patches would be 2 x 2 against 3 — measured 10 % slower on two compute units)
+    return !options().ws_no_windows && npad > 1024 && npad <= 2048 && !options().ws_no_duo && have_workspace &&
+           2 * (((npad / 64 + 1) / 2 * 64 + WS_THREADS - 1) / WS_THREADS) <= (npad + WS_THREADS - 1) / WS_THREADS;
+}
+
+hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int num_cus, hipStream_t stream, bool allow_multi_cu) {
     if (args.n_pairs <= 0) return hipSuccess;
     switch (variant) {
         case SA_REG128: return launch_reg<2, 4, false>(args, num_cus, stream);
@@ -2033,26 +2055,20 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
             if (ws_windows && npad <= 1024) {
                 // everything a pass needs in LDS: window origins + windows + parked grid inputs (4 + 60 + 88 KB)
                 constexpr size_t lds = (16 + WS_DWORDS) * 1024 * sizeof(uint32_t);
-                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 1024, true>,
-                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                const hipError_t attr = optin_dynamic_lds<sparse_align_ws_kernel<WS_NPW, 1024, true>>(lds);
                 if (attr != hipSuccess) return attr;
                 hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024, true>), grid, dim3(WS_THREADS), lds, stream, args);
-            } else if (ws_windows && npad <= 2048 && !options().ws_no_duo && args.workspace &&
-                       2 * (((npad / 64 + 1) / 2 * 64 + WS_THREADS - 1) / WS_THREADS) <= (npad + WS_THREADS - 1) / WS_THREADS) {
-                // (only where two halves cost no more lane rounds than the whole: 2000 patches = 2 x 2 rounds of 512 lanes
-                // against 4; 1500 patches would be 2 x 2 against 3 — measured 10 % slower on two compute units)
+            } else if (allow_multi_cu && sparse_align_uses_duo(args.max_features, args.workspace != nullptr)) {
                 // one pair on two compute units, each half wholly in LDS; the exchange words are zeroed per launch
                 constexpr size_t lds = (16 + WS_DWORDS) * 1024 * sizeof(uint32_t);
-                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 1024, true, 2>,
-                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                const hipError_t attr = optin_dynamic_lds<sparse_align_ws_kernel<WS_NPW, 1024, true, 2>>(lds);
                 if (attr != hipSuccess) return attr;
                 const hipError_t ez = hipMemsetAsync(args.workspace, 0, (size_t)args.n_pairs * DUO_BYTES, stream);
                 if (ez != hipSuccess) return ez;
                 const dim3 grid2((unsigned)((args.n_pairs + 7) / 8 * 16));
                 hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024, true, 2>), grid2, dim3(WS_THREADS), lds, stream, args);
             } else if (ws_windows && npad <= 2048) {
-                static const hipError_t attr = hipFuncSetAttribute((const void*)sparse_align_ws_kernel<WS_NPW, 2048>,
-                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 2048 * sizeof(uint32_t));
+                const hipError_t attr = optin_dynamic_lds<sparse_align_ws_kernel<WS_NPW, 2048>>(16 * 2048 * sizeof(uint32_t));
                 if (attr != hipSuccess) return attr;
                 hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 2048>), grid, dim3(WS_THREADS), 16 * 2048 * sizeof(uint32_t), stream, args);
             } else {

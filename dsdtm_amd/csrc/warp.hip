@@ -121,14 +121,16 @@ __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
     const int j = threadIdx.x;
     const int k = a.cand_kf[c];
     const int tLevel = a.ref_level[c];
-    if (k < 0 || k >= a.n_kf || tLevel < 0 || tLevel >= a.levels) {
+    const int fr = a.cand_frame ? a.cand_frame[c] : 0;
+    if (k < 0 || k >= a.n_kf || tLevel < 0 || tLevel >= a.levels || fr < 0 || (a.cand_frame && fr >= a.n_frames)) {
+        // a candidate that names a keyframe, level or current frame outside the batch is rejected, not dereferenced
         if (j == 0) a.search_level[c] = -1;
         if (j < 100) a.patch_border[(size_t)c * 100 + j] = 0;
         if (j < 64) a.patch[(size_t)c * 64 + j] = 0;
         return;
     }
     // ---- SolveAffineMatrix (:160-190) ----
-    const SE3x Tcur = xse3_from_rt(a.cand_frame ? a.T_cur_w_arr + 12 * (size_t)a.cand_frame[c] : a.T_cur_w);
+    const SE3x Tcur = xse3_from_rt(a.cand_frame ? a.T_cur_w_arr + 12 * (size_t)fr : a.T_cur_w);
     const SE3x Tkf = xse3_from_rt(a.T_kf_w + 12 * (size_t)k);
     const SE3x Tki = xse3_inverse(Tkf);
     const double* P = a.p_world + 3 * (size_t)c;

@@ -226,7 +226,9 @@ int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* cur, const 
 /* The same for the candidates of n_frames CURRENT frames at once (independent sequences batch their reprojection search
  * as they batch Run): packed DEVICE pyramids (current frames at cur_pyr + f * pyr_pitch, keyframes at kf_pyr + k *
  * pyr_pitch, one geometry), device arrays throughout, nothing copied, asynchronous on hip_stream. cand_frame[i] is the
- * current frame of candidate i (T_cur_w: n_frames x 12), cand_kf[i] its reference keyframe. scratch:
+ * current frame of candidate i (T_cur_w: n_frames x 12), cand_kf[i] its reference keyframe; a candidate whose
+ * cand_frame is outside [0, n_frames), cand_kf outside [0, n_kf) or ref_level outside the pyramid is rejected on the
+ * device (search_level -1, converged 0, pixel untouched) — never dereferenced. scratch:
  * dsdtm_match_candidates_scratch_bytes(m) bytes (affine matrices and warped patches; overwritten). px_xy in/out in
  * level-0 pixels, as above. Replaces FindMatchDirect (src/Feature_alignment.cpp:128-158) per candidate. */
 int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t* cur_pyr, int n_frames, const uint8_t* kf_pyr, int n_kf,
@@ -249,7 +251,9 @@ int dsdtm_detect_cells_frame(dsdtm_ctx* ctx, const dsdtm_frame* frame, const uin
  * work as they batch Run, pyramids, Align2D and the pose refinement. Every pointer is a device pointer; nothing is
  * copied; asynchronous on hip_stream. grid_occupied: n_frames * cells bytes or NULL. score_scratch: n_frames * pyr_pitch
  * bytes, key_scratch: n_frames * cells 64-bit words (both overwritten). Outputs: n_frames * cells entries each, the
- * meaning of dsdtm_detect_cells' outputs. Replaces the image part of src/Feature_detection.cpp:69-154 per frame. */
+ * meaning of dsdtm_detect_cells' outputs. pyr, score_scratch and pyr_pitch must be 4-byte aligned and
+ * n_frames * params->levels <= 65535 per call (DSDTM_ERR_INVALID otherwise: split the batch).
+ * Replaces the image part of src/Feature_detection.cpp:69-154 per frame. */
 int dsdtm_detect_cells_batch_device(dsdtm_ctx* ctx, const uint8_t* pyr, size_t pyr_pitch, int n_frames, int levels,
                                     const int* width, const int* height, const int* stride, const size_t* level_offset,
                                     const uint8_t* grid_occupied, const dsdtm_detect_params* params,
@@ -342,11 +346,19 @@ int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx, const dsd
 /* Pairs [*lo, *hi) of shard `shard` of `n_shards` over `n_pairs` pairs: contiguous blocks of ceil(n_pairs / n_shards). */
 void dsdtm_shard_range(int n_pairs, int n_shards, int shard, int* lo, int* hi);
 
-/* Result check for callers of the asynchronous batch entry point: waits for `hip_stream`, then reads (and
- * clears) the kernels' hand-over timeout flag. DSDTM_OK, or DSDTM_ERR_HIP when a bounded wait inside a kernel
- * ran out (a workgroup waited for a partner that never became resident): the results of the launches since the
- * last check are then not to be trusted. The reference has no counterpart (its path is one CPU thread); the
- * single-pair host entry points above perform this check themselves. */
+/* Result check for callers of the asynchronous batch entry point: waits for `hip_stream` and settles the launches
+ * issued on it through this context since the last check. Shapes that spread one pair over several compute units
+ * (few pairs of more than 448 features; batches of 1025..2048 features) wait for partner workgroups, i.e. for the
+ * GPU's dispatch; should such a wait run out (a foreign load on the device), the launch is re-seeded from a copy of
+ * its input poses and re-run HERE on the one-compute-unit kernels, and the caller still gets DSDTM_OK with the
+ * results of the reference's Run (which cannot fail for scheduling reasons, src/Sprase_ImageAlign.cpp:29-60) — so
+ * results are final once this function has returned, not before. DSDTM_ERR_HIP remains for a hand-over that failed
+ * inside one workgroup (a broken protocol; never observed) and for a re-run that failed as well. Timeout words,
+ * counters and re-run records are per context (host-mapped words read without a copy): a check never synchronises
+ * the device or touches another context's state. At most 64 multi-compute-unit launches of a context are kept
+ * unsettled; the 65th first waits for the oldest. On devices that are not one 8-XCD / 256-CU partition, and inside
+ * a stream capture, those shapes run the one-compute-unit kernels from the start. The reference has no counterpart
+ * (its path is one CPU thread); the single-pair host entry points above settle their launch themselves. */
 int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream);
 
 /* Streams and hipGraphs. Launches of one context may be in flight on up to 16 different streams at once (a 17th

@@ -1,0 +1,36 @@
+"""The multi-process GPU path of bench.py, rehearsed on ONE GPU: the code an 8-GPU SCALE run executes first.
+
+`python bench.py --gpus 2` spawns one worker per rank BEFORE anything in the parent touches the GPU; the ranks
+rendezvous on 127.0.0.1, build their own batches (seeded per rank), run the contract's barrier / synchronize /
+max-over-ranks timing around real launches and rank 0 prints ONE line. With DSDTM_BENCH_SHARE_GPU=1 both ranks use
+device 0 (gloo carries the barrier: RCCL refuses two ranks on one device), so the whole path except the RCCL backend
+itself runs here. tests/test_multiproc_cpu.py covers the same plumbing without a GPU (--stub)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["DSDTM_BENCH_SHARE_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "64",
+                        "--preroll", "4", "--no-cpu", "--no-secondary"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["pairs_per_gpu"] == 64 and out["config"]["barrier_backend"] == "gloo"
+    # whole-job rate: both ranks' pairs over the max-over-ranks time
+    assert out["value"] is not None and out["value"] > 0
+    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-6 * out["value"]
+    # rank 0's own results are sane (64 synthetic pairs converge to their ground truth)
+    assert out["err_vs_ground_truth_median"]["rad"] < 1e-3 and out["n_tracked_mean"] > 250
+    assert out["roofline"]["frac"] > 0

@@ -1,0 +1,168 @@
+"""The hot path on REAL image statistics (round-3 verdict item 6).
+
+The one real image the reference holds is Thirdparty/fast/test/data/test1.png (752x480, 8-bit grey — the geometry of
+Config/Rpg_uzh.yaml:9-16); its bytes travel as DATA in tests/golden/fast_reference.npz["test1"] (committed for the
+detector fixtures, tests/golden/make_golden_fast.py). Every alignment / Align2D / FindMatchDirect test elsewhere runs
+on seeded 1/f noise: here the same kernels meet flat regions, saturated pixels, repeated structure and real corner
+statistics — features come from the product's own detector (FAST-10 + Shi-Tomasi per 25-px cell), not from a uniform
+random draw. Every comparison is against the CPU restatement (oracle/): poses to 1e-9 with identical iteration
+counts, bytes / flags / pixels bit-exact.
+"""
+import numpy as np
+import pytest
+
+from dsdtm_amd import feature_alignment as FA
+from dsdtm_amd import synth
+from dsdtm_amd.feature_detection import Feature_detector
+from dsdtm_amd.frame import Config, Frame
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+# Config/Rpg_uzh.yaml:9-25 (752x480; the float32 intrinsics of include/Camera.h:138-142)
+RPG = dict(fx=315.5, fy=315.5, cx=376.0, cy=240.0, f=315.5, width=752, height=480)
+
+
+@pytest.fixture(scope="module")
+def test1():
+    img = np.load(H.golden_path("fast_reference.npz"))["test1"]
+    assert img.shape == (480, 752) and img.dtype == np.uint8
+    return np.ascontiguousarray(img)
+
+
+def _detector_corners(img, levels, ctx, max_fts=600):
+    """Feature_detector::detect (src/Feature_detection.cpp:69-154) on the image's pyramid: level-0 pixels + levels."""
+    cam = synth.Camera(**RPG)
+    old = {k: Config.Get(k) for k in ("Camera.Max_fts", "Camera.MaxPyraLevels", "Camera.CellSize")}
+    try:
+        Config.Set("Camera.Max_fts", max_fts); Config.Set("Camera.MaxPyraLevels", levels); Config.Set("Camera.CellSize", 25)
+        fr = Frame(cam, synth.build_pyramid(img, levels))
+        det = Feature_detector(cam.width, cam.height, ctx=ctx)
+        n = det.detect(fr, 20.0)
+    finally:
+        for k, v in old.items():
+            Config.Set(k, v)
+    assert n == fr.n_features and n > 150, n            # the reference's own test finds 167 FAST corners at barrier 75
+    return cam, fr.px.copy(), fr.level.copy()
+
+
+def _plane_scene(img, cam, px, levels, xi, depth, T_ref_w=None):
+    """test1 seen from a second pose: the image is the texture of a fronto-parallel plane `depth` metres in front of the
+    reference camera (cubic resampling), the features are the detector's corners with map points on that plane."""
+    T_cr = synth.se3_exp(xi)
+    cur = synth.warp_plane(img.astype(np.float64), cam, T_cr, depth)
+    bearing = synth.bearing_from_px(cam, px)
+    X_r = bearing * (depth / bearing[:, 2:3])
+    T_ref_w = np.eye(4)[:3] if T_ref_w is None else np.asarray(T_ref_w, np.float64).reshape(-1, 4)[:3]
+    p_world = (X_r - T_ref_w[:, 3]) @ T_ref_w[:, :3]
+    T4 = np.eye(4); T4[:3] = T_ref_w
+    return synth.AlignScene(cam, synth.build_pyramid(img, levels), synth.build_pyramid(cur, levels), px.astype(np.float32), bearing,
+                            p_world, np.ones(len(px), np.uint8), T_ref_w.copy(), T_ref_w.copy(), (T_cr @ T4)[:3], depth)
+
+
+@pytest.mark.parametrize("params", [(4, 0, 10), (5, 0, 8)], ids=["test_SpraseImg_alignment(4,0,cap)", "Tracking(5,0,8)"])
+def test_run_on_the_reference_image(gpu_ctx, oracle, test1, params):
+    """Sprase_ImgAlign::Run (src/Sprase_ImageAlign.cpp:29-60) on test1 against a plane-warped test1 at the Rpg_uzh
+    intrinsics, features = the product detector's corners (real corner statistics: clustered on structure, none in the
+    flat regions). Constructor arguments of Test/test_SpraseImg_alignment.cpp:110 (4 levels; cap 10 as in BASELINE) and of
+    src/Tracking.cpp:20-24 (5 levels, cap 8)."""
+    L, lo, cap = params
+    cam, px, _ = _detector_corners(test1, L, gpu_ctx)
+    rng = np.random.default_rng(11)
+    sc = _plane_scene(test1, cam, px, L, xi=(0.012, -0.007, 0.005, 0.004, -0.003, 0.006), depth=2.0,
+                      T_ref_w=synth.random_pose(rng))
+    To, no, so = oracle.sparse_align(sc, L, lo, cap)
+    Tg, ng, sg = H.gpu_sparse_align(sc, L, lo, cap, ctx=gpu_ctx)
+    H.assert_pose_close(Tg, To, H.TIGHT_RAD, H.TIGHT_M, what="test1")
+    assert ng == no and sg["iters"] == so["iters"] and sg["n_ref"] == so["n_ref"] and sg["n_vis"] == so["n_vis"]
+    assert sg["exit_code"] == so["exit_code"]
+    # and it is an alignment, not just agreement: the warp is recovered (cubic resampling + u8 rounding limit the accuracy)
+    ang, dt = synth.pose_error(Tg, sc.T_cur_w_true)
+    assert ang < 2e-3 and dt < 5e-3, (ang, dt)
+    assert no > 100
+
+
+def test_run_on_the_reference_image_resident_and_batched(gpu_ctx, oracle, test1):
+    """The same pair through the device-resident frames (level 0 uploaded, pyramid by the device pyrDown) and as a batch
+    of shifted crops: real-image bytes through pyrdown.hip + the batch kernel, against the oracle on the host pyramids."""
+    from dsdtm_amd.frame import frames_from_scene
+    from dsdtm_amd.sparse_align import Sprase_ImgAlign
+    L = 4
+    cam, px, _ = _detector_corners(test1, L, gpu_ctx)
+    sc = _plane_scene(test1, cam, px, L, xi=(-0.01, 0.008, -0.004, -0.003, 0.005, -0.004), depth=1.6)
+    To, no, so = oracle.sparse_align(sc, L, 0, 10)
+    al = Sprase_ImgAlign(L, 0, 10, ctx=gpu_ctx, resident_frames=True)
+    cur, ref = frames_from_scene(sc)
+    n = al.Run(cur, ref)
+    H.assert_pose_close(cur.Get_Pose(), To, H.TIGHT_RAD, H.TIGHT_M, what="test1, resident frames")
+    assert n == no and al.last_stats["iters"] == so["iters"]
+
+
+def test_feature_alignment_known_answer_on_the_reference_image(gpu_ctx, oracle, test1):
+    """Test/test_Feature_alignment.cpp:47-86 — px_true (130.2, 120.3), start error (-1.1, -0.8), 3 iterations — on
+    test1 instead of the absent SVO frame; plus the same at the strongest detector corners (":55 TODO: test on
+    corner/gradient features") with FindMatchDirect's 10 iterations. Pixels and flags bit-identical to the restatement."""
+    pb, p = H.make_border_patches(test1, [(130.2, 120.3)])
+    for iters in (3, 10):
+        px0 = np.array([130.2, 120.3]) - np.array([-1.1, -0.8])           # px_est = px_true - px_error (:74)
+        oko, pxo = oracle.align2d(test1, pb[0], p[0], iters, px0)
+        pxg = px0.copy()
+        okg = FA.Feature_Alignment.Align2DGaussNewton(test1, pb[0], p[0], iters, pxg, ctx=gpu_ctx)
+        assert okg == oko and np.array_equal(pxg, pxo, equal_nan=True)
+    cam, px, lv = _detector_corners(test1, 3, gpu_ctx)
+    pyr = synth.build_pyramid(test1, 3)
+    rng = np.random.default_rng(3)
+    sel = [i for i in range(len(px)) if 12 <= px[i, 0] / (1 << lv[i]) < pyr[lv[i]].shape[1] - 12 and 12 <= px[i, 1] / (1 << lv[i]) < pyr[lv[i]].shape[0] - 12]
+    centers = px[sel] / (1 << lv[sel])[:, None] + rng.uniform(0, 1, (len(sel), 2))
+    pbs, ps = [], []
+    for c, l in zip(centers, lv[sel]):
+        a, b = H.make_border_patches(pyr[l], [tuple(c)])
+        pbs.append(a[0]); ps.append(b[0])
+    px0 = centers + rng.uniform(-1.5, 1.5, centers.shape)
+    co, pxo = oracle.align2d_batch(pyr, pbs, ps, lv[sel].astype(np.int32), px0, 10)
+    cg, pxg = FA.align2d_batch(pyr, pbs, ps, lv[sel].astype(np.int32), px0, 10, ctx=gpu_ctx)
+    assert np.array_equal(cg, co) and np.array_equal(pxg, pxo, equal_nan=True)
+    good = co & (np.hypot(*(pxo - centers).T) < 0.25)
+    assert good.mean() > 0.6, good.mean()                 # corners: the alignment finds its way back from 1.5 px
+
+
+def test_find_match_direct_on_corners_and_flat_regions(gpu_ctx, oracle, test1):
+    """FindMatchDirect's prelude + Align2D (src/Feature_alignment.cpp:128-275) for candidates on the detector's corners AND
+    on the image's flat regions: a constant 10x10 warp gives a singular 3x3 H, Matrix3f::inverse() divides by zero and
+    the update turns NaN — Align2D returns false and WRITES THE NaN BACK into the pixel (quirks A2, A4). The kernel must do
+    the same on real flat regions, bit for bit, and neither trap nor touch its neighbours."""
+    L = 5
+    cam, px, lv = _detector_corners(test1, L, gpu_ctx)
+    pyr = synth.build_pyramid(test1, L)
+    # the flattest 8x8 blocks of level 0 (saturated / textureless areas of test1)
+    blk = test1[:480 // 8 * 8, :752 // 8 * 8].reshape(60, 8, 94, 8).astype(np.int32)
+    rngb = blk.max(axis=(1, 3)) - blk.min(axis=(1, 3))
+    ys, xs = np.nonzero(rngb == 0)
+    flat = np.stack([xs * 8 + 4, ys * 8 + 4], 1).astype(np.float32)
+    flat = flat[(flat[:, 0] > 40) & (flat[:, 0] < 712) & (flat[:, 1] > 40) & (flat[:, 1] < 440)][:60]
+    assert len(flat) >= 10, "test1 has constant 8x8 blocks (saturated regions)"
+    rpx = np.concatenate([px, flat]).astype(np.float32)
+    rlv = np.concatenate([lv, np.zeros(len(flat), np.int32)]).astype(np.int32)
+    m = len(rpx)
+    # keyframe = test1 at the identity, current frame = the same plane from a nearby pose
+    depth, xi = 2.0, (0.02, -0.01, 0.01, 0.006, -0.004, 0.01)
+    sc = _plane_scene(test1, cam, rpx, L, xi=xi, depth=depth)
+    T_kf = sc.T_ref_w[None]
+    ck = np.zeros(m, np.int32)
+    aff_o, sl_o, pb_o, pp_o = oracle.warp_patches([sc.ref_pyr], cam, T_kf, sc.T_cur_w_true, ck, rpx, rlv, sc.bearing, sc.p_world, L - 3)
+    aff_g, sl_g, pb_g, pp_g = FA.warp_patches([sc.ref_pyr], cam, T_kf, sc.T_cur_w_true, ck, rpx, rlv, sc.bearing, sc.p_world, L - 3, ctx=gpu_ctx)
+    assert np.array_equal(sl_g, sl_o) and np.array_equal(pb_g, pb_o) and np.array_equal(pp_g, pp_o) and np.array_equal(aff_g, aff_o)
+    # candidates' predicted pixels in the current frame (ReprojectPoint), then Align2D on the search level
+    Xc = sc.p_world @ sc.T_cur_w_true[:, :3].T + sc.T_cur_w_true[:, 3]
+    cpx = np.stack([cam.fx * Xc[:, 0] / Xc[:, 2] + cam.cx, cam.fy * Xc[:, 1] / Xc[:, 2] + cam.cy], 1)
+    cpx += np.random.default_rng(9).uniform(-0.8, 0.8, cpx.shape)
+    co, pxo = oracle.align2d_batch(sc.cur_pyr, pb_o, pp_o, sl_o, cpx / (1 << sl_o)[:, None], 10)
+    kf = Frame(cam, sc.ref_pyr, sc.T_ref_w)
+    cur = Frame(cam, sc.cur_pyr, sc.T_cur_w_true)
+    cg, pxg, slg = FA.match_candidates_frames(cur, [kf], cam, T_kf, sc.T_cur_w_true, ck, rpx, rlv, sc.bearing, sc.p_world, cpx, L - 3, 10, ctx=gpu_ctx)
+    assert np.array_equal(slg, sl_o) and np.array_equal(cg, co)
+    assert np.array_equal(pxg, pxo * (1 << sl_o)[:, None], equal_nan=True)
+    nf = len(flat)
+    singular = np.isnan(pxo[-nf:]).any(axis=1)
+    assert singular.sum() >= nf // 2 and not co[-nf:][singular].any()      # flat patches: NaN written back, not matched
+    assert co[:-nf].mean() > 0.5                                            # corners: matched

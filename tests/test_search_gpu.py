@@ -191,3 +191,20 @@ def test_match_candidates_batch_device_equals_per_frame_calls(gpu_ctx):
         assert np.array_equal(px[o:o + n], px_f, equal_nan=True)
         o += n
     assert o == M and conv.sum() > 100
+    # candidates that name a current frame outside the batch are rejected on the device, not dereferenced (the frame
+    # index is data: a corrupted one must not become an out-of-bounds read of cur_pyr / T_cur_w)
+    fr = d["frame"].clone()
+    bad = torch.tensor([0, 5, M - 1], device=dev)
+    fr[bad] = torch.tensor([-1, 3, 1 << 20], dtype=fr.dtype, device=dev)
+    px_in = cat["px"]
+    d_px2, d_sl2, d_cv2 = d["px"].clone(), torch.full_like(d_sl, 7), torch.ones_like(d_cv)
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_match_candidates_batch_device(
+        gpu_ctx.handle, d_cur.data_ptr(), 3, d_kf.data_ptr(), 9, pitch, L, wa, ha, sa, oa, C.byref(capi.camera_struct(cam)),
+        d_Tk.data_ptr(), d_Tc.data_ptr(), fr.data_ptr(), d["kf"].data_ptr(), d["rp"].data_ptr(), d["rl"].data_ptr(),
+        d["rb"].data_ptr(), d["pw"].data_ptr(), L - 3, 10, M, d_scr.data_ptr(), d_px2.data_ptr(), d_sl2.data_ptr(), d_cv2.data_ptr(), None))
+    torch.cuda.synchronize()
+    conv2, px2, sl2 = d_cv2.cpu().numpy().astype(bool), d_px2.cpu().numpy(), d_sl2.cpu().numpy()
+    badn = bad.cpu().numpy()
+    assert not conv2[badn].any() and (sl2[badn] == -1).all() and np.array_equal(px2[badn], px_in[badn])
+    keep = np.ones(M, bool); keep[badn] = False
+    assert np.array_equal(conv2[keep], conv[keep]) and np.array_equal(sl2[keep], sl[keep]) and np.array_equal(px2[keep], px[keep], equal_nan=True)
