@@ -59,6 +59,16 @@ class BatchDesc(C.Structure):
                 ("n_tracked", C.c_void_p), ("stats", C.c_void_p)]
 
 
+class StreamDesc(C.Structure):
+    """dsdtm_stream_desc: a host sequence of level-0 images + feature columns for dsdtm_sparse_align_batch_streamed."""
+    _fields_ = [("n_pairs", C.c_int32), ("max_features", C.c_int32), ("levels", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32), ("row_stride", C.c_int32), ("image_pitch", C.c_size_t),
+                ("ref_image", C.c_void_p), ("cur_image", C.c_void_p), ("px_xy", C.c_void_p),
+                ("bearing", C.c_void_p), ("p_world", C.c_void_p), ("initial", C.c_void_p),
+                ("n_features", C.c_void_p), ("T_ref_w", C.c_void_p), ("T_cur_w", C.c_void_p),
+                ("n_tracked", C.c_void_p), ("stats", C.c_void_p)]
+
+
 class ImageDesc(C.Structure):
     _fields_ = [("levels", C.c_int), ("width", C.c_int * MAX_LEVELS),
                 ("height", C.c_int * MAX_LEVELS), ("stride", C.c_int * MAX_LEVELS),
@@ -129,7 +139,7 @@ EXPORTED_SYMBOLS = [
     "dsdtm_frame_create", "dsdtm_frame_create_from_image", "dsdtm_frame_destroy", "dsdtm_sparse_align_frames",
     "dsdtm_detect_cells", "dsdtm_detect_cells_frame", "dsdtm_match_candidates_frames",
     "dsdtm_pose_optimization", "dsdtm_pose_optimization_batch_device",
-    "dsdtm_sparse_align_batch_sharded", "dsdtm_shard_range", "dsdtm_detect_cells_batch_device",
+    "dsdtm_sparse_align_batch_sharded", "dsdtm_sparse_align_batch_streamed", "dsdtm_shard_range", "dsdtm_detect_cells_batch_device",
     "dsdtm_match_candidates_batch_device", "dsdtm_match_candidates_scratch_bytes",
 ]
 
@@ -245,6 +255,9 @@ def load():
     lib.dsdtm_sparse_align_batch_sharded.restype = C.c_int
     lib.dsdtm_sparse_align_batch_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(BatchDesc), C.POINTER(Camera),
                                                      C.POINTER(AlignParams)]
+    lib.dsdtm_sparse_align_batch_streamed.restype = C.c_int
+    lib.dsdtm_sparse_align_batch_streamed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamDesc), C.c_int, C.POINTER(Camera),
+                                                      C.POINTER(AlignParams)]
     lib.dsdtm_shard_range.restype = None
     lib.dsdtm_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.dsdtm_debug_set_option.restype = C.c_int

@@ -82,6 +82,10 @@ struct dsdtm_ctx {
     unsigned long long rec_tick = 0;
     unsigned long long recovered = 0;     // launches re-run on the one-CU kernels so far (dsdtm_debug_recovered_launches)
     bool multi_cu_ok = true;              // the dispatch assumptions of the multi-CU kernels hold on this device
+    // dsdtm_sparse_align_batch_streamed: two copy streams and one event per chunk, created on first use
+    hipStream_t copy_stream[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> copy_events;
+    hipEvent_t copy_fence = nullptr;
     int num_cus = 256;
 };
 
@@ -241,6 +245,9 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (ctx->d_team) (void)hipFree(ctx->d_team);
     if (ctx->team_event) (void)hipEventDestroy(ctx->team_event);
     for (auto& r : ctx->rec) { if (r.d_seed) (void)hipFree(r.d_seed); if (r.done) (void)hipEventDestroy(r.done); }
+    for (auto& cs : ctx->copy_stream) if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+    for (auto& e : ctx->copy_events) (void)hipEventDestroy(e);
+    if (ctx->copy_fence) (void)hipEventDestroy(ctx->copy_fence);
     if (ctx->h_flags) (void)hipHostFree((void*)ctx->h_flags);
     delete ctx;
 }
@@ -678,6 +685,163 @@ extern "C" int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx
         int lo, hi;
         dsdtm_shard_range(hb->n_pairs, n_ctx, 0, &lo, &hi);
         rc[0] = sharded_one(ctx[0], hb, cam, prm, lo, hi);      // the calling thread takes the first shard
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < n_ctx; ++g) if (rc[g] != DSDTM_OK) return rc[g];
+    return DSDTM_OK;
+}
+
+// ---- the batch STREAMED from host memory: level 0 only, chunked, copy overlapped with compute ---------------
+// One shard = pairs [lo, hi) of the host sequence on `ctx`: chunks of `chunk` pairs; per chunk the level-0 images and
+// feature columns go up on one of two copy streams, the pyramids are built by the device pyrDown and the chunk is
+// aligned on the context's stream behind the copy's event, the results come back behind the alignment — the upload of
+// chunk j + 1 overlaps pyramids + alignment + download of chunk j. Device memory holds the whole shard (0.41 MB per
+// 640x480 frame: thousands of frames are a few GB of 288).
+static int streamed_one(dsdtm_ctx* ctx, const dsdtm_stream_desc* s, const dsdtm_camera* cam, const dsdtm_align_params* prm,
+                        int chunk, int lo, int hi) {
+    const int n = hi - lo;
+    if (n <= 0) return DSDTM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool chained = s->cur_image == nullptr;
+    // device pyramid layout: the one dsdtm_frame_create_from_image uses (levels 64-byte aligned, pitch 256)
+    int w[DSDTM_MAX_LEVELS], h[DSDTM_MAX_LEVELS], st[DSDTM_MAX_LEVELS];
+    size_t offl[DSDTM_MAX_LEVELS], o = 0;
+    for (int l = 0; l < s->levels; ++l) {
+        w[l] = l ? (w[l - 1] + 1) / 2 : s->width; h[l] = l ? (h[l - 1] + 1) / 2 : s->height; st[l] = w[l];
+        offl[l] = o; o += align_up((size_t)w[l] * h[l], 64);
+    }
+    const size_t pit = align_up(o, 256), img = (size_t)s->width * s->height, nf = (size_t)s->max_features;
+    const int n_frames = chained ? n + 1 : n;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t v = off; off = align_up(off + bytes, 256); return v; };
+    const size_t o_ref = take((size_t)n_frames * pit), o_cur = chained ? o_ref + pit : take((size_t)n * pit),
+                 o_px = take(n * nf * 8), o_be = take(n * nf * 24), o_pw = take(n * nf * 24), o_in = take(n * nf),
+                 o_nf = take(s->n_features ? (size_t)n * 4 : 0), o_tr = take((size_t)n * 96), o_tc = take((size_t)n * 96),
+                 o_nt = take((size_t)n * 4), o_st = take(s->stats ? n * sizeof(dsdtm_align_stats) : 0);
+    if (off > ctx->d_cap) {
+        if (ctx->d_stage) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_stage); }
+        ctx->d_stage = nullptr; ctx->d_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_stage, off));
+        ctx->d_cap = off;
+    }
+    uint8_t* d = (uint8_t*)ctx->d_stage;
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->copy_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream[i], hipStreamNonBlocking));
+    const int n_chunks = (n + chunk - 1) / chunk;
+    while ((int)ctx->copy_events.size() < n_chunks) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->copy_events.push_back(e);
+    }
+    // the copy streams start behind whatever the context's stream still does with the staging buffer
+    if (!ctx->copy_fence) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->copy_fence, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->copy_fence, ctx->stream));
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream[i], ctx->copy_fence, 0));
+    // level 0 of frames [f0, f1) of host array `src` (frame 0 = the shard's first) -> device pyramids at d + base
+    auto up_images = [&](hipStream_t cs, const uint8_t* src, size_t base, int f0, int f1) -> hipError_t {
+        if (f1 <= f0) return hipSuccess;
+        if (s->row_stride == s->width)      // whole images: ONE strided copy (an image is a "row" of W*H bytes)
+            return hipMemcpy2DAsync(d + base + (size_t)f0 * pit, pit, src + (size_t)f0 * s->image_pitch, s->image_pitch, img,
+                                    (size_t)(f1 - f0), hipMemcpyHostToDevice, cs);
+        for (int f = f0; f < f1; ++f) {     // padded rows: one 2-D copy per image
+            const hipError_t e = hipMemcpy2DAsync(d + base + (size_t)f * pit, (size_t)s->width, src + (size_t)f * s->image_pitch,
+                                                  (size_t)s->row_stride, (size_t)s->width, (size_t)s->height, hipMemcpyHostToDevice, cs);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    auto up = [&](hipStream_t cs, size_t dst, const void* src, size_t bytes) {
+        return bytes ? hipMemcpyAsync(d + dst, src, bytes, hipMemcpyHostToDevice, cs) : hipSuccess;
+    };
+    const uint8_t* ref_h = s->ref_image + (size_t)lo * s->image_pitch;
+    const uint8_t* cur_h = chained ? nullptr : s->cur_image + (size_t)lo * s->image_pitch;
+    dsdtm_batch_desc b;
+    memset(&b, 0, sizeof b);
+    b.max_features = s->max_features; b.levels = s->levels; b.pyr_pitch = pit;
+    for (int l = 0; l < s->levels; ++l) { b.width[l] = w[l]; b.height[l] = h[l]; b.stride[l] = st[l]; b.level_offset[l] = offl[l]; }
+    hipStream_t comp = ctx->stream;
+    for (int j = 0; j < n_chunks; ++j) {
+        const int p0 = j * chunk, p1 = p0 + chunk < n ? p0 + chunk : n;      // pairs of this chunk (shard-relative)
+        const size_t np = (size_t)(p1 - p0);
+        hipStream_t cs = ctx->copy_stream[j & 1];
+        // frames that arrive with this chunk — chained: the `cur` frames of its pairs (+ frame 0 with the first chunk)
+        const int f0 = chained ? (j == 0 ? 0 : p0 + 1) : p0, f1 = chained ? p1 + 1 : p1;
+        HIP_TRY(ctx, up_images(cs, ref_h, o_ref, f0, f1));
+        if (!chained) HIP_TRY(ctx, up_images(cs, cur_h, o_cur, p0, p1));
+        const size_t g0 = (size_t)(lo + p0);                                   // first pair of the chunk in the host arrays
+        HIP_TRY(ctx, up(cs, o_px + p0 * nf * 8, s->px_xy + g0 * nf * 2, np * nf * 8));
+        HIP_TRY(ctx, up(cs, o_be + p0 * nf * 24, s->bearing + g0 * nf * 3, np * nf * 24));
+        HIP_TRY(ctx, up(cs, o_pw + p0 * nf * 24, s->p_world + g0 * nf * 3, np * nf * 24));
+        HIP_TRY(ctx, up(cs, o_in + p0 * nf, s->initial + g0 * nf, np * nf));
+        if (s->n_features) HIP_TRY(ctx, up(cs, o_nf + (size_t)p0 * 4, s->n_features + g0, np * 4));
+        HIP_TRY(ctx, up(cs, o_tr + (size_t)p0 * 96, s->T_ref_w + g0 * 12, np * 96));
+        HIP_TRY(ctx, up(cs, o_tc + (size_t)p0 * 96, s->T_cur_w + g0 * 12, np * 96));
+        HIP_TRY(ctx, hipEventRecord(ctx->copy_events[j], cs));
+        HIP_TRY(ctx, hipStreamWaitEvent(comp, ctx->copy_events[j], 0));
+        // Frame::ComputeImagePyramid (src/Frame.cpp:74-81) for the frames that just arrived, on the device
+        if (int rc = dsdtm_pyrdown_batch_device(ctx, d + o_ref + (size_t)f0 * pit, pit, f1 - f0, s->levels, w, h, st, offl, comp)) return rc;
+        if (!chained)
+            if (int rc = dsdtm_pyrdown_batch_device(ctx, d + o_cur + (size_t)p0 * pit, pit, p1 - p0, s->levels, w, h, st, offl, comp)) return rc;
+        b.n_pairs = p1 - p0;
+        b.ref_pyr = d + o_ref + (size_t)p0 * pit; b.cur_pyr = d + o_cur + (size_t)p0 * pit;
+        b.px_xy = (const float*)(d + o_px + p0 * nf * 8); b.bearing = (const double*)(d + o_be + p0 * nf * 24);
+        b.p_world = (const double*)(d + o_pw + p0 * nf * 24); b.initial = d + o_in + p0 * nf;
+        b.n_features = s->n_features ? (const int32_t*)(d + o_nf + (size_t)p0 * 4) : nullptr;
+        b.T_ref_w = (const double*)(d + o_tr + (size_t)p0 * 96); b.T_cur_w = (double*)(d + o_tc + (size_t)p0 * 96);
+        b.n_tracked = (int32_t*)(d + o_nt + (size_t)p0 * 4);
+        b.stats = s->stats ? (dsdtm_align_stats*)(d + o_st + p0 * sizeof(dsdtm_align_stats)) : nullptr;
+        if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, comp)) return rc;
+        // (multi-CU shapes: results are final after the check below; a chunk's download is repeated there if it was re-run)
+        HIP_TRY(ctx, hipMemcpyAsync(s->T_cur_w + g0 * 12, d + o_tc + (size_t)p0 * 96, np * 96, hipMemcpyDeviceToHost, comp));
+        HIP_TRY(ctx, hipMemcpyAsync(s->n_tracked + g0, d + o_nt + (size_t)p0 * 4, np * 4, hipMemcpyDeviceToHost, comp));
+        if (s->stats) HIP_TRY(ctx, hipMemcpyAsync(s->stats + g0, d + o_st + p0 * sizeof(dsdtm_align_stats), np * sizeof(dsdtm_align_stats), hipMemcpyDeviceToHost, comp));
+    }
+    const unsigned long long rerun0 = ctx->recovered;
+    if (int rc = dsdtm_sparse_align_check(ctx, comp)) return rc;
+    if (ctx->recovered != rerun0) {          // a chunk was re-run on the one-CU kernels: fetch everything again
+        HIP_TRY(ctx, hipMemcpyAsync(s->T_cur_w + (size_t)lo * 12, d + o_tc, (size_t)n * 96, hipMemcpyDeviceToHost, comp));
+        HIP_TRY(ctx, hipMemcpyAsync(s->n_tracked + lo, d + o_nt, (size_t)n * 4, hipMemcpyDeviceToHost, comp));
+        if (s->stats) HIP_TRY(ctx, hipMemcpyAsync(s->stats + lo, d + o_st, n * sizeof(dsdtm_align_stats), hipMemcpyDeviceToHost, comp));
+        HIP_TRY(ctx, hipStreamSynchronize(comp));
+    }
+    return DSDTM_OK;
+}
+
+extern "C" int dsdtm_sparse_align_batch_streamed(dsdtm_ctx* const* ctx, int n_ctx, const dsdtm_stream_desc* s, int chunk_pairs,
+                                                 const dsdtm_camera* cam, const dsdtm_align_params* prm) {
+    if (!ctx || n_ctx <= 0 || !s || !cam || !prm) return DSDTM_ERR_INVALID;
+    for (int g = 0; g < n_ctx; ++g) if (!ctx[g]) return DSDTM_ERR_INVALID;
+    for (int g = 0; g < n_ctx; ++g)
+        for (int k = g + 1; k < n_ctx; ++k)
+            if (ctx[g] == ctx[k]) { set_err(ctx[0], "streamed batch: a context appears twice (one context per shard)"); return DSDTM_ERR_INVALID; }
+    if (s->n_pairs < 0 || !s->ref_image || !s->T_ref_w || !s->T_cur_w || !s->n_tracked ||
+        (s->max_features > 0 && (!s->px_xy || !s->bearing || !s->p_world || !s->initial))) {
+        set_err(ctx[0], "streamed batch: NULL host pointers"); return DSDTM_ERR_INVALID;
+    }
+    if (s->max_features < 0 || s->max_features > 32767 || s->levels <= 0 || s->levels > DSDTM_MAX_LEVELS || s->width <= 0 ||
+        s->height <= 0 || s->row_stride < s->width || s->image_pitch < (size_t)s->row_stride * (s->height - 1) + s->width) {
+        set_err(ctx[0], "streamed batch: bad geometry"); return DSDTM_ERR_INVALID;
+    }
+    if (int rc0 = validate_params(ctx[0], prm, s->levels)) return rc0;
+    const int chunk = chunk_pairs > 0 ? chunk_pairs : 128;
+    std::vector<int> rc(n_ctx, DSDTM_OK);
+    std::vector<std::thread> th;
+    bool spawn_failed = false;
+    for (int g = 1; g < n_ctx && !spawn_failed; ++g) {
+        int lo, hi;
+        dsdtm_shard_range(s->n_pairs, n_ctx, g, &lo, &hi);
+        try {
+            th.emplace_back([=, &rc]() { rc[g] = streamed_one(ctx[g], s, cam, prm, chunk, lo, hi); });
+        } catch (...) {
+            spawn_failed = true;
+            rc[g] = DSDTM_ERR_NOMEM;
+            set_err(ctx[g], "streamed batch: could not start the host thread of shard %d", g);
+        }
+    }
+    if (!spawn_failed) {
+        int lo, hi;
+        dsdtm_shard_range(s->n_pairs, n_ctx, 0, &lo, &hi);
+        rc[0] = streamed_one(ctx[0], s, cam, prm, chunk, lo, hi);
     }
     for (auto& t : th) t.join();
     for (int g = 0; g < n_ctx; ++g) if (rc[g] != DSDTM_OK) return rc[g];

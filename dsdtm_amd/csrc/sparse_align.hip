@@ -284,9 +284,6 @@ __device__ __forceinline__ RefGeom ref_geom(const FeatureRegs& F, const LevelGeo
     return g;
 }
 __device__ __forceinline__ uint32_t ref_row_offset(const LevelGeom& lg, const RefGeom& g, int r) {
-#ifdef DSDTM_EXP_NOGATHER   // experiment (tools/ws_cap.py): every lane fetches the level's first bytes — the cost of a level start WITHOUT its gathers
-    return lg.off;
-#endif
     return g.valid ? lg.off + (uint32_t)(g.fv - 3 + r) * (uint32_t)lg.stride + (uint32_t)(g.fu - 3) : lg.off;
 }
 // 7x7 u8 footprint rows fv-3..fv+3, cols fu-3..fu+3, fetched as aligned dwords. All seven row gathers
@@ -511,11 +508,7 @@ __device__ __forceinline__ void window_issue(const SAKernelArgs& a, const LevelG
     // precompute_patch)
 #pragma unroll
     for (int r = 0; r < WIN_ROWS; ++r) {
-#ifdef DSDTM_EXP_NOGATHER
-        const uint32_t o = lg.off;
-#else
         const uint32_t o = lg.off + (uint32_t)(v_i - HR + r) * (uint32_t)lg.stride + (uint32_t)(u_i - 3);
-#endif
         f.w[r] = gather_x3(img32 + min(o >> 2, last_dw - 2u));
     }
 }

@@ -1,8 +1,12 @@
 // example_batch.cpp — a single-process C++ caller in the shape of the reference's process (src/System.cpp:39-55: one
 // process, a few threads) spreading BASELINE config 4's independent frame pairs over several GPUs through the C ABI:
-// one dsdtm_ctx per shard (device g % device_count), dsdtm_sparse_align_batch_sharded cuts the host batch into
-// contiguous blocks and runs each on its own host thread. Reads a batch dumped by tests/test_sharded_gpu.py.
-//   usage: example_batch <batch.bin> <n_contexts>
+// one dsdtm_ctx per shard (device g % device_count); the host batch is cut into contiguous blocks, each run on its own
+// host thread. Default: dsdtm_sparse_align_batch_streamed — only level 0 of every frame crosses the link (the packed
+// host pyramids double as an image array: level 0 sits at offset 0, image_pitch = pyr_pitch), pyramids are built on the
+// device, chunks of pairs are uploaded beside the alignment of the previous chunk. "sharded": the whole-pyramid upload of
+// dsdtm_sparse_align_batch_sharded (same results, bit for bit). Reads a batch dumped by tests/test_sharded_gpu.py.
+// (A production caller pins its arrays — hipHostMalloc / hipHostRegister — so that the copies run at link speed.)
+//   usage: example_batch <batch.bin> <n_contexts> [sharded]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -53,8 +57,20 @@ int main(int argc, char** argv) {
     std::vector<dsdtm_ctx*> ctx(G, nullptr);
     for (int g = 0; g < G; ++g)
         if (dsdtm_create(g % ndev, &ctx[g]) != DSDTM_OK) { std::fprintf(stderr, "dsdtm_create: %s\n", dsdtm_last_error(nullptr)); return 3; }
-    const int rc = dsdtm_sparse_align_batch_sharded(ctx.data(), G, &b, &cam, &prm);
-    if (rc != DSDTM_OK) { std::fprintf(stderr, "sharded batch failed: %d\n", rc); return 4; }
+    int rc;
+    if (argc > 3 && std::strcmp(argv[3], "sharded") == 0) {
+        rc = dsdtm_sparse_align_batch_sharded(ctx.data(), G, &b, &cam, &prm);
+    } else {
+        dsdtm_stream_desc s;
+        std::memset(&s, 0, sizeof s);
+        s.n_pairs = P; s.max_features = N; s.levels = L; s.width = hdr[3]; s.height = hdr[4];
+        s.row_stride = hdr[3]; s.image_pitch = b.pyr_pitch;
+        s.ref_image = ref.data(); s.cur_image = cur.data();
+        s.px_xy = px.data(); s.bearing = be.data(); s.p_world = pw.data(); s.initial = ini.data();
+        s.T_ref_w = Tr.data(); s.T_cur_w = Tc.data(); s.n_tracked = nt.data(); s.stats = st.data();
+        rc = dsdtm_sparse_align_batch_streamed(ctx.data(), G, &s, 2, &cam, &prm);      // chunks of 2 pairs: the pipeline at toy size
+    }
+    if (rc != DSDTM_OK) { std::fprintf(stderr, "batch failed: %d (%s)\n", rc, dsdtm_last_error(ctx[0])); return 4; }
     for (int g = 0; g < G; ++g) {
         int lo, hi;
         dsdtm_shard_range(P, G, g, &lo, &hi);

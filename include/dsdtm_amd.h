@@ -346,6 +346,32 @@ int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx, const dsd
 /* Pairs [*lo, *hi) of shard `shard` of `n_shards` over `n_pairs` pairs: contiguous blocks of ceil(n_pairs / n_shards). */
 void dsdtm_shard_range(int n_pairs, int n_shards, int shard, int* lo, int* hi);
 
+/* The same batch STREAMED from host memory — the form a host-fed pipeline wants (the reference feeds frames from host
+ * memory: src/Tracking.cpp:45-57 -> src/Frame.cpp:35-41,74-81 -> src/Sprase_ImageAlign.cpp:29-60). Only LEVEL 0 of every
+ * frame crosses the link (24 % fewer bytes than a 4-level pyramid); levels 1.. are built on the device by the bit-exact
+ * pyrDown (Frame::ComputeImagePyramid), and a CHAINED sequence (cur_image == NULL: n_pairs + 1 frames at ref_image,
+ * frame i + 1 is the current frame of pair i — a tracked sequence) uploads and builds every frame once instead of twice.
+ * Per shard (contiguous pairs per context, as dsdtm_shard_range) the pairs run in chunks of `chunk_pairs` (<= 0: 128):
+ * upload of chunk j + 1 on one of two copy streams overlaps pyramids + alignment + result download of chunk j. Pin the
+ * host arrays (hipHostMalloc / hipHostRegister) for the copies to run at link speed and asynchronously. Results are
+ * those of dsdtm_sparse_align_batch_sharded on the same frames, bit for bit. Returns when every shard is done. */
+typedef struct dsdtm_stream_desc {
+    int32_t n_pairs, max_features, levels;   /* levels of the pyramids built on the device (1..DSDTM_MAX_LEVELS) */
+    int32_t width, height;                   /* level 0 */
+    int32_t row_stride;                      /* bytes between image rows on the host (== width: whole images are copied at once) */
+    size_t image_pitch;                      /* bytes between two frames on the host */
+    const uint8_t* ref_image;                /* host: pair i's reference frame at ref_image + i * image_pitch */
+    const uint8_t* cur_image;                /* host, or NULL = chained (n_pairs + 1 frames at ref_image) */
+    const float* px_xy; const double* bearing; const double* p_world; const uint8_t* initial;   /* host, as dsdtm_batch_desc */
+    const int32_t* n_features;               /* host, n_pairs, or NULL */
+    const double* T_ref_w;                   /* host, n_pairs * 12 */
+    double* T_cur_w;                         /* host, n_pairs * 12, in: seed, out: result */
+    int32_t* n_tracked;                      /* host, n_pairs */
+    dsdtm_align_stats* stats;                /* host, n_pairs, or NULL */
+} dsdtm_stream_desc;
+int dsdtm_sparse_align_batch_streamed(dsdtm_ctx* const* ctx, int n_ctx, const dsdtm_stream_desc* host_frames, int chunk_pairs,
+                                      const dsdtm_camera* cam, const dsdtm_align_params* params);
+
 /* Result check for callers of the asynchronous batch entry point: waits for `hip_stream` and settles the launches
  * issued on it through this context since the last check. Shapes that spread one pair over several compute units
  * (few pairs of more than 448 features; batches of 1025..2048 features) wait for partner workgroups, i.e. for the

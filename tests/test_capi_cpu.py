@@ -40,6 +40,7 @@ def test_struct_layouts_match_the_header():
     assert capi.STATS_DTYPE.itemsize == C.sizeof(capi.AlignStats)
     # 3 ints + 3*8 ints (=108, padded to 112) + 8 size_t + pitch + 11 pointers
     assert C.sizeof(capi.BatchDesc) == 112 + 64 + 8 + 88
+    assert C.sizeof(capi.StreamDesc) == 6 * 4 + 8 + 11 * 8
     assert C.sizeof(capi.ImageDesc) == 4 + 3 * 32 + 4 + 64 + 8 + 8
     assert C.sizeof(capi.DetectParams) == 5 * 4 + 4
     assert C.sizeof(capi.PoseOptParams) == 8 and C.sizeof(capi.PoseOptSummary) == 16 + 16 + 48
@@ -50,6 +51,7 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
     import subprocess
     pairs = [("dsdtm_camera", capi.Camera, []), ("dsdtm_pyramid", capi.Pyramid, []), ("dsdtm_align_params", capi.AlignParams, []),
              ("dsdtm_align_stats", capi.AlignStats, []), ("dsdtm_batch_desc", capi.BatchDesc, []),
+             ("dsdtm_stream_desc", capi.StreamDesc, ["row_stride", "image_pitch", "ref_image", "cur_image", "n_features", "stats"]),
              ("dsdtm_detect_params", capi.DetectParams, ["detection_threshold"]),
              ("dsdtm_pose_opt_params", capi.PoseOptParams, ["max_iterations"]),
              ("dsdtm_pose_opt_summary", capi.PoseOptSummary, ["termination", "n_residual_blocks", "initial_cost", "final_cost", "x"])]

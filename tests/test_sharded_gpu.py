@@ -109,6 +109,8 @@ def test_example_batch_cpp_over_several_contexts(tmp_path, gpu_ctx, oracle):
         for k in ("ref", "cur", "px", "bear", "pw", "ini", "Tr", "Tc"):
             f.write(a[k].tobytes())
     out = subprocess.run([exe, str(path), "3"], capture_output=True, text=True, check=True).stdout.split("\n")
+    # (default: the streamed entry — level 0 only, pyramids on the device; "sharded": whole pyramids. Same bits.)
+    assert subprocess.run([exe, str(path), "3", "sharded"], capture_output=True, text=True, check=True).stdout.split("\n") == out
     shards = [l.split() for l in out if l.startswith("shard")]
     assert [(int(s[5]), int(s[6])) for s in shards] == [shard.pair_range(7, g, 3) for g in range(3)]
     rows = [l.split() for l in out if l.startswith("pair")]
@@ -224,3 +226,126 @@ def test_twenty_streams_through_one_context(gpu_ctx, oracle):
                 assert ntg[i] == no
     ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, streams[0].cuda_stream))
     ctx.close()
+
+
+def _stream_desc(a, frames_ref, frames_cur, P, N, L, W, Hh, row_stride=None, image_pitch=None):
+    s = capi.StreamDesc()
+    s.n_pairs, s.max_features, s.levels, s.width, s.height = P, N, L, W, Hh
+    s.row_stride = row_stride or W
+    s.image_pitch = image_pitch or W * Hh
+    s.ref_image = frames_ref.ctypes.data
+    s.cur_image = frames_cur.ctypes.data if frames_cur is not None else None
+    s.px_xy, s.bearing, s.p_world, s.initial = (a[k].ctypes.data for k in ("px", "bear", "pw", "ini"))
+    s.n_features, s.T_ref_w, s.T_cur_w, s.n_tracked, s.stats = None, a["Tr"].ctypes.data, a["Tc"].ctypes.data, a["nt"].ctypes.data, a["st"].ctypes.data
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chained", [False, True], ids=["separate ref/cur frames", "chained sequence"])
+def test_streamed_batch_equals_the_sharded_entry(gpu_ctx, oracle, chained):
+    """dsdtm_sparse_align_batch_streamed: level 0 only from host memory, chunks of 4 pairs (upload of chunk j + 1 beside
+    pyramids + alignment of chunk j), pyramids by the device pyrDown — over 1, 2 and 3 contexts on one device. Bit for bit
+    the results of dsdtm_sparse_align_batch_sharded on the same frames with host-built pyramids, i.e. the oracle's."""
+    W, Hh, L, N = 320, 240, 3, 150
+    if chained:
+        scenes = synth.make_sequence(n_frames=12, width=W, height=Hh, levels=L, n_patches=N, seed=23, margin=12)
+    else:
+        scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=4100 + i, margin=12) for i in range(11)]
+    P = len(scenes)
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    lib = gpu_ctx.lib
+    a0, b0, _ = _host_batch(scenes, L, W, Hh)
+    one = (C.c_void_p * 1)(gpu_ctx.handle)
+    assert lib.dsdtm_sparse_align_batch_sharded(one, 1, C.byref(b0), C.byref(cam), C.byref(prm)) == 0
+    if chained:
+        fr = np.stack([sc.ref_pyr[0] for sc in scenes] + [scenes[-1].cur_pyr[0]]).reshape(P + 1, W * Hh)
+        fc = None
+    else:
+        fr = np.stack([sc.ref_pyr[0] for sc in scenes]).reshape(P, W * Hh)
+        fc = np.stack([sc.cur_pyr[0] for sc in scenes]).reshape(P, W * Hh)
+    for G in (1, 2, 3):
+        ctxs = [capi.Context(0) for _ in range(G)]
+        a, _, _ = _host_batch(scenes, L, W, Hh)
+        s = _stream_desc(a, fr, fc, P, N, L, W, Hh)
+        arr = (C.c_void_p * G)(*[c.handle for c in ctxs])
+        rc = lib.dsdtm_sparse_align_batch_streamed(arr, G, C.byref(s), 4, C.byref(cam), C.byref(prm))
+        assert rc == 0, ctxs[0].lib.dsdtm_last_error(ctxs[0].handle)
+        assert np.array_equal(a["Tc"], a0["Tc"]) and np.array_equal(a["nt"], a0["nt"])
+        assert np.array_equal(a["st"]["iters"], a0["st"]["iters"]) and np.array_equal(a["st"]["chi2"], a0["st"]["chi2"])
+        for c in ctxs:
+            c.close()
+    for i, sc in enumerate(scenes):
+        To, no, _ = oracle.sparse_align(sc, L, 0, 10)
+        H.assert_pose_close(a0["Tc"][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"pair {i}")
+        assert a0["nt"][i] == no
+
+
+@pytest.mark.gpu
+def test_streamed_batch_padded_rows_ragged_counts_and_bad_arguments(gpu_ctx, oracle):
+    """Host images with padded rows (row_stride > width: one 2-D copy per image), per-pair live feature counts, a chunk
+    size larger than the batch, 5 contexts for 3 pairs; and the argument checks (done before any thread starts)."""
+    import copy
+    W, Hh, L, N = 320, 240, 3, 150
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=4100 + i, margin=12) for i in range(3)]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    a, _, _ = _host_batch(scenes, L, W, Hh)
+    RS = W + 24
+    fr = np.full((3, Hh, RS), 7, np.uint8); fc = np.full((3, Hh, RS), 9, np.uint8)
+    for i, sc in enumerate(scenes):
+        fr[i, :, :W] = sc.ref_pyr[0]; fc[i, :, :W] = sc.cur_pyr[0]
+    nf = np.array([150, 90, 10], np.int32)
+    s = _stream_desc(a, fr, fc, 3, N, L, W, Hh, row_stride=RS, image_pitch=RS * Hh)
+    s.n_features = nf.ctypes.data
+    ctxs = [capi.Context(0) for _ in range(5)]
+    arr = (C.c_void_p * 5)(*[c.handle for c in ctxs])
+    assert gpu_ctx.lib.dsdtm_sparse_align_batch_streamed(arr, 5, C.byref(s), 1000, C.byref(cam), C.byref(prm)) == 0
+    for i, sc in enumerate(scenes):
+        s2 = copy.copy(sc)
+        n = int(nf[i])
+        s2.px, s2.bearing, s2.p_world, s2.initial = sc.px[:n], sc.bearing[:n], sc.p_world[:n], sc.initial[:n]
+        To, no, _ = oracle.sparse_align(s2, L, 0, 10)
+        assert a["nt"][i] == no
+        H.assert_pose_close(a["Tc"][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"pair {i}")
+    assert a["nt"][2] == 0 and np.array_equal(a["Tc"][2], scenes[2].T_cur_w_seed.reshape(12))
+    # refused up front: negative feature count, no levels, rows shorter than the image, a context listed twice
+    for field, value in (("max_features", -1), ("levels", 0), ("row_stride", W - 1), ("image_pitch", 10)):
+        bad = capi.StreamDesc.from_buffer_copy(bytes(s))
+        setattr(bad, field, value)
+        assert gpu_ctx.lib.dsdtm_sparse_align_batch_streamed(arr, 5, C.byref(bad), 4, C.byref(cam), C.byref(prm)) == capi.ERR_INVALID
+    twice = (C.c_void_p * 2)(ctxs[0].handle, ctxs[0].handle)
+    assert gpu_ctx.lib.dsdtm_sparse_align_batch_streamed(twice, 2, C.byref(s), 4, C.byref(cam), C.byref(prm)) == capi.ERR_INVALID
+    # the sharded entry checks its descriptor before it sizes any staging from it (round-3 advice)
+    _, b, _ = _host_batch(scenes, L, W, Hh)
+    for field, value in (("max_features", -1), ("levels", 0), ("pyr_pitch", 0), ("pyr_pitch", 6)):
+        bad = capi.BatchDesc.from_buffer_copy(bytes(b))
+        setattr(bad, field, value)
+        assert gpu_ctx.lib.dsdtm_sparse_align_batch_sharded(arr, 5, C.byref(bad), C.byref(cam), C.byref(prm)) == capi.ERR_INVALID
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_sharded_large_pairs_take_the_big_lds_kernels_on_every_context(gpu_ctx, oracle):
+    """1000- and 2000-feature pairs run kernels that need the > 64 KB dynamic-LDS opt-in — per kernel AND per device
+    (round 3 set it once per process). Three contexts, each launching from its own host thread: every shard must get a
+    launchable kernel, and the oracle's results."""
+    W, Hh, L = 320, 240, 3
+    for N, P in ((1000, 99), (1900, 54)):      # 33 / 18 pairs per shard: too many for teams -> the one-CU / two-member LDS kernels
+        base = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=5200 + N + i, margin=12) for i in range(2)]
+        want = [oracle.sparse_align(sc, L, 0, 10) for sc in base]
+        scenes = [base[i % 2] for i in range(P)]
+        cam = capi.camera_struct(scenes[0].cam)
+        prm = capi.AlignParams(L, 0, 10, 15)
+        a, b, _ = _host_batch(scenes, L, W, Hh)
+        ctxs = [capi.Context(0) for _ in range(3)]
+        arr = (C.c_void_p * 3)(*[c.handle for c in ctxs])
+        rc = gpu_ctx.lib.dsdtm_sparse_align_batch_sharded(arr, 3, C.byref(b), C.byref(cam), C.byref(prm))
+        assert rc == 0, [c.lib.dsdtm_last_error(c.handle) for c in ctxs]
+        for c in ctxs:
+            c.close()
+        for i in range(P):
+            To, no, _ = want[i % 2]
+            H.assert_pose_close(a["Tc"][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"N={N} pair {i}")
+            assert a["nt"][i] == no
