@@ -1,0 +1,300 @@
+"""bench_tracking.py — what the reference's Tracking sees: ONE pair / ONE frame at a time (bench.py's `secondary` entries).
+
+BASELINE configs 2, 3 and 5 are literally "1 frame pair, 1 x MI355X": Tracking::TrackWithLastFrame calls Run once per frame
+(src/Tracking.cpp:199-217), then SearchLocalPoints -> FindMatchDirect and Optimizer::PoseOptimization
+(src/Tracking.cpp:224-256). These entries time exactly that through the C ABI's host entry points on device-resident frames
+(the drop-in's shape: each frame crosses the link once, as level 0), with the CPU oracle on the same inputs beside every
+number and the pose delta GPU-vs-CPU.
+
+Two clocks per step, medians of >= 50 calls:
+  wall_ms   — host wall clock around the synchronous host entry point (packing, the launch, the wait, the copy back);
+  device_ms — HIP events on the launch stream around the SAME kernels issued through the asynchronous *_device entry on
+              device-resident copies of the same inputs (what rocprofv3 --kernel-trace sums up for the call).
+Never part of the timed region of the headline value.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+
+
+def _median_wall(fn, n=60, warm=6):
+    ts, r = [], None
+    for _ in range(n + warm):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts[warm:]) * 1e3), float(np.min(ts[warm:]) * 1e3), r
+
+
+def _median_device(torch, stream, fn, n=60, warm=6, before=None):
+    """Median HIP-event time of fn() on `stream` (events recorded on the launch stream; `before` re-seeds in/out buffers
+    outside the event pair)."""
+    ev = []
+    with torch.cuda.stream(stream):
+        for k in range(n + warm):
+            if before:
+                before()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            fn()
+            b.record(stream)
+            ev.append((a, b))
+    stream.synchronize()
+    t = [a.elapsed_time(b) for a, b in ev][warm:]
+    return float(np.median(t)), float(np.min(t))
+
+
+def _device_pair(torch, dev, capi, sc, L):
+    """One scene as a 1-pair device batch (packed pyramids + feature columns), for the asynchronous device entry."""
+    W, Hh = sc.cam.width, sc.cam.height
+    ws, hs, st, offs, nbytes = capi.pyramid_layout(W, Hh, L)
+    pitch = (nbytes + 255) // 256 * 256
+    ref = np.zeros((1, pitch), np.uint8)
+    cur = np.zeros((1, pitch), np.uint8)
+    for l in range(L):
+        ref[0, offs[l]:offs[l] + ws[l] * hs[l]] = sc.ref_pyr[l].reshape(-1)
+        cur[0, offs[l]:offs[l] + ws[l] * hs[l]] = sc.cur_pyr[l].reshape(-1)
+    arr = dict(ref=ref, cur=cur, px=sc.px[None], bear=sc.bearing[None], pw=sc.p_world[None], ini=sc.initial[None],
+               Tr=sc.T_ref_w.reshape(1, 12), Tc=sc.T_cur_w_seed.reshape(1, 12))
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in arr.items()}
+    t["seed"] = t["Tc"].clone()
+    t["nt"] = torch.zeros(1, dtype=torch.int32, device=dev)
+    b = capi.BatchDesc()
+    b.n_pairs, b.max_features, b.levels = 1, len(sc.px), L
+    for l in range(L):
+        b.width[l], b.height[l], b.stride[l], b.level_offset[l] = ws[l], hs[l], st[l], offs[l]
+    b.pyr_pitch = pitch
+    b.ref_pyr, b.cur_pyr, b.px_xy, b.bearing, b.p_world = (t[k].data_ptr() for k in ("ref", "cur", "px", "bear", "pw"))
+    b.initial, b.n_features, b.T_ref_w, b.T_cur_w = t["ini"].data_ptr(), None, t["Tr"].data_ptr(), t["Tc"].data_ptr()
+    b.n_tracked, b.stats = t["nt"].data_ptr(), None
+    return t, b, (ws, hs, st, offs, pitch)
+
+
+def single_pair_entries(torch, dev, ctx, stream):
+    """Sprase_ImgAlign::Run on ONE pair at BASELINE configs 2, 3 and 5 (+ config 5's Align2D refinement)."""
+    from dsdtm_amd import capi, synth, feature_alignment as FA
+    from dsdtm_amd.frame import Config, frames_from_scene
+    from dsdtm_amd.sparse_align import Sprase_ImgAlign
+    from tests import helpers, oracle_lib
+    Config.Set("Camera.Min_fts", 15)
+    out = []
+    for name, kw, prm in (
+            ("config 2: 640x480, 4 levels, 300 patches, cap 10", dict(), (4, 0, 10)),
+            ("config 3 shape: 640x480 (fr3 intrinsics), 4 levels, 1000 patches, cap 10",
+             dict(n_patches=1000, cam=synth.Camera.tum(640, 480, synth.TUM_FR3)), (4, 0, 10)),
+            ("config 5: 1280x960, 4 levels, 2000 patches, cap 10", dict(width=1280, height=960, n_patches=2000, margin=60), (4, 0, 10))):
+        sc = synth.make_scene(**kw)
+        L = prm[0]
+        al = Sprase_ImgAlign(*prm, ctx=ctx, resident_frames=True)
+        cur, ref = frames_from_scene(sc)
+        seed = cur.Get_Pose().copy()
+
+        def run():
+            cur.Set_Pose(seed)
+            return al.Run(cur, ref)
+        wall, wall_min, n_g = _median_wall(run)
+        Tg, st_g = cur.Get_Pose().copy(), dict(al.last_stats)
+        new_ms, new_min, df = _median_wall(lambda: capi.DeviceFrame.from_image(ctx, sc.cur_pyr[0], L), n=50, warm=5)
+        df.close()
+        # the same launch through the asynchronous entry on `stream`, HIP events around it
+        t, b, _ = _device_pair(torch, dev, capi, sc, L)
+        cs, ap = capi.camera_struct(sc.cam), capi.AlignParams(prm[0], prm[1], prm[2], 15)
+        dev_ms, dev_min = _median_device(
+            torch, stream,
+            lambda: ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cs), C.byref(ap), stream.cuda_stream)),
+            before=lambda: t["Tc"].copy_(t["seed"], non_blocking=True))
+        ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, stream.cuda_stream))
+        same = bool(np.array_equal(t["Tc"].cpu().numpy().reshape(3, 4), Tg))
+        t0 = time.perf_counter()
+        To, no, so = oracle_lib.sparse_align(sc, *prm)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        ang, dt = synth.pose_error(Tg, To)
+        e = {"workload": f"ONE pair per call, resident frames — Sprase_ImgAlign::Run, {name}",
+             "unit": "ms per call (median)", "calls": 60,
+             "run_wall_ms": wall, "run_wall_ms_min": wall_min, "run_device_ms": dev_ms, "run_device_ms_min": dev_min,
+             "new_frame_wall_ms": new_ms,
+             "new_frame_note": "dsdtm_frame_create_from_image: level-0 upload + pyramid on the device (one launch), per new frame",
+             "frame_wall_ms": wall + new_ms, "value": 1e3 / (wall + new_ms), "value_unit": "frames/s of one tracker (Run + new frame, wall)",
+             "cpu_oracle_ms": cpu_ms, "cpu_note": "the CPU oracle on the same pair, one thread (the reference's tracking thread)",
+             "device_entry_pose_equals_host_entry": same,
+             "pose_delta_vs_cpu": {"rad": ang, "m": dt, "n_tracked_equal": bool(n_g == no),
+                                   "iterations_equal": bool(list(st_g["iters"]) == list(so["iters"]))},
+             "iterations": [int(x) for x in st_g["iters"][:L]]}
+        if "2000" in name:
+            # config 5's second half: per-feature Align2D refinement of the 2000 features on the current frame
+            rng = np.random.default_rng(0)
+            W, Hh = sc.cam.width, sc.cam.height
+            cpts = np.stack([rng.uniform(20, W - 20, 2000), rng.uniform(20, Hh - 20, 2000)], 1)
+            pb, p = helpers.make_border_patches(sc.cur_pyr[0], cpts)
+            px0 = cpts + rng.uniform(-1.5, 1.5, cpts.shape)
+            lv = np.zeros(2000, np.int32)
+            a_wall, a_min, (cg, pxg) = _median_wall(lambda: FA.align2d_batch(sc.cur_pyr, pb, p, lv, px0, 10, ctx=ctx), n=50, warm=5)
+            t0 = time.perf_counter()
+            co, pxo = oracle_lib.align2d_batch(sc.cur_pyr, pb, p, lv, px0, 10)
+            a_cpu = (time.perf_counter() - t0) * 1e3
+            e["align2d_2000_features"] = {"wall_ms": a_wall, "wall_note": "host entry: uploads the 1280x960 pyramid + patches, one wavefront per feature",
+                                          "cpu_oracle_ms": a_cpu, "flags_equal": bool(np.array_equal(cg, co)),
+                                          "pixels_bit_identical": bool(np.array_equal(pxg, pxo, equal_nan=True))}
+        out.append(e)
+        del t
+    return out
+
+
+def tracked_frame_entry(torch, dev, ctx, stream):
+    """One tracked frame of the front end (src/Tracking.cpp:199-256): new frame -> Run -> FindMatchDirect for every candidate
+    of SearchLocalPoints -> Optimizer::PoseOptimization, each step through its host entry (wall) and through its device entry
+    (HIP events), the CPU oracle's restatement of the same step beside it."""
+    from dsdtm_amd import capi, synth, search, feature_alignment as FA
+    from dsdtm_amd.frame import Config, Frame
+    from dsdtm_amd.optimizer import pose_optimization
+    from dsdtm_amd.sparse_align import Sprase_ImgAlign
+    from tests import oracle_lib
+    from tests.test_search_gpu import make_world
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    cam, kfs, cur, mps = make_world(11, n_points=900)
+    L = 5
+    ref = kfs[0]
+    nf = min(ref.n_features, 300)
+    bb = ref.bearing[:nf]
+    ref_run = Frame(cam, ref.mvImg_Pyr, ref.Get_Pose())
+    ref_run.set_features(ref.px[:nf], bb, bb * (2.0 / bb[:, 2:3]), np.ones(nf, np.uint8))
+    steps = []
+    tdev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ws, hs, ss, offs, nb = capi.pyramid_layout(cam.width, cam.height, L)
+    pitch = (nb + 255) // 256 * 256
+    wa, ha, sa, oa = (C.c_int * L)(*ws), (C.c_int * L)(*hs), (C.c_int * L)(*ss), (C.c_size_t * L)(*offs)
+
+    def pack(pyr):
+        p = np.zeros(pitch, np.uint8)
+        for l in range(L):
+            p[offs[l]:offs[l] + ws[l] * hs[l]] = pyr[l].reshape(-1)
+        return p
+
+    # 1. new frame: level 0 to the device, pyramid there
+    w1, _, df = _median_wall(lambda: capi.DeviceFrame.from_image(ctx, cur.mvImg_Pyr[0], L))
+    h_img = torch.from_numpy(np.ascontiguousarray(cur.mvImg_Pyr[0]).reshape(-1)).pin_memory()
+    d_new = torch.zeros(pitch, dtype=torch.uint8, device=dev)
+
+    def new_frame_dev():
+        d_new[:h_img.numel()].copy_(h_img, non_blocking=True)
+        ctx.check(ctx.lib.dsdtm_pyrdown_batch_device(ctx.handle, d_new.data_ptr(), pitch, 1, L, wa, ha, sa, oa, stream.cuda_stream))
+    d1, _ = _median_device(torch, stream, new_frame_dev)
+    t0 = time.perf_counter(); [oracle_lib.pyrdown(cur.mvImg_Pyr[l]) for l in range(L - 1)]; c1 = (time.perf_counter() - t0) * 1e3
+    steps.append(("new frame (level-0 upload + ComputeImagePyramid on the device)", w1, d1, c1))
+    cur._device_frame = df
+    capi.device_frame_of(ctx, ref_run)
+    for k in kfs:
+        capi.device_frame_of(ctx, k)
+
+    # 2. Sprase_ImgAlign::Run(cur, last): Tracking's constructor arguments (5 levels, cap 8; src/Tracking.cpp:20-24)
+    al = Sprase_ImgAlign(L, 0, 8, ctx=ctx, resident_frames=True)
+    seed = ref.Get_Pose().copy()
+
+    def run():
+        cur.Set_Pose(seed)
+        return al.Run(cur, ref_run)
+    w2, _, n_tr = _median_wall(run)
+    T_run = cur.Get_Pose().copy()
+
+    class _S:
+        pass
+    sc = _S()
+    sc.cam, sc.ref_pyr, sc.cur_pyr, sc.px, sc.bearing = cam, ref_run.mvImg_Pyr, cur.mvImg_Pyr, ref_run.px, ref_run.bearing
+    sc.p_world, sc.initial, sc.T_ref_w, sc.T_cur_w_seed = ref_run.p_world, ref_run.initial, ref_run.Get_Pose(), seed
+    t, b, _ = _device_pair(torch, dev, capi, sc, L)
+    cs, ap = capi.camera_struct(cam), capi.AlignParams(L, 0, 8, 15)
+    d2, _ = _median_device(torch, stream,
+                           lambda: ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cs), C.byref(ap), stream.cuda_stream)),
+                           before=lambda: t["Tc"].copy_(t["seed"], non_blocking=True))
+    t0 = time.perf_counter(); To, no, so = oracle_lib.sparse_align(sc, L, 0, 8); c2 = (time.perf_counter() - t0) * 1e3
+    ang, dt = synth.pose_error(T_run, To)
+    steps.append((f"Sprase_ImgAlign::Run ({nf} features, 5 levels, cap 8; tracked {n_tr})", w2, d2, c2))
+
+    # 3. FindMatchDirect for every candidate of SearchLocalPoints
+    s = search.LocalPointSearch(cam, ctx=ctx, resident_frames=True)
+    s.ResetGrid()
+    for mp in mps:
+        s.ReprojectPoint(cur, mp)
+    cand = []
+    for cell in s.mCells:
+        for mp, px in cell:
+            if mp.IsBad():
+                continue
+            obs = search.get_closest_obs(mp, cur, kfs)
+            if obs is not None:
+                cand.append((mp, px, obs[0], obs[1]))
+    ck = np.array([c[2] for c in cand], np.int32)
+    rp = np.array([kfs[c[2]].px[c[3]] for c in cand], np.float32)
+    rl = np.array([kfs[c[2]].level[c[3]] for c in cand], np.int32)
+    rb = np.array([kfs[c[2]].bearing[c[3]] for c in cand])
+    pw = np.array([c[0].Get_Pose() for c in cand])
+    cpx = np.array([c[1] for c in cand])
+    Tk = np.array([k.Get_Pose() for k in kfs])
+    w3, _, (conv, pxo, sl) = _median_wall(lambda: FA.match_candidates_frames(cur, kfs, cam, Tk, cur.Get_Pose(), ck, rp, rl, rb, pw, cpx, L - 3, 10, ctx=ctx))
+    M = len(cand)
+    d_cur, d_kf = tdev(pack(cur.mvImg_Pyr)[None]), tdev(np.stack([pack(k.mvImg_Pyr) for k in kfs]))
+    d_Tk, d_Tc = tdev(Tk.reshape(len(kfs), 12)), tdev(np.asarray(cur.Get_Pose()).reshape(1, 12))
+    d_fr, d_ck, d_rp, d_rl, d_rb, d_pw = tdev(np.zeros(M, np.int32)), tdev(ck), tdev(rp), tdev(rl), tdev(rb), tdev(pw)
+    d_px0 = tdev(cpx.astype(np.float64)); d_px = d_px0.clone()
+    d_sl, d_cv = torch.zeros(M, dtype=torch.int32, device=dev), torch.zeros(M, dtype=torch.uint8, device=dev)
+    d_scr = torch.empty(ctx.lib.dsdtm_match_candidates_scratch_bytes(M), dtype=torch.uint8, device=dev)
+    wl, hl, sl_, ol = (C.c_int * L)(*ws), (C.c_int * L)(*hs), (C.c_int * L)(*ss), (C.c_size_t * L)(*offs)
+    d3, _ = _median_device(
+        torch, stream,
+        lambda: ctx.check(ctx.lib.dsdtm_match_candidates_batch_device(
+            ctx.handle, d_cur.data_ptr(), 1, d_kf.data_ptr(), len(kfs), pitch, L, wl, hl, sl_, ol, C.byref(cs), d_Tk.data_ptr(), d_Tc.data_ptr(),
+            d_fr.data_ptr(), d_ck.data_ptr(), d_rp.data_ptr(), d_rl.data_ptr(), d_rb.data_ptr(), d_pw.data_ptr(), L - 3, 10, M,
+            d_scr.data_ptr(), d_px.data_ptr(), d_sl.data_ptr(), d_cv.data_ptr(), stream.cuda_stream)),
+        before=lambda: d_px.copy_(d_px0, non_blocking=True))
+    fmd_same = bool(np.array_equal(d_cv.cpu().numpy().astype(bool), conv) and np.array_equal(d_px.cpu().numpy(), pxo, equal_nan=True))
+
+    def cpu_match():
+        aff, sl_o, pb, pp = oracle_lib.warp_patches([k.mvImg_Pyr for k in kfs], cam, Tk, cur.Get_Pose(), ck, rp, rl, rb, pw, L - 3)
+        return oracle_lib.align2d_batch(cur.mvImg_Pyr, pb, pp, sl_o, cpx / (1 << sl_o)[:, None], 10)
+    t0 = time.perf_counter(); conv_o, px_o = cpu_match(); c3 = (time.perf_counter() - t0) * 1e3
+    steps.append((f"FindMatchDirect x {M} candidates (warp prelude + Align2D; {int(conv.sum())} matched)", w3, d3, c3))
+
+    # 4. Optimizer::PoseOptimization on the matches (src/Tracking.cpp:236)
+    ok = conv.astype(bool)
+    bear = synth.bearing_from_px(cam, pxo[ok].astype(np.float32))
+    lvl, pws, use = sl[ok].astype(np.int32), pw[ok], np.ones(int(ok.sum()), np.uint8)
+
+    def po():
+        T = np.ascontiguousarray(cur.Get_Pose(), np.float64).reshape(12).copy()
+        return pose_optimization(ctx, bear, pws, lvl, use, T), T
+    w4, _, ((rn, sm), T_po) = _median_wall(po)
+    nobs = int(ok.sum())
+    d_b, d_w, d_l, d_u = tdev(bear[None]), tdev(pws[None]), tdev(lvl[None]), tdev(use[None])
+    d_T0 = tdev(np.asarray(cur.Get_Pose()).reshape(1, 12)); d_T = d_T0.clone()
+    d_rn = torch.zeros((1, nobs), dtype=torch.float64, device=dev)
+    d_sm = torch.zeros((1, C.sizeof(capi.PoseOptSummary)), dtype=torch.uint8, device=dev)
+    pp_ = capi.PoseOptParams(100, 0)
+    fpo = ctx.lib.dsdtm_pose_optimization_batch_device
+    fpo.restype = C.c_int
+    fpo.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.POINTER(capi.PoseOptParams), C.c_void_p, C.c_void_p, C.c_void_p]
+    d4, _ = _median_device(torch, stream,
+                           lambda: ctx.check(fpo(ctx.handle, 1, nobs, None, d_b.data_ptr(), d_w.data_ptr(), d_l.data_ptr(), d_u.data_ptr(), d_T.data_ptr(),
+                                                 C.byref(pp_), d_rn.data_ptr(), d_sm.data_ptr(), stream.cuda_stream)),
+                           before=lambda: d_T.copy_(d_T0, non_blocking=True))
+    t0 = time.perf_counter(); Tc_o, rn_o, sm_o = oracle_lib.pose_optimization(bear, pws, lvl, use, cur.Get_Pose(), linear_solver=0); c4 = (time.perf_counter() - t0) * 1e3
+    ang4, dt4 = synth.pose_error(T_po.reshape(3, 4), Tc_o)
+    steps.append((f"Optimizer::PoseOptimization ({nobs} observations, {sm['iterations']} trust-region iterations)", w4, d4, c4))
+
+    wall, devt, cpu = (sum(x[i] for x in steps) for i in (1, 2, 3))
+    return {"workload": "ONE tracked frame of the front end (src/Tracking.cpp:199-256) on device-resident frames, 640x480, 5 levels: new frame -> "
+                        "Run -> FindMatchDirect for every candidate of SearchLocalPoints -> PoseOptimization; medians of 60 calls per step",
+            "value": 1e3 / wall, "unit": "tracked frames/s of one tracker (sum of the four library calls, wall)",
+            "frame_wall_ms": wall, "frame_device_ms": devt, "frame_cpu_oracle_ms": cpu,
+            "steps": [{"step": n, "wall_ms": w, "device_ms": d, "cpu_oracle_ms": c} for n, w, d, c in steps],
+            "clock_note": "wall = host wall clock around the synchronous host entry; device = HIP events on the launch stream around the same "
+                          "kernels issued through the asynchronous device entry (incl. the level-0 H2D copy for the new frame); cpu = the CPU "
+                          "oracle's restatement of the step, one thread",
+            "parity": {"run_pose_delta_vs_cpu": {"rad": ang, "m": dt, "n_tracked_equal": bool(n_tr == no),
+                                                 "iterations_equal": bool(list(al.last_stats["iters"]) == list(so["iters"]))},
+                       "find_match_flags_equal_cpu": bool(np.array_equal(conv, conv_o)),
+                       "find_match_pixels_bit_identical_cpu": bool(np.array_equal(pxo, px_o * (1 << sl)[:, None], equal_nan=True)),
+                       "find_match_device_entry_equals_host_entry": fmd_same,
+                       "pose_opt_delta_vs_cpu": {"rad": ang4, "m": dt4, "iterations_equal": bool(sm["iterations"] == sm_o["iterations"])}}}
