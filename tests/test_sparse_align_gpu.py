@@ -1050,3 +1050,73 @@ def test_workspace_launches_are_graph_capturable_after_reserve(gpu_ctx, oracle, 
         assert np.array_equal(first, Tg)
     del g
     ctx.close()
+
+
+def test_more_unsettled_multi_cu_launches_than_recovery_slots(gpu_ctx, oracle):
+    """A context keeps what a re-run needs for 64 unsettled multi-CU launches. The first of 70 team launches on one stream
+    loses a member (its waits run out); nobody calls dsdtm_sparse_align_check in between, so the 65th launch has to settle
+    the oldest one itself — waits for its event, finds the timeout word set, re-seeds and re-runs it on the one-CU kernels —
+    before it reuses the slot. Every launch ends with the oracle's results and the final check has nothing left to repair."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N = 320, 240, 3, 600
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=1300 + N + i, margin=12) for i in range(2)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in scenes]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    ctx = capi.Context(0)                                  # its own context: all 64 slots free
+    f, recovered = _short_team(ctx)
+    st = torch.cuda.Stream(device=dev)
+    packed = [_device_batch(torch, dev, scenes, L, W, Hh) for _ in range(70)]
+    for k, (t, b) in enumerate(packed):
+        launch = f if k == 0 else ctx.lib.dsdtm_sparse_align_batch_device
+        ctx.check(launch(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+        assert recovered(ctx.handle) == (1 if k >= 64 else 0)       # launch 64 (the 65th) settled launch 0
+    ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, st.cuda_stream))
+    assert recovered(ctx.handle) == 1
+    for k, (t, b) in enumerate(packed):
+        Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+        for i, (To, no, _) in enumerate(want):
+            H.assert_pose_close(Tg[i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"launch {k} pair {i}")
+            assert ntg[i] == no
+    ctx.close()
+
+
+def test_captured_large_pairs_run_the_one_cu_kernels(gpu_ctx, oracle):
+    """Inside a stream capture no multi-CU kernel is used (a graph replay could be neither ordered against live team
+    launches nor re-run after a timeout): 18 pairs of 1900 features captured into a hipGraph run the one-CU workspace kernel
+    (scratch reserved up front), replay twice with the oracle's results, and leave nothing to settle."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N, P = 320, 240, 3, 1900, 18
+    base = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=1300 + N + i, margin=12) for i in range(3)]
+    scenes = [base[i % 3] for i in range(P)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in base]
+    t, b = _device_batch(torch, dev, scenes, L, W, Hh)
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    ctx = capi.Context(0)
+    _, recovered = _short_team(ctx)
+    ctx.check(ctx.lib.dsdtm_reserve(ctx.handle, ctx.lib.dsdtm_sparse_align_workspace_bytes(C.byref(b))))
+    seed = t["Tc"].clone()
+    st = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        t["Tc"].copy_(seed)
+        ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), torch.cuda.current_stream().cuda_stream))
+    for rep in range(2):
+        t["Tc"].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+        for i in range(P):
+            To, no, _ = want[i % 3]
+            H.assert_pose_close(Tg[i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"replay {rep} pair {i}")
+            assert ntg[i] == no
+    ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, st.cuda_stream))
+    assert recovered(ctx.handle) == 0
+    ctx.close()

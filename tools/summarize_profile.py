@@ -1,7 +1,7 @@
 """Folds the rocprofv3 output of tools/profile.sh (per case: kernel-trace stats, kernel trace, one --pmc pass per
 counter group) into the summaries kept under profiles/:
-    <out>/r03_kernel_stats.csv     per case and kernel: calls, average / min / max duration
-    <out>/r03_bench_pmc.json       "profile_binary_sha": sha256 (16 hex digits) of the libdsdtm_amd.so the passes ran with —
+    <out>/r04_kernel_stats.csv     per case and kernel: calls, average / min / max duration
+    <out>/r04_bench_pmc.json       "profile_binary_sha": sha256 (16 hex digits) of the libdsdtm_amd.so the passes ran with —
                                    bench.py reports these numbers only while it loads that same binary;
                                    per case and kernel: counters per dispatch + "hbm_traffic_per_launch" entries (what
                                    bench.py's roofline.traffic reads): FETCH_SIZE and WRITE_SIZE are KiB per dispatch;
@@ -24,7 +24,7 @@ with open(os.path.join(REPO, "dsdtm_amd", "csrc", "libdsdtm_amd.so"), "rb") as f
     sha = hashlib.sha256(f.read()).hexdigest()[:16]
 sys.path.insert(0, REPO)
 from dsdtm_amd.csrc import build as hip_build
-stats_rows, pmc = [], {"round": 3, "profile_binary_sha": sha, "profile_source_sha": hip_build.source_sha(), "command": "tools/profile.sh (see the file for every command line)", "cases": {},
+stats_rows, pmc = [], {"round": 4, "profile_binary_sha": sha, "profile_source_sha": hip_build.source_sha(), "command": "tools/profile.sh (see the file for every command line)", "cases": {},
                        "hbm_traffic_per_launch": [], "fp64_per_launch": [], "overlap": {}}
 for case in sorted(os.listdir(src)):
     d = os.path.join(src, case)
@@ -34,7 +34,7 @@ for case in sorted(os.listdir(src)):
         for r in csv.DictReader(open(f)):
             if "dsdtm" not in r["Name"]:
                 continue                              # torch's data-generation kernels are not ours to report
-            if case not in ("track", "poseopt", "kernels") and "sparse_align" not in r["Name"]:
+            if case not in ("track", "poseopt", "kernels", "secondary") and "sparse_align" not in r["Name"]:
                 continue                              # bench cases: the kernel of record only (pyramids there are set-up)
             stats_rows.append(dict(case=case, kernel=r["Name"], calls=r["Calls"], avg_ns=r["AverageNs"], min_ns=r["MinNs"],
                                    max_ns=r["MaxNs"], total_ns=r["TotalDurationNs"], percent=r["Percentage"]))
@@ -59,6 +59,40 @@ for case in sorted(os.listdir(src)):
             flops = 64.0 * (m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + 2.0 * m["SQ_INSTS_VALU_FMA_F64"] + m["SQ_INSTS_VALU_TRANS_F64"])
             if flops > 0:
                 pmc["fp64_per_launch"].append(dict(case=case, kernel=k, wave_instructions=m, fp64_flops_per_launch=flops))
+    if case == "secondary":
+        # Entries of the driver line that are made of several kernels / of kernels that also run at other sizes: dispatches are
+        # told apart by their grid size (work-items), traffic = sum over the kernels of ONE call of the entry.
+        by_grid = collections.defaultdict(lambda: collections.defaultdict(list))
+        for f in glob.glob(f"{d}/pmc_*/**/*_counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "dsdtm" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    by_grid[(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        def one(sub, grid):
+            for (k, g), cs in by_grid.items():
+                if sub in k and g == grid and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                    return k, sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024.0, sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024.0
+            return None
+        def entry(name, parts, alg):
+            got = [one(sub, grid) for sub, grid in parts]
+            if any(g is None for g in got):
+                print("secondary: no dispatches for", name, parts)
+                return
+            fetch, write = sum(g[1] for g in got), sum(g[2] for g in got)
+            pmc["hbm_traffic_per_launch"].append(dict(
+                case=case, kernel=name, dispatches_per_launch=len(parts), algorithmic_bytes_per_launch=alg, fetch_bytes_raw=fetch,
+                fetch_bytes_gfx950_corrected=2.0 * fetch, write_bytes=write, traffic_over_algorithmic=(2.0 * fetch + write) / alg))
+        M, Mm, nfm, nfr = 262144, 64 * 800, 64, 256
+        pyr5 = 640 * 480 + 320 * 240 + 160 * 120 + 80 * 60 + 40 * 30
+        entry("align2d_kernel", [("align2d_kernel", M // 4 * 256)], M * 197 + 1280 * 960)
+        entry("warp_kernel+align2d_kernel", [("warp_kernel", Mm * 128), ("align2d_kernel", Mm // 4 * 256)],
+              Mm * (4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1 + 2 * (100 + 64)) + 2 * nfm * 640 * 480)
+        strip_tasks = (640 // 4) * ((480 + 3) // 4)
+        sel_tasks = (640 // 4) * 480
+        entry("fast_score_strip_kernel+fast_select_kernel+detect_decode_kernel",
+              [("fast_score_strip_kernel", (strip_tasks + 255) // 256 * 256 * 5 * nfr), ("fast_select_kernel", (sel_tasks + 255) // 256 * 256 * 5 * nfr),
+               ("detect_decode_kernel", (nfr * 26 * 20 + 255) // 256 * 256)], nfr * 3 * pyr5)
+        for (k, g), cs in sorted(by_grid.items()):
+            print("secondary dispatch", k[:60], g, {c: len(v) for c, v in cs.items()})
     if case in ALG:
         sub, alg, nd = ALG[case]
         for k, cs in ctr.items():
@@ -69,7 +103,7 @@ for case in sorted(os.listdir(src)):
                     case=case, kernel=k, dispatches_per_launch=nd, algorithmic_bytes_per_launch=alg, fetch_bytes_raw=fetch,
                     fetch_bytes_gfx950_corrected=2.0 * fetch, write_bytes=write,
                     traffic_over_algorithmic=(2.0 * fetch + write) / alg))
-with open(os.path.join(src, "r03_kernel_stats.csv"), "w", newline="") as f:
+with open(os.path.join(src, "r04_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=["case", "kernel", "calls", "avg_ns", "min_ns", "max_ns", "total_ns", "percent"])
     w.writeheader()
     w.writerows(stats_rows)
@@ -96,7 +130,7 @@ for f in glob.glob(f"{src}/main/trace/**/*_kernel_trace.csv", recursive=True):
               union_span_ns=busy, union_span_per_launch_ns=busy / len(rows), launches_in_flight_avg=weighted / busy,
               first_start=st[0], last_end=max(en), wall_per_launch_ns=(max(en) - st[0]) / len(rows))
 pmc["overlap"] = ov
-json.dump(pmc, open(os.path.join(src, "r03_bench_pmc.json"), "w"), indent=1)
+json.dump(pmc, open(os.path.join(src, "r04_bench_pmc.json"), "w"), indent=1)
 print(json.dumps(ov, indent=1))
 print(json.dumps(pmc["hbm_traffic_per_launch"], indent=1))
 for r in stats_rows:
