@@ -119,7 +119,7 @@ hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, 
 hipError_t pyrdown_fused_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int levels, const int* w, const int* h,
                                 const int* stride, const size_t* off, int band, hipStream_t stream, bool* launched);
 
-// Warp prelude: one 128-thread group per candidate (100 sample lanes).
+// Warp prelude: groups of 2 / 64 candidates per 128-thread workgroup (lane = candidate for the FP64 chain, thread = sample for the patches).
 struct WarpKernelArgs {
     const uint8_t* kf_pyr;        // n_kf packed pyramids, pitch kf_pitch ...
     const uint8_t* const* kf_ptrs; // ... or (non-null) n_kf base pointers of separately allocated pyramids (device array)

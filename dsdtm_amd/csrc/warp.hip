@@ -3,8 +3,8 @@
 // Replaces reference src/Feature_alignment.cpp:160-190 (SolveAffineMatrix), :192-204
 // (GetBestSearchLevel), :206-259 (WarpAffine), :261-275 (GetPatchNoBoarder), including the
 // integer-division quirk W1 (`1/(1<<lvl)` is 0 for lvl>=1, :231) and the float->u8 truncation.
-// One 128-thread group per candidate: the 2x2 affine is evaluated in FP64 by every lane
-// (wave-uniform), lanes 0..99 each produce one sample of the 10x10 bordered patch.
+// Groups of 2 or 64 candidates per 128-thread workgroup: the 2x2 affine is evaluated in FP64 ONCE per candidate
+// (lane = candidate), then the group's 10x10 bordered patches are sampled thread = sample (warp_kernel below).
 //
 // The outputs are BYTES (float sample positions truncated to u8) and a search level decided by a
 // threshold on det(A): a last-bit difference in the FP64 pose chain can flip either. So this file
@@ -115,107 +115,154 @@ __device__ __forceinline__ void cam2px(const WarpKernelArgs& a, double x, double
     v = (double)a.fy * y / z + (double)a.cy;
 }
 
+// What phase 2 needs of a candidate (phase 1 -> LDS): the inverse affine in float (:209-213), the reference pixel on its
+// level (:215-216), quirk W1's integer scale, and where to sample.
+typedef uint16_t __attribute__((aligned(1))) U16u;      // a 16-bit load at any byte address
+
+struct WarpCand {
+    float Ai0, Ai1, Ai2, Ai3;
+    float refx, refy;
+    int int_scale;
+    int meta;              // ref level | keyframe << 8, or -1: rejected (zero patches)
+};
+
+// G candidates per 128-thread group (2 for one frame's search, 64 for batches), two phases:
+//  1. lane = candidate (G of the 128 lanes): the FP64 chain — SolveAffineMatrix, GetBestSearchLevel, the inverse affine —
+//     ONCE per candidate. (Round 1-3: one group per candidate with all 128 lanes evaluating the same chain: 2 waves x ~2 k
+//     dependent FP64 instructions per candidate, 96 % of the kernel; 51 200 candidates took 213 us.)
+//  2. thread = sample: the group's G x 100 samples of the 10x10 bordered patches in one strided loop (consecutive
+//     threads write consecutive bytes of patch_border), four byte gathers each.
+// Same arithmetic, same operation order, same bytes as before (tests/test_align2d_gpu.py::test_warp_patches_match_oracle).
+template <int G>
 __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
-    const int c = blockIdx.x;
-    if (c >= a.m) return;
-    const int j = threadIdx.x;
-    const int k = a.cand_kf[c];
-    const int tLevel = a.ref_level[c];
-    const int fr = a.cand_frame ? a.cand_frame[c] : 0;
-    if (k < 0 || k >= a.n_kf || tLevel < 0 || tLevel >= a.levels || fr < 0 || (a.cand_frame && fr >= a.n_frames)) {
+    __shared__ WarpCand s_c[G];
+    const int c0 = (int)blockIdx.x * G;
+    const int tid = threadIdx.x;
+    const int ng = a.m - c0 < G ? a.m - c0 : G;          // candidates of this group
+    if (tid < ng) {
+        const int c = c0 + tid;
+        WarpCand wc;
+        wc.Ai0 = wc.Ai1 = wc.Ai2 = wc.Ai3 = wc.refx = wc.refy = 0.0f; wc.int_scale = 0; wc.meta = -1;
+        const int k = a.cand_kf[c];
+        const int tLevel = a.ref_level[c];
+        const int fr = a.cand_frame ? a.cand_frame[c] : 0;
         // a candidate that names a keyframe, level or current frame outside the batch is rejected, not dereferenced
-        if (j == 0) a.search_level[c] = -1;
-        if (j < 100) a.patch_border[(size_t)c * 100 + j] = 0;
-        if (j < 64) a.patch[(size_t)c * 64 + j] = 0;
-        return;
-    }
-    // ---- SolveAffineMatrix (:160-190) ----
-    const SE3x Tcur = xse3_from_rt(a.cand_frame ? a.T_cur_w_arr + 12 * (size_t)fr : a.T_cur_w);
-    const SE3x Tkf = xse3_from_rt(a.T_kf_w + 12 * (size_t)k);
-    const SE3x Tki = xse3_inverse(Tkf);
-    const double* P = a.p_world + 3 * (size_t)c;
-    const double* nb = a.ref_bearing + 3 * (size_t)c;
-    const double d0 = Tki.tx - P[0], d1 = Tki.ty - P[1], d2 = Tki.tz - P[2];
-    const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-    const double rp0 = dist * nb[0], rp1 = dist * nb[1], rp2 = dist * nb[2];          // :167
-    const float rx = a.ref_px[2 * (size_t)c], ry = a.ref_px[2 * (size_t)c + 1];
-    const int HPL = 5;
-    const double pxU0 = (double)(rx + (float)(HPL * (1 << tLevel))), pxU1 = (double)ry;   // :171
-    const double pxV0 = (double)rx, pxV1 = (double)(ry + (float)(HPL * (1 << tLevel)));  // :172
-    // Pixel2Camera(Vector2d, 1.0f) (src/Camera.cpp:180-185), normalise, rescale to the ref depth
-    double U0 = 1.0f * (pxU0 - (double)a.cx) / (double)a.fx, U1 = 1.0f * (pxU1 - (double)a.cy) / (double)a.fy, U2 = 1.0;
-    double V0 = 1.0f * (pxV0 - (double)a.cx) / (double)a.fx, V1 = 1.0f * (pxV1 - (double)a.cy) / (double)a.fy, V2 = 1.0;
-    {
-        const double nU = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
-        U0 /= nU; U1 /= nU; U2 /= nU;
-        const double nV = sqrt(V0 * V0 + V1 * V1 + V2 * V2);
-        V0 /= nV; V1 /= nV; V2 /= nV;
-        const double sU = rp2 / U2, sV = rp2 / V2;
-        U0 *= sU; U1 *= sU; U2 *= sU;
-        V0 *= sV; V1 *= sV; V2 *= sV;
-    }
-    const SE3x Tc2r = xse3_mul(Tcur, Tki);                                             // :181
-    double q0x, q0y, q0z, qUx, qUy, qUz, qVx, qVy, qVz;
-    xq_rotate(Tc2r, rp0, rp1, rp2, q0x, q0y, q0z); q0x += Tc2r.tx; q0y += Tc2r.ty; q0z += Tc2r.tz;
-    xq_rotate(Tc2r, U0, U1, U2, qUx, qUy, qUz);    qUx += Tc2r.tx; qUy += Tc2r.ty; qUz += Tc2r.tz;
-    xq_rotate(Tc2r, V0, V1, V2, qVx, qVy, qVz);    qVx += Tc2r.tx; qVy += Tc2r.ty; qVz += Tc2r.tz;
-    double c0u, c0v, cUu, cUv, cVu, cVv;
-    cam2px(a, q0x, q0y, q0z, c0u, c0v);
-    cam2px(a, qUx, qUy, qUz, cUu, cUv);
-    cam2px(a, qVx, qVy, qVz, cVu, cVv);
-    const double A00 = (cUu - c0u) / HPL, A10 = (cUv - c0v) / HPL;                     // :186
-    const double A01 = (cVu - c0u) / HPL, A11 = (cVv - c0v) / HPL;                     // :187
-    // ---- GetBestSearchLevel (:192-204) ----
-    int sl = 0;
-    double D = A00 * A11 - A01 * A10;
-    while (D > 3.0 && sl < a.max_search_level) { sl++; D = D * 0.25; }
-    if (j == 0) {
-        if (a.affine) {
-            double* o = a.affine + 4 * (size_t)c;
-            o[0] = A00; o[1] = A01; o[2] = A10; o[3] = A11;
+        const bool ok = !(k < 0 || k >= a.n_kf || tLevel < 0 || tLevel >= a.levels || fr < 0 || (a.cand_frame && fr >= a.n_frames));
+        if (!ok) {
+            a.search_level[c] = -1;
+        } else {
+            // ---- SolveAffineMatrix (:160-190) ----
+            const SE3x Tcur = xse3_from_rt(a.cand_frame ? a.T_cur_w_arr + 12 * (size_t)fr : a.T_cur_w);
+            const SE3x Tkf = xse3_from_rt(a.T_kf_w + 12 * (size_t)k);
+            const SE3x Tki = xse3_inverse(Tkf);
+            const double* P = a.p_world + 3 * (size_t)c;
+            const double* nb = a.ref_bearing + 3 * (size_t)c;
+            const double d0 = Tki.tx - P[0], d1 = Tki.ty - P[1], d2 = Tki.tz - P[2];
+            const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+            const double rp0 = dist * nb[0], rp1 = dist * nb[1], rp2 = dist * nb[2];          // :167
+            const float rx = a.ref_px[2 * (size_t)c], ry = a.ref_px[2 * (size_t)c + 1];
+            const int HPL = 5;
+            const double pxU0 = (double)(rx + (float)(HPL * (1 << tLevel))), pxU1 = (double)ry;   // :171
+            const double pxV0 = (double)rx, pxV1 = (double)(ry + (float)(HPL * (1 << tLevel)));  // :172
+            // Pixel2Camera(Vector2d, 1.0f) (src/Camera.cpp:180-185), normalise, rescale to the ref depth
+            double U0 = 1.0f * (pxU0 - (double)a.cx) / (double)a.fx, U1 = 1.0f * (pxU1 - (double)a.cy) / (double)a.fy, U2 = 1.0;
+            double V0 = 1.0f * (pxV0 - (double)a.cx) / (double)a.fx, V1 = 1.0f * (pxV1 - (double)a.cy) / (double)a.fy, V2 = 1.0;
+            {
+                const double nU = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
+                U0 /= nU; U1 /= nU; U2 /= nU;
+                const double nV = sqrt(V0 * V0 + V1 * V1 + V2 * V2);
+                V0 /= nV; V1 /= nV; V2 /= nV;
+                const double sU = rp2 / U2, sV = rp2 / V2;
+                U0 *= sU; U1 *= sU; U2 *= sU;
+                V0 *= sV; V1 *= sV; V2 *= sV;
+            }
+            const SE3x Tc2r = xse3_mul(Tcur, Tki);                                             // :181
+            double q0x, q0y, q0z, qUx, qUy, qUz, qVx, qVy, qVz;
+            xq_rotate(Tc2r, rp0, rp1, rp2, q0x, q0y, q0z); q0x += Tc2r.tx; q0y += Tc2r.ty; q0z += Tc2r.tz;
+            xq_rotate(Tc2r, U0, U1, U2, qUx, qUy, qUz);    qUx += Tc2r.tx; qUy += Tc2r.ty; qUz += Tc2r.tz;
+            xq_rotate(Tc2r, V0, V1, V2, qVx, qVy, qVz);    qVx += Tc2r.tx; qVy += Tc2r.ty; qVz += Tc2r.tz;
+            double c0u, c0v, cUu, cUv, cVu, cVv;
+            cam2px(a, q0x, q0y, q0z, c0u, c0v);
+            cam2px(a, qUx, qUy, qUz, cUu, cUv);
+            cam2px(a, qVx, qVy, qVz, cVu, cVv);
+            const double A00 = (cUu - c0u) / HPL, A10 = (cUv - c0v) / HPL;                     // :186
+            const double A01 = (cVu - c0u) / HPL, A11 = (cVv - c0v) / HPL;                     // :187
+            // ---- GetBestSearchLevel (:192-204) ----
+            int sl = 0;
+            double D = A00 * A11 - A01 * A10;
+            while (D > 3.0 && sl < a.max_search_level) { sl++; D = D * 0.25; }
+            if (a.affine) {
+                double* o = a.affine + 4 * (size_t)c;
+                o[0] = A00; o[1] = A01; o[2] = A10; o[3] = A11;
+            }
+            a.search_level[c] = sl;
+            // ---- WarpAffine, per-candidate part (:206-216, :231) ----
+            const double det = A00 * A11 - A01 * A10;
+            const double invdet = 1.0 / det;
+            wc.Ai0 = (float)(A11 * invdet); wc.Ai1 = (float)(-A01 * invdet);
+            wc.Ai2 = (float)(-A10 * invdet); wc.Ai3 = (float)(A00 * invdet);
+            wc.refx = rx / (float)(1 << tLevel); wc.refy = ry / (float)(1 << tLevel);          // :215-216
+            wc.int_scale = 1 / (1 << sl);                                                      // :231 quirk W1
+            wc.meta = tLevel | (k << 8);
         }
-        a.search_level[c] = sl;
+        s_c[tid] = wc;
     }
-    if (j >= 100) return;
-    // ---- WarpAffine (:206-259) ----
-    const double det = A00 * A11 - A01 * A10;
-    const double invdet = 1.0 / det;
-    const float Ai0 = (float)(A11 * invdet), Ai1 = (float)(-A01 * invdet);
-    const float Ai2 = (float)(-A10 * invdet), Ai3 = (float)(A00 * invdet);
-    const LevelGeom lg = a.lv[tLevel];
-    const uint8_t* __restrict__ img = (a.kf_ptrs ? a.kf_ptrs[k] : a.kf_pyr + (size_t)k * a.kf_pitch) + lg.off;
-    const float refx = rx / (float)(1 << tLevel), refy = ry / (float)(1 << tLevel);     // :215-216
-    const int int_scale = 1 / (1 << sl);                                                // :231 quirk W1
-    const int ix = (j % 10) - 5, iy = (j / 10) - 5;
-    const float gx = (Ai0 * (float)ix + Ai1 * (float)iy) * (float)int_scale;
-    const float gy = (Ai2 * (float)ix + Ai3 * (float)iy) * (float)int_scale;
-    const float wx = gx + refx, wy = gy + refy;                                         // :232
-    uint8_t outv = 0;
-    if (!(wx != wx) && !(wy != wy) && !(wx < 0) && !(wy < 0) && !(wx > (float)(lg.w - 1)) && !(wy > (float)(lg.h - 1))) {
-        const int fx_ = (int)floor((double)wx), fy_ = (int)floor((double)wy);
-        const float sx = wx - (float)fx_, sy = wy - (float)fy_;
-        const float omx = 1.0f - sx, omy = 1.0f - sy;
-        const float w00 = omx * omy;
-        const float w01 = omx * sy;                                                     // :242
-        const float w10 = sx * omy;                                                     // :243
-        const float w11 = 1.0f - w00 - w01 - w10;                                       // :244
-        const int sz = lg.stride * lg.h, o = lg.stride * fy_ + fx_;
-        const float p00 = (float)img[o];
-        const float p01 = (o + lg.stride < sz) ? (float)img[o + lg.stride] : 0.0f;
-        const float p10 = (o + 1 < sz) ? (float)img[o + 1] : 0.0f;
-        const float p11 = (o + lg.stride + 1 < sz) ? (float)img[o + lg.stride + 1] : 0.0f;
-        const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;                // :254
-        outv = (uint8_t)(int)val;                                                       // truncation
+    __syncthreads();
+    // ---- WarpAffine, per-sample part (:217-259) + GetPatchNoBoarder (:261-275) ----
+    const int n_samples = ng * 100;
+    for (int s = tid; s < n_samples; s += 128) {
+        const int cl = s / 100, j = s - cl * 100;
+        const WarpCand wc = s_c[cl];
+        const int c = c0 + cl;
+        uint8_t outv = 0;
+        if (wc.meta >= 0) {
+            const int tLevel = wc.meta & 0xff, k = wc.meta >> 8;
+            const LevelGeom lg = a.lv[tLevel];
+            const uint8_t* __restrict__ img = (a.kf_ptrs ? a.kf_ptrs[k] : a.kf_pyr + (size_t)k * a.kf_pitch) + lg.off;
+            const int ix = (j % 10) - 5, iy = (j / 10) - 5;
+            const float gx = (wc.Ai0 * (float)ix + wc.Ai1 * (float)iy) * (float)wc.int_scale;
+            const float gy = (wc.Ai2 * (float)ix + wc.Ai3 * (float)iy) * (float)wc.int_scale;
+            const float wx = gx + wc.refx, wy = gy + wc.refy;                                   // :232
+            if (!(wx != wx) && !(wy != wy) && !(wx < 0) && !(wy < 0) && !(wx > (float)(lg.w - 1)) && !(wy > (float)(lg.h - 1))) {
+                const int fx_ = (int)floor((double)wx), fy_ = (int)floor((double)wy);
+                const float sx = wx - (float)fx_, sy = wy - (float)fy_;
+                const float omx = 1.0f - sx, omy = 1.0f - sy;
+                const float w00 = omx * omy;
+                const float w01 = omx * sy;                                                     // :242
+                const float w10 = sx * omy;                                                     // :243
+                const float w11 = 1.0f - w00 - w01 - w10;                                       // :244
+                const int sz = lg.stride * lg.h, o = lg.stride * fy_ + fx_;
+                float p00, p01, p10, p11;
+                if (o + lg.stride + 1 < sz) {
+                    // both rows inside the level (everywhere but its last row): the two horizontal neighbours of a row in ONE
+                    // 16-bit load (unaligned global loads are native on gfx950) — the sampling loop is bound by the number of
+                    // per-lane gathers, not by bytes
+                    const uint16_t r0 = *(const U16u*)(img + o), r1 = *(const U16u*)(img + o + lg.stride);
+                    p00 = (float)(r0 & 0xff); p10 = (float)(r0 >> 8);
+                    p01 = (float)(r1 & 0xff); p11 = (float)(r1 >> 8);
+                } else {
+                    p00 = (float)img[o];
+                    p01 = (o + lg.stride < sz) ? (float)img[o + lg.stride] : 0.0f;
+                    p10 = (o + 1 < sz) ? (float)img[o + 1] : 0.0f;
+                    p11 = 0.0f;                                                                 // o + stride + 1 >= sz here
+                }
+                const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;                // :254
+                outv = (uint8_t)(int)val;                                                       // truncation
+            }
+        }
+        a.patch_border[(size_t)c * 100 + j] = outv;
+        const int r = j / 10, cc = j % 10;
+        if (r >= 1 && r <= 8 && cc >= 1 && cc <= 8) a.patch[(size_t)c * 64 + (r - 1) * 8 + (cc - 1)] = outv;
     }
-    a.patch_border[(size_t)c * 100 + j] = outv;
-    // ---- GetPatchNoBoarder (:261-275) ----
-    const int r = j / 10, cc = j % 10;
-    if (r >= 1 && r <= 8 && cc >= 1 && cc <= 8) a.patch[(size_t)c * 64 + (r - 1) * 8 + (cc - 1)] = outv;
 }
 
 hipError_t warp_launch(const WarpKernelArgs& args, hipStream_t stream) {
     if (args.m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)args.m), dim3(128), 0, stream, args);
+    // few candidates (one frame's search: ~800): groups of 2 — the call is bound by the latency of one candidate's FP64
+    // chain, so the sampling loop behind it is kept to two rounds and the groups spread over every compute unit;
+    // batches: groups of 64 (one full wave of phase-1 lanes)
+    if (args.m < 8192) hipLaunchKernelGGL(warp_kernel<2>, dim3((unsigned)((args.m + 1) / 2)), dim3(128), 0, stream, args);
+    else hipLaunchKernelGGL(warp_kernel<64>, dim3((unsigned)((args.m + 63) / 64)), dim3(128), 0, stream, args);
     return hipGetLastError();
 }
 

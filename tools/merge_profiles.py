@@ -19,6 +19,8 @@ for d in sys.argv[1:]:
     pmc["fp64_per_launch"] += p["fp64_per_launch"]
     if p.get("overlap"):
         pmc["overlap"] = p["overlap"]
+    if p.get("secondary_kernel_durations"):
+        pmc["secondary_kernel_durations"] = p["secondary_kernel_durations"]
 with open(os.path.join(REPO, "profiles", "r04_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()

@@ -60,6 +60,15 @@ for case in sorted(os.listdir(src)):
             if flops > 0:
                 pmc["fp64_per_launch"].append(dict(case=case, kernel=k, wave_instructions=m, fp64_flops_per_launch=flops))
     if case == "secondary":
+        # kernel durations of the driver line's secondary entries, told apart by grid size (the stats file averages all sizes)
+        dur = collections.defaultdict(list)
+        for f in glob.glob(f"{d}/trace/**/*_kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "dsdtm" in r["Kernel_Name"]:
+                    g = int(r.get("Grid_Size") or (int(r.get("Grid_Size_X", 0)) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1))))
+                    dur[(r["Kernel_Name"], g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        pmc["secondary_kernel_durations"] = [dict(kernel=k, grid_work_items=g, calls=len(v), avg_ns=sum(v) / len(v), min_ns=min(v))
+                                             for (k, g), v in sorted(dur.items())]
         # Entries of the driver line that are made of several kernels / of kernels that also run at other sizes: dispatches are
         # told apart by their grid size (work-items), traffic = sum over the kernels of ONE call of the entry.
         by_grid = collections.defaultdict(lambda: collections.defaultdict(list))
