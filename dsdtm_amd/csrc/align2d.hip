@@ -156,11 +156,190 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The product kernel: FOUR features per wavefront — one per 16-lane DPP row, four pixels of a patch row per lane.
+// One wavefront per feature (rounds 1-3, the template above, now the DSDTM_A2D_TREE diagnostic only) is bound by the
+// latency of an iteration (footprint loads -> 64 sequential float subtractions -> update) times the waves a compute
+// unit holds: a wave carried one feature through that chain with 16 byte gathers per pixel row. Here a wave carries four
+// features through the same chain at once (the DPP row reductions of H and the twelve sequential Jres chains are
+// row-local), a lane fetches the two footprint rows of its four pixels with two 8-byte loads per iteration instead of
+// sixteen byte loads, and a launch needs a quarter of the waves. Per pixel the arithmetic is the old kernel's, expression
+// for expression; the Jres sums run in the reference's raster order (:389-391) as before: pixels and flags stay
+// bit-identical to the CPU restatement.
+typedef uint32_t __attribute__((aligned(1))) U32u;
+typedef uint16_t __attribute__((aligned(1))) U16a;
+struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row (integers below 2^22 in float: exact in any order)
+__device__ __forceinline__ float row_sum_f32(float v) {
+    v += dpp_f32<0x128, 0xf>(v);  // row_ror:8
+    v += dpp_f32<0x124, 0xf>(v);  // row_ror:4
+    v += dpp_f32<0x122, 0xf>(v);  // row_ror:2
+    v += dpp_f32<0x121, 0xf>(v);  // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float lane_bcast_f32(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
+__global__ __launch_bounds__(256) void align2d_rows_kernel(const A2DKernelArgs a) {
+    // no FMA contraction: the reference build has none (CMakeLists.txt:5-8, SSE only) and the
+    // 0.03^2 convergence threshold (:400) is compared on float values
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float s_prod[16][192];      // per feature: 3 x 64 products (Jres chains)
+    __shared__ LevelGeom s_lv[DSDTM_MAX_LEVELS];
+    if (threadIdx.x < DSDTM_MAX_LEVELS) s_lv[threadIdx.x] = a.lv[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int row = lane >> 4, l = lane & 15;                           // feature of the wave, lane of the feature
+    const int slot = (threadIdx.x >> 6) * 4 + row;                      // feature of the workgroup
+    const int f = blockIdx.x * 16 + slot;
+    float* const prod = s_prod[slot];
+    const bool exists = f < a.m;
+    const int lvl = exists ? a.level[f] : -1;
+    const int fr = (exists && a.frame) ? a.frame[f] : 0;
+    const bool valid = exists && !(lvl < 0 || lvl >= a.levels || fr < 0 || (a.frame && fr >= a.n_frames));
+    if (exists && !valid && l == 0) a.converged[f] = 0;                 // invalid level / frame: report "not converged"
+    const LevelGeom lg = s_lv[valid ? lvl : 0];
+    const uint8_t* __restrict__ img = a.cur_pyr + (size_t)fr * a.pyr_pitch + lg.off;
+    const int img_size = lg.stride * lg.h;
+
+    // this lane's four pixels: q = 4 l .. 4 l + 3 of the 8x8 patch in raster order -> row r, columns c0 .. c0 + 3
+    const int r = l >> 1, c0 = (l & 1) * 4;
+    float dx[4], dy[4], ref[4];
+    {
+        // bordered-patch rows r, r + 1, r + 2 around the pixels (10x10, the patch sits at (1, 1)):
+        // gradients :336-337, 0.5 * (it[1] - it[-1]) is exact in float
+        uint32_t up = 0, dn = 0, mid_lo = 0, mid_hi = 0, pw = 0;
+        if (valid) {
+            const uint8_t* __restrict__ bp = a.patch_border + (size_t)f * 100 + r * 10 + c0;
+            up = *(const U32u*)(bp + 1);                                // row r,     columns c0 + 1 .. c0 + 4
+            mid_lo = *(const U32u*)(bp + 10);                           // row r + 1, columns c0 .. c0 + 3
+            mid_hi = *(const U16a*)(bp + 14);                           //            columns c0 + 4, c0 + 5
+            dn = *(const U32u*)(bp + 21);                               // row r + 2, columns c0 + 1 .. c0 + 4
+            pw = *(const U32u*)(a.patch + (size_t)f * 64 + 4 * l);
+        }
+        const unsigned long long mid = (unsigned long long)mid_lo | ((unsigned long long)mid_hi << 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int right = (int)((mid >> (8 * (i + 2))) & 0xff), left = (int)((mid >> (8 * i)) & 0xff);
+            dx[i] = 0.5f * (float)(right - left);
+            dy[i] = 0.5f * (float)((int)((dn >> (8 * i)) & 0xff) - (int)((up >> (8 * i)) & 0xff));
+            ref[i] = (float)((pw >> (8 * i)) & 0xff);
+        }
+    }
+    // H = sum J J^T, J = [dx, dy, 1]  (:341) over the feature's 64 pixels: 4 per lane, then the row
+    float s00 = 0.0f, s01 = 0.0f, s02 = 0.0f, s11 = 0.0f, s12 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s00 += dx[i] * dx[i]; s01 += dx[i] * dy[i]; s02 += dx[i]; s11 += dy[i] * dy[i]; s12 += dy[i]; }
+    const float h00 = row_sum_f32(s00), h01 = row_sum_f32(s01), h02 = row_sum_f32(s02), h11 = row_sum_f32(s11), h12 = row_sum_f32(s12);
+    const float h22 = 64.0f;
+    // Matrix3f::inverse() (:345): Eigen cofactor formula, no conditioning check (quirk A2)
+    const float m00 = h00, m01 = h01, m02 = h02, m10 = h01, m11 = h11, m12 = h12, m20 = h02, m21 = h12, m22 = h22;
+    const float c00 = m11 * m22 - m12 * m21;
+    const float c10 = m21 * m02 - m22 * m01;   // cofactor_3x3<1,0>
+    const float c20 = m01 * m12 - m02 * m11;   // cofactor_3x3<2,0>
+    const float det = c00 * m00 + (c10 * m10 + c20 * m20);
+    const float invdet = 1.0f / det;
+    const float i00 = c00 * invdet, i01 = c10 * invdet, i02 = c20 * invdet;
+    const float i10 = (m12 * m20 - m10 * m22) * invdet;   // cofactor<0,1>
+    const float i11 = (m22 * m00 - m20 * m02) * invdet;   // cofactor<1,1>
+    const float i12 = (m02 * m10 - m00 * m12) * invdet;   // cofactor<2,1>
+    const float i20 = (m10 * m21 - m11 * m20) * invdet;   // cofactor<0,2>
+    const float i21 = (m20 * m01 - m21 * m00) * invdet;   // cofactor<1,2>
+    const float i22 = (m00 * m11 - m01 * m10) * invdet;   // cofactor<2,2>
+
+    // (px_level0: the caller's pixel is in level-0 units; the division by 2^level is exact in double, :150)
+    const double lscale = (a.px_level0 && valid) ? (double)(1 << lvl) : 1.0;
+    float u = valid ? (float)(a.px_xy[2 * (size_t)f] / lscale) : 0.0f;
+    float v = valid ? (float)(a.px_xy[2 * (size_t)f + 1] / lscale) : 0.0f;
+    float mean_diff = 0.0f;
+    const float min_update_squared = (float)(0.03 * 0.03);
+    bool converged = false;
+    bool active = valid;                                               // row-uniform: the four features of a wave end on their own
+    for (int it = 0; it < a.max_iters; ++it) {
+        if (active && (u != u || v != v)) active = false;                                        // :368 isnan
+        const float fu = floorf(u), fv = floorf(v);
+        // compare as floats: the int conversion of a huge float would be undefined
+        if (active && (fu < 4.0f || fv < 4.0f || fu > (float)(lg.w - 4) || fv > (float)(lg.h - 4))) active = false;   // :367-368
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f, t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        if (active) {
+            const int u_r = (int)fu, v_r = (int)fv;
+            const float sx = u - (float)u_r, sy = v - (float)v_r;
+            const float wTL = (float)((1.0 - (double)sx) * (1.0 - (double)sy));  // :373 (double arithmetic)
+            const float wTR = sx * (1.0f - sy);                                   // :374 (float arithmetic)
+            const float wBL = (float)((1.0 - (double)sx) * (double)sy);          // :375
+            const float wBR = sx * sy;                                            // :376
+            const int o = (v_r + r - 4) * lg.stride + (u_r + c0 - 4);            // :383, this lane's first pixel
+            // the two footprint rows of the four pixels: bytes o .. o + 4 and o + stride .. o + stride + 4
+            unsigned long long b0, b1;
+            if (o + lg.stride + 8 <= img_size) {
+                const U64u w0 = *(const U64u*)(img + o), w1 = *(const U64u*)(img + o + lg.stride);
+                b0 = (unsigned long long)w0.lo | ((unsigned long long)w0.hi << 32);
+                b1 = (unsigned long long)w1.lo | ((unsigned long long)w1.hi << 32);
+            } else {
+                // quirk A3: offsets past the level image read as 0 (undefined in the reference)
+                b0 = b1 = 0ull;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    if (o + k < img_size) b0 |= (unsigned long long)img[o + k] << (8 * k);
+                    if (o + lg.stride + k < img_size) b1 |= (unsigned long long)img[o + lg.stride + k] << (8 * k);
+                }
+            }
+            float res[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p00 = (float)((b0 >> (8 * i)) & 0xff), p01 = (float)((b0 >> (8 * i + 8)) & 0xff);
+                const float p10 = (float)((b1 >> (8 * i)) & 0xff), p11 = (float)((b1 >> (8 * i + 8)) & 0xff);
+                const float search = wTL * p00 + wTR * p01 + wBL * p10 + wBR * p11;  // :386
+                res[i] = search - ref[i] + mean_diff;                                // :387
+            }
+            p0 = res[0] * dx[0]; p1 = res[1] * dx[1]; p2 = res[2] * dx[2]; p3 = res[3] * dx[3];
+            q0 = res[0] * dy[0]; q1 = res[1] * dy[1]; q2 = res[2] * dy[2]; q3 = res[3] * dy[3];
+            t0 = res[0]; t1 = res[1]; t2 = res[2]; t3 = res[3];
+        }
+        // Jres[k] -= res * J[k] over the pixels q = 0..63 in order, starting from 0 (:389-391): lane k < 3 of the feature's
+        // row folds chain k over the feature's 64 products (this lane's are q = 4 l .. 4 l + 3)
+        ((float4*)prod)[l] = make_float4(p0, p1, p2, p3);
+        ((float4*)(prod + 64))[l] = make_float4(q0, q1, q2, q3);
+        ((float4*)(prod + 128))[l] = make_float4(t0, t1, t2, t3);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float acc = 0.0f;
+        if (l < 3 && active) {
+            const float4* src = (const float4*)(prod + 64 * l);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 w = src[q];
+                acc = acc - w.x; acc = acc - w.y; acc = acc - w.z; acc = acc - w.w;
+            }
+        }
+        const float j0 = lane_bcast_f32(acc, row * 16), j1 = lane_bcast_f32(acc, row * 16 + 1), j2 = lane_bcast_f32(acc, row * 16 + 2);
+        __builtin_amdgcn_wave_barrier();      // the next iteration's stores come after every lane's loads
+        if (active) {
+            const float up0 = (i00 * j0 + i01 * j1) + i02 * j2;                  // :395
+            const float up1 = (i10 * j0 + i11 * j1) + i12 * j2;
+            const float up2 = (i20 * j0 + i21 * j1) + i22 * j2;
+            u += up0;
+            v += up1;
+            mean_diff += up2;
+            if (up0 * up0 + up1 * up1 < min_update_squared) { converged = true; active = false; }   // :400
+        }
+    }
+    if (valid && l == 0) {
+        a.px_xy[2 * (size_t)f] = (double)u * lscale;                         // :414 always written back (:154-156 back to level 0)
+        a.px_xy[2 * (size_t)f + 1] = (double)v * lscale;
+        a.converged[f] = converged ? 1 : 0;
+    }
+}
+
 hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream) {
     if (args.m <= 0) return hipSuccess;
     // DSDTM_A2D_TREE=1 (diagnostic, cost comparison only): DPP tree sums instead of the reference's order
     if (options().a2d_tree) hipLaunchKernelGGL(align2d_kernel<true>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL(align2d_kernel<false>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(align2d_rows_kernel, dim3((unsigned)((args.m + 15) / 16)), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -1554,6 +1554,7 @@ extern "C" int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t
         set_err(ctx, "bad argument"); return DSDTM_ERR_INVALID;
     }
     if (max_search_level < 0 || max_search_level >= levels) { set_err(ctx, "max_search_level outside the pyramid"); return DSDTM_ERR_INVALID; }
+    if (((size_t)scratch) & 15) { set_err(ctx, "scratch must be 16-byte aligned (the warped patches are written as whole dwords)"); return DSDTM_ERR_INVALID; }
     if (m == 0) return DSDTM_OK;
     const size_t M = (size_t)m;
     WarpKernelArgs a;
