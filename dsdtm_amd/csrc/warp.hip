@@ -123,7 +123,9 @@ struct WarpCand {
     float Ai0, Ai1, Ai2, Ai3;
     float refx, refy;
     int int_scale;
-    int meta;              // ref level | keyframe << 8, or -1: rejected (zero patches)
+    int ok;                // 0: rejected (zero patches)
+    const uint8_t* img;    // the reference level of the candidate's keyframe (phase 2 chases no pointer and indexes no table)
+    int w, h, stride, pad;
 };
 
 // G candidates per 128-thread group (2 for one frame's search, 64 for batches), two phases:
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
     if (tid < ng) {
         const int c = c0 + tid;
         WarpCand wc;
-        wc.Ai0 = wc.Ai1 = wc.Ai2 = wc.Ai3 = wc.refx = wc.refy = 0.0f; wc.int_scale = 0; wc.meta = -1;
+        wc.Ai0 = wc.Ai1 = wc.Ai2 = wc.Ai3 = wc.refx = wc.refy = 0.0f; wc.int_scale = 0; wc.ok = 0;
+        wc.img = nullptr; wc.w = wc.h = wc.stride = wc.pad = 0;
         const int k = a.cand_kf[c];
         const int tLevel = a.ref_level[c];
         const int fr = a.cand_frame ? a.cand_frame[c] : 0;
@@ -207,21 +210,37 @@ __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
             wc.Ai2 = (float)(-A10 * invdet); wc.Ai3 = (float)(A00 * invdet);
             wc.refx = rx / (float)(1 << tLevel); wc.refy = ry / (float)(1 << tLevel);          // :215-216
             wc.int_scale = 1 / (1 << sl);                                                      // :231 quirk W1
-            wc.meta = tLevel | (k << 8);
+            wc.ok = 1;
+            const LevelGeom lg = a.lv[tLevel];
+            wc.img = (a.kf_ptrs ? a.kf_ptrs[k] : a.kf_pyr + (size_t)k * a.kf_pitch) + lg.off;
+            wc.w = lg.w; wc.h = lg.h; wc.stride = lg.stride;
         }
         s_c[tid] = wc;
     }
     __syncthreads();
     // ---- WarpAffine, per-sample part (:217-259) + GetPatchNoBoarder (:261-275) ----
+    // A sample is two dependent steps — where to read (float arithmetic on the candidate's record), then the bilinear
+    // blend of what was read — and every candidate's patch lies somewhere else in its keyframe: each read is an L2 / HBM
+    // round trip. UNROLL samples per thread are prepared and their loads issued before the first blend, so a thread has
+    // 2 x UNROLL loads in flight instead of 2 (64 candidates per group: 50 dependent round trips per thread -> 10).
+    constexpr int UNROLL = 5;
+    typedef const __attribute__((address_space(1))) uint8_t* GlobalU8;
+    typedef const __attribute__((address_space(1))) U16u* GlobalU16;
+    struct Sample { float w00, w01, w10, w11; uint32_t r0, r1; int mode; };   // mode 0: outside (0), 1: two 16-bit rows, 2: last row
     const int n_samples = ng * 100;
-    for (int s = tid; s < n_samples; s += 128) {
-        const int cl = s / 100, j = s - cl * 100;
-        const WarpCand wc = s_c[cl];
-        uint8_t outv = 0;
-        if (wc.meta >= 0) {
-            const int tLevel = wc.meta & 0xff, k = wc.meta >> 8;
-            const LevelGeom lg = a.lv[tLevel];
-            const uint8_t* __restrict__ img = (a.kf_ptrs ? a.kf_ptrs[k] : a.kf_pyr + (size_t)k * a.kf_pitch) + lg.off;
+    for (int s0 = tid; s0 < n_samples; s0 += 128 * UNROLL) {
+        Sample sm[UNROLL];
+#pragma unroll
+        for (int uu = 0; uu < UNROLL; ++uu) {
+            const int s = s0 + uu * 128;
+            Sample& q = sm[uu];
+            q.mode = 0; q.r0 = q.r1 = 0u; q.w00 = q.w01 = q.w10 = q.w11 = 0.0f;
+            if (s >= n_samples) continue;
+            const int cl = s / 100, j = s - cl * 100;
+            const WarpCand wc = s_c[cl];
+            if (!wc.ok) continue;
+            struct { int w, h, stride; } lg = {wc.w, wc.h, wc.stride};
+            GlobalU8 img = (GlobalU8)wc.img;
             const int ix = (j % 10) - 5, iy = (j / 10) - 5;
             const float gx = (wc.Ai0 * (float)ix + wc.Ai1 * (float)iy) * (float)wc.int_scale;
             const float gy = (wc.Ai2 * (float)ix + wc.Ai3 * (float)iy) * (float)wc.int_scale;
@@ -230,32 +249,41 @@ __global__ __launch_bounds__(128) void warp_kernel(const WarpKernelArgs a) {
                 const int fx_ = (int)floor((double)wx), fy_ = (int)floor((double)wy);
                 const float sx = wx - (float)fx_, sy = wy - (float)fy_;
                 const float omx = 1.0f - sx, omy = 1.0f - sy;
-                const float w00 = omx * omy;
-                const float w01 = omx * sy;                                                     // :242
-                const float w10 = sx * omy;                                                     // :243
-                const float w11 = 1.0f - w00 - w01 - w10;                                       // :244
+                q.w00 = omx * omy;
+                q.w01 = omx * sy;                                                               // :242
+                q.w10 = sx * omy;                                                               // :243
+                q.w11 = 1.0f - q.w00 - q.w01 - q.w10;                                           // :244
                 const int sz = lg.stride * lg.h, o = lg.stride * fy_ + fx_;
-                float p00, p01, p10, p11;
                 if (o + lg.stride + 1 < sz) {
                     // both rows inside the level (everywhere but its last row): the two horizontal neighbours of a row in ONE
-                    // 16-bit load (unaligned global loads are native on gfx950) — the sampling loop is bound by the number of
-                    // per-lane gathers, not by bytes
-                    const uint16_t r0 = *(const U16u*)(img + o), r1 = *(const U16u*)(img + o + lg.stride);
-                    p00 = (float)(r0 & 0xff); p10 = (float)(r0 >> 8);
-                    p01 = (float)(r1 & 0xff); p11 = (float)(r1 >> 8);
+                    // 16-bit load (unaligned global loads are native on gfx950)
+                    q.mode = 1;
+                    q.r0 = *(GlobalU16)(img + o);
+                    q.r1 = *(GlobalU16)(img + o + lg.stride);
                 } else {
-                    p00 = (float)img[o];
-                    p01 = (o + lg.stride < sz) ? (float)img[o + lg.stride] : 0.0f;
-                    p10 = (o + 1 < sz) ? (float)img[o + 1] : 0.0f;
-                    p11 = 0.0f;                                                                 // o + stride + 1 >= sz here
+                    q.mode = 2;                                                                 // o + stride + 1 >= sz: p11 = 0
+                    q.r0 = (uint32_t)img[o] | ((o + 1 < sz) ? (uint32_t)img[o + 1] << 8 : 0u);
+                    q.r1 = (o + lg.stride < sz) ? (uint32_t)img[o + lg.stride] : 0u;
                 }
-                const float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;                // :254
-                outv = (uint8_t)(int)val;                                                       // truncation
             }
         }
-        s_pb[s] = outv;
-        const int r = j / 10, cc = j % 10;
-        if (r >= 1 && r <= 8 && cc >= 1 && cc <= 8) s_pp[cl * 64 + (r - 1) * 8 + (cc - 1)] = outv;
+#pragma unroll
+        for (int uu = 0; uu < UNROLL; ++uu) {
+            const int s = s0 + uu * 128;
+            if (s >= n_samples) continue;
+            const Sample& q = sm[uu];
+            const int cl = s / 100, j = s - cl * 100;
+            uint8_t outv = 0;
+            if (q.mode) {
+                const float p00 = (float)(q.r0 & 0xff), p10 = (float)((q.r0 >> 8) & 0xff);
+                const float p01 = (float)(q.r1 & 0xff), p11 = (float)((q.r1 >> 8) & 0xff);
+                const float val = q.w00 * p00 + q.w01 * p01 + q.w10 * p10 + q.w11 * p11;        // :254
+                outv = (uint8_t)(int)val;                                                       // truncation
+            }
+            s_pb[s] = outv;
+            const int r = j / 10, cc = j % 10;
+            if (r >= 1 && r <= 8 && cc >= 1 && cc <= 8) s_pp[cl * 64 + (r - 1) * 8 + (cc - 1)] = outv;
+        }
     }
     __syncthreads();
     // (c0 * 100 and c0 * 64 are multiples of 4 for every G used — 2 and 64 — and the scratch sections are 256-byte aligned)
@@ -274,8 +302,16 @@ hipError_t warp_launch(const WarpKernelArgs& args, hipStream_t stream) {
     // few candidates (one frame's search: ~800): groups of 2 — the call is bound by the latency of one candidate's FP64
     // chain, so the sampling loop behind it is kept to two rounds and the groups spread over every compute unit;
     // batches: groups of 64 (one full wave of phase-1 lanes)
-    if (args.m < 8192) hipLaunchKernelGGL(warp_kernel<2>, dim3((unsigned)((args.m + 1) / 2)), dim3(128), 0, stream, args);
-    else hipLaunchKernelGGL(warp_kernel<64>, dim3((unsigned)((args.m + 63) / 64)), dim3(128), 0, stream, args);
+    const int g = options().warp_group ? options().warp_group : (args.m < 8192 ? 2 : 16);
+    const dim3 grid((unsigned)((args.m + g - 1) / g));
+    switch (g) {
+        case 2: hipLaunchKernelGGL(warp_kernel<2>, grid, dim3(128), 0, stream, args); break;
+        case 8: hipLaunchKernelGGL(warp_kernel<8>, grid, dim3(128), 0, stream, args); break;
+        case 16: hipLaunchKernelGGL(warp_kernel<16>, grid, dim3(128), 0, stream, args); break;
+        case 32: hipLaunchKernelGGL(warp_kernel<32>, grid, dim3(128), 0, stream, args); break;
+        case 64: hipLaunchKernelGGL(warp_kernel<64>, grid, dim3(128), 0, stream, args); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
