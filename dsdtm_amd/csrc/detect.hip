@@ -253,6 +253,147 @@ __global__ __launch_bounds__(256) void fast_select_kernel(const DetectArgs a) {
     }
 }
 
+// ---- batches: one thread per dword column x SEL_ROWS rows, four survivors scored per round ---------------------------
+// fast_select_kernel<4> above is bound by LATENCY per wave, not by bytes or instructions: a wave reads its score dwords,
+// then (dependent) the neighbours of the non-zero ones, then scores its ~2.5 survivors one after the other, each a round
+// of loads -> wave sums -> atomic; 1.5 M waves of ~3.8 us for 256 frames (0.71 ms). Here a thread owns 4 x SEL_ROWS pixels:
+// the SEL_ROWS + 2 score rows it needs are fetched up front as 8-byte words (no data-dependent second round: the 3x3
+// non-maximum test runs on registers), and the survivors of a wave's 1024 pixels are scored FOUR per round — one per
+// 16-lane DPP row, four pixels of the 8x8 Shi-Tomasi box per lane, row-local integer sums. Same decisions, same keys.
+constexpr int SEL_ROWS = 4;
+typedef uint32_t __attribute__((aligned(1))) SelU32;
+struct __attribute__((packed, aligned(1))) SelU64 { uint32_t lo, hi; };
+__device__ __forceinline__ unsigned long long sel_load64(const uint8_t* p) {
+    const SelU64 w = *(const SelU64*)p;
+    return (unsigned long long)w.lo | ((unsigned long long)w.hi << 32);
+}
+__device__ __forceinline__ int row_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);   // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);   // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);   // row_ror:1
+    return v;
+}
+
+__global__ __launch_bounds__(256) void fast_select_rows_kernel(const DetectArgs a) {
+    const int level = blockIdx.y, frame = blockIdx.z;
+    const LevelGeom lg = a.lv[level];
+    const int lane = threadIdx.x & 63;
+    const int rowdw = lg.w >> 2;                                          // the launcher guarantees w, stride, off multiples of 4
+    const int chunks = (lg.h + SEL_ROWS - 1) / SEL_ROWS;
+    const int task = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)(blockIdx.x * blockDim.x) >= rowdw * chunks) return;        // whole block outside the level (block-uniform)
+    const bool live = task < rowdw * chunks;
+    const int chunk = live ? task / rowdw : 0, q = live ? task - chunk * rowdw : 0;
+    const int y0 = chunk * SEL_ROWS;
+    const uint8_t* __restrict__ smap = a.score + (size_t)frame * a.pyr_pitch + lg.off;
+    const uint8_t* __restrict__ img = a.pyr + (size_t)frame * a.pyr_pitch + lg.off;
+    const int cells = a.grid_cols * a.grid_rows;
+    // score rows y0 - 1 .. y0 + SEL_ROWS, bytes 4 q - 1 .. 4 q + 4 of each in bits 0..47. Candidate rows are 3 .. h - 4, so
+    // only rows 2 .. h - 3 are ever needed: rows outside read as 0 (and the 8-byte fetch of a row never leaves the level)
+    unsigned long long rw[SEL_ROWS + 2];
+#pragma unroll
+    for (int k = 0; k < SEL_ROWS + 2; ++k) {
+        const int y = y0 - 1 + k;
+        rw[k] = 0ull;
+        if (live && y >= 2 && y <= lg.h - 3) {
+            const uint8_t* rp = smap + (size_t)y * lg.stride + 4 * q;
+            rw[k] = q > 0 ? sel_load64(rp - 1) : (sel_load64(rp) << 8);
+        }
+    }
+    // The 3x3 non-maximum test (nonmax_3x3.cpp:47-106: suppressed iff a neighbouring corner scores >=, ties suppress both) on
+    // packed u16 pairs, two pixels per instruction: of every fetched row the byte pairs (0,1) (1,2) (2,3) (3,4) (4,5) by one
+    // v_perm each; pixels (0,1) of a row are centred on pair (1,2), pixels (2,3) on pair (3,4). Per row in its three roles —
+    // above / below: the three-wide maxima T, T2; centre: the two-sided maxima H, H2 — then neighbours = max(T_up, T_down, H_mid)
+    // and "survives" = saturating (centre - neighbours) != 0, which also says centre > 0. (~120 instead of ~400 instructions per
+    // thread: this pass had become bound by VALU issue once its latency was out of the way.)
+    fs_u16x2 T[SEL_ROWS + 2], T2[SEL_ROWS + 2], Hm[SEL_ROWS + 2], Hm2[SEL_ROWS + 2], C1[SEL_ROWS + 2], C2[SEL_ROWS + 2];
+#pragma unroll
+    for (int k = 0; k < SEL_ROWS + 2; ++k) {
+        const uint32_t lo = (uint32_t)rw[k], hi = (uint32_t)(rw[k] >> 32);
+        const fs_u16x2 p01 = __builtin_bit_cast(fs_u16x2, __builtin_amdgcn_perm(hi, lo, 0x0c010c00u));
+        const fs_u16x2 q12 = __builtin_bit_cast(fs_u16x2, __builtin_amdgcn_perm(hi, lo, 0x0c020c01u));
+        const fs_u16x2 p23 = __builtin_bit_cast(fs_u16x2, __builtin_amdgcn_perm(hi, lo, 0x0c030c02u));
+        const fs_u16x2 q34 = __builtin_bit_cast(fs_u16x2, __builtin_amdgcn_perm(hi, lo, 0x0c040c03u));
+        const fs_u16x2 p45 = __builtin_bit_cast(fs_u16x2, __builtin_amdgcn_perm(hi, lo, 0x0c050c04u));
+        T[k] = fs_max(fs_max(p01, q12), p23); T2[k] = fs_max(fs_max(p23, q34), p45);
+        Hm[k] = fs_max(p01, p23); Hm2[k] = fs_max(p23, p45);
+        C1[k] = q12; C2[k] = q34;
+    }
+    unsigned colmask = 0;                                                 // valid columns: 3 <= x < w - 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (4 * q + i >= 3 && 4 * q + i < lg.w - 3) colmask |= 1u << i;
+    unsigned cand = 0;                                                    // bit 4 j + i: pixel (4 q + i, y0 + j) survives the 3x3 test
+#pragma unroll
+    for (int j = 0; j < SEL_ROWS; ++j) {
+        const int y = y0 + j;
+        const fs_u16x2 nA = fs_max(fs_max(T[j], T[j + 2]), Hm[j + 1]), nB = fs_max(fs_max(T2[j], T2[j + 2]), Hm2[j + 1]);
+        const uint32_t dA = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(C1[j + 1], nA));
+        const uint32_t dB = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(C2[j + 1], nB));
+        unsigned bits = ((dA & 0xffffu) ? 1u : 0u) | ((dA >> 16) ? 2u : 0u) | ((dB & 0xffffu) ? 4u : 0u) | ((dB >> 16) ? 8u : 0u);
+        bits &= (y >= 3 && y < lg.h - 3) ? colmask : 0u;
+        cand |= bits << (4 * j);
+    }
+    if (a.keep) {                                                         // diagnostic map of the survivors (dsdtm_debug_fast10)
+        for (unsigned m = cand; m; m &= m - 1) {
+            const int b = __ffs((int)m) - 1;
+            a.keep[lg.off + (size_t)(y0 + (b >> 2)) * lg.stride + 4 * q + (b & 3)] = 1;
+        }
+    }
+    // the survivors of this wave's pixels, four per round: DPP row g of the wave scores the g-th pending lane's lowest one
+    const int row = lane >> 4, l = lane & 15;
+    const int br = l >> 1, bc = (l & 1) * 4;                              // this lane's four pixels of an 8x8 box: row br, columns bc .. bc + 3
+    for (;;) {
+        unsigned long long pend = __ballot(cand != 0u);
+        if (!pend) break;
+        int src[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            src[g] = pend ? __ffsll((long long)pend) - 1 : -1;
+            pend &= pend - 1;                                             // (0 & anything stays 0)
+        }
+        const int my = row == 0 ? src[0] : row == 1 ? src[1] : row == 2 ? src[2] : src[3];
+        const int b = cand ? __ffs((int)cand) - 1 : 0;
+        const int ox = 4 * q + (b & 3), oy = y0 + (b >> 2);               // this lane's own lowest survivor
+        const int cx = __builtin_amdgcn_ds_bpermute((my < 0 ? lane : my) << 2, ox);
+        const int cy = __builtin_amdgcn_ds_bpermute((my < 0 ? lane : my) << 2, oy);
+        if (lane == src[0] || lane == src[1] || lane == src[2] || lane == src[3]) cand &= cand - 1u;
+        if (my < 0) continue;
+        const int scale = 1 << level;
+        const int k = ((cy * scale) / a.cell_size) * a.grid_cols + (cx * scale) / a.cell_size;       // :97-98
+        if (k < 0 || k >= cells || (a.occupied && a.occupied[(size_t)frame * cells + k])) continue;  // :100 (row-uniform)
+        // Feature_detector::shiTomasiScore (:157-198) by the 16 lanes of the row
+        float scf = 0.0f;
+        {
+#pragma clang fp contract(off)
+            const int x_min = cx - 4, x_max = cx + 4, y_min = cy - 4, y_max = cy + 4;
+            if (!(x_min < 1 || x_max >= lg.w - 1 || y_min < 1 || y_max >= lg.h - 1)) {                  // :173
+                const uint8_t* __restrict__ p = img + (size_t)lg.stride * (y_min + br) + x_min + bc;
+                const unsigned long long m = sel_load64(p - 1);           // columns bc - 1 .. bc + 4 (+ 2 spare bytes, inside the level)
+                const uint32_t u4 = *(const SelU32*)(p - lg.stride), d4 = *(const SelU32*)(p + lg.stride);
+                int sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int dx = (int)((m >> (8 * (i + 2))) & 0xff) - (int)((m >> (8 * i)) & 0xff);
+                    const int dy = (int)((d4 >> (8 * i)) & 0xff) - (int)((u4 >> (8 * i)) & 0xff);
+                    sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+                }
+                sxx = row_sum_i32(sxx); syy = row_sum_i32(syy); sxy = row_sum_i32(sxy);
+                const float dXX = (float)sxx / 128.0f, dYY = (float)syy / 128.0f, dXY = (float)sxy / 128.0f;   // / (2.0 * box_area), exact
+                const float tr = dXX + dYY;
+                const float disc = tr * tr - 4 * (dXX * dYY - dXY * dXY);
+                scf = 0.5f * (tr - sqrtf(disc));
+            }
+        }
+        if (l == 0 && scf > a.detection_threshold) {                                                       // :104 vs the initial score (:74)
+            // max score wins; among equal scores the first in (level, row, column) order, as the sequential loop's strict '>' leaves it
+            const unsigned order = ((unsigned)level << 28) | ((unsigned)cy << 14) | (unsigned)cx;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(scf) << 32) | (unsigned long long)(0xffffffffu - order);
+            atomicMax(a.cell_key + (size_t)frame * cells + k, key);
+        }
+    }
+}
+
 // keys -> the four per-cell arrays the reference's `corners` vector holds (batch entry; the single-frame entries decode on the host)
 __global__ __launch_bounds__(256) void detect_decode_kernel(const DetectArgs a) {
     const size_t n = (size_t)a.n_frames * a.grid_cols * a.grid_rows;
@@ -283,11 +424,18 @@ hipError_t detect_launch(const DetectArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(fast_score_kernel, dim3((unsigned)((a.lv[0].w + 255) / 256), (unsigned)a.lv[0].h, (unsigned)(a.levels * a.n_frames)),
                            dim3(256), 0, stream, a, pixel_mask);
     const int px = a.n_frames >= 8 ? 4 : 1;
-    int sel_tasks = 0;
-    for (int l = 0; l < a.levels; ++l) { const int t = ((a.lv[l].w + px - 1) / px) * a.lv[l].h; sel_tasks = t > sel_tasks ? t : sel_tasks; }
-    const dim3 sel_grid((unsigned)((sel_tasks + 255) / 256), (unsigned)a.levels, (unsigned)a.n_frames);
-    if (px == 4) hipLaunchKernelGGL(fast_select_kernel<4>, sel_grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(fast_select_kernel<1>, sel_grid, dim3(256), 0, stream, a);
+    if (px == 4 && pixel_mask == 0) {
+        // batches whose levels are all whole dwords wide: 4 x SEL_ROWS pixels per thread, four survivors scored per round
+        int sel_tasks = 0;
+        for (int l = 0; l < a.levels; ++l) { const int t = (a.lv[l].w >> 2) * ((a.lv[l].h + SEL_ROWS - 1) / SEL_ROWS); sel_tasks = t > sel_tasks ? t : sel_tasks; }
+        hipLaunchKernelGGL(fast_select_rows_kernel, dim3((unsigned)((sel_tasks + 255) / 256), (unsigned)a.levels, (unsigned)a.n_frames), dim3(256), 0, stream, a);
+    } else {
+        int sel_tasks = 0;
+        for (int l = 0; l < a.levels; ++l) { const int t = ((a.lv[l].w + px - 1) / px) * a.lv[l].h; sel_tasks = t > sel_tasks ? t : sel_tasks; }
+        const dim3 sel_grid((unsigned)((sel_tasks + 255) / 256), (unsigned)a.levels, (unsigned)a.n_frames);
+        if (px == 4) hipLaunchKernelGGL(fast_select_kernel<4>, sel_grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(fast_select_kernel<1>, sel_grid, dim3(256), 0, stream, a);
+    }
     if (a.cell_score) {
         const size_t n = (size_t)a.n_frames * a.grid_cols * a.grid_rows;
         hipLaunchKernelGGL(detect_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);

@@ -139,11 +139,13 @@ def test_detect_honours_the_moving_object_mask(gpu_ctx):
     assert all(200 - 26 <= x < 500 + 26 and 100 - 26 <= y < 300 + 26 for x, y in extra) and len(extra) < 20
 
 
-@pytest.mark.parametrize("size,levels,n", [((640, 480), 5, 6), ((752, 480), 4, 3)])
+@pytest.mark.parametrize("size,levels,n", [((640, 480), 5, 6), ((752, 480), 4, 3), ((640, 480), 5, 9), ((320, 240), 3, 12), ((752, 480), 3, 8)])
 def test_batch_entry_equals_the_oracle_frame_by_frame(gpu_ctx, oracle, size, levels, n):
     """dsdtm_detect_cells_batch_device: n packed device pyramids in one call (strip kernel where the level rows are whole
     dwords, one thread per pixel where they are not: 752 -> 94 -> 47 columns), every frame with its own occupancy
-    grid, against the oracle's cells frame by frame."""
+    grid, against the oracle's cells frame by frame. From 8 frames the select pass is the batch kernel (4 x 4 pixels per
+    thread, four survivors scored per round) when every level is whole dwords wide: 9 x 640x480x5, 12 x 320x240x3 and
+    8 x 752x480x3 (the reference's test1.png among them) run it; 6 and 3 frames run the one-pixel-per-thread kernel."""
     import torch
     from dsdtm_amd.feature_detection import Feature_detector
     from dsdtm_amd.frame import Config
@@ -153,6 +155,7 @@ def test_batch_entry_equals_the_oracle_frame_by_frame(gpu_ctx, oracle, size, lev
     imgs = [np.clip(np.rint(synth.make_texture(h, w, 300 + i)), 0, 255).astype(np.uint8) for i in range(n)]
     if size == (752, 480):
         imgs[0] = np.load(H.golden_path("fast_reference.npz"))["test1"]
+        imgs[-1] = np.ascontiguousarray(imgs[0][::-1, ::-1])
     pyrs = [synth.build_pyramid(im, levels) for im in imgs]
     ws, hs, ss, offs, nbytes = capi.pyramid_layout(w, h, levels)
     pitch = (nbytes + 255) // 256 * 256
