@@ -535,11 +535,11 @@ def tracked_frame_entries(torch, dev, ctx, stream):
     b_feat = 100 + 64 + 16 + 17                      # bordered patch + patch + pixel in/out + level and flag
     alg = M * b_feat + ws[0] * hs[0]                 # + the level image the features sit on, once
     out.append({"workload": f"Feature_Alignment::Align2DGaussNewton: {M} features per call on one {Wa}x{Ha} level, cap 10 iterations "
-                            f"(one wavefront per feature, float sums in the reference's order)",
+                            f"(four features per wavefront, float sums in the reference's order)",
                 "value": M / (ms * 1e-3), "unit": "features/s", "converged_fraction": float(d_cv.float().mean().item()),
                 "roofline": roofline_block("align2d", alg, ms, None, M, b_feat, "feature",
-                                           {"note": "latency-bound: <= 10 dependent iterations of 64 bilinear samples per wavefront; "
-                                                    "the bytes are 197 per feature + the level image once"})})
+                                           {"note": "bound by VALU issue and the latency of <= 10 dependent iterations (64 bilinear samples, then 64 "
+                                                    "sequential float subtractions per feature); the bytes are 197 per feature + the level image once"})})
     del d_pb, d_p, d_px0, d_px, d_lv, d_cv
 
     # ---- pose-only refinement: 4096 frames x 200 features (observations on levels 0..3)
@@ -624,9 +624,9 @@ def tracked_frame_entries(torch, dev, ctx, stream):
                 "value": Mm / (ms * 1e-3), "unit": "candidates/s", "us_per_frame": ms * 1e3 / nfm,
                 "matched_fraction": float(d_cv.float().mean().item()),
                 "roofline": roofline_block("warp", alg, ms, None, Mm, b_cand, "candidate",
-                                           {"note": "two launches (warp prelude: one thread per candidate, FP64 chain in the reference's operation "
-                                                    "order; Align2D: one wavefront per candidate); latency-bound, the bytes are 433 per candidate "
-                                                    "+ the level-0 images once"})})
+                                           {"note": "two launches (warp prelude: lane = candidate for the FP64 chain in the reference's operation "
+                                                    "order, thread = sample for the 10x10 patches; Align2D: four candidates per wavefront); bound by "
+                                                    "dependent FP64 / float chains, the bytes are 433 per candidate + the level-0 images once"})})
     del d_cur, d_kf, d_rp, d_rb, d_pw, d_px0, d_px, d_scr
 
     # ---- detector image work: 256 frames of 640x480x5 levels per call
@@ -661,7 +661,7 @@ def tracked_frame_entries(torch, dev, ctx, stream):
                 "cells_with_a_corner_per_frame": float((d_s > 5.0).sum().item()) / nfr,
                 "roofline": roofline_block("fast_", nfr * b_fr, ms, None, nfr, b_fr, "frame",
                                            {"note": "three launches (score, select, decode); the score pass is bound by its min/max network "
-                                                    "(~95 VALU instructions per pixel), the select pass by the serial Shi-Tomasi scoring of a wave's corners"})})
+                                                    "(~95 VALU instructions per pixel), the select pass by the Shi-Tomasi scoring of the survivors (four per round)"})})
     return out
 
 

@@ -135,7 +135,7 @@ def single_pair_entries(torch, dev, ctx, stream):
             t0 = time.perf_counter()
             co, pxo = oracle_lib.align2d_batch(sc.cur_pyr, pb, p, lv, px0, 10)
             a_cpu = (time.perf_counter() - t0) * 1e3
-            e["align2d_2000_features"] = {"wall_ms": a_wall, "wall_note": "host entry: uploads the 1280x960 pyramid + patches, one wavefront per feature",
+            e["align2d_2000_features"] = {"wall_ms": a_wall, "wall_note": "host entry: uploads the 1280x960 pyramid + patches, four features per wavefront",
                                           "cpu_oracle_ms": a_cpu, "flags_equal": bool(np.array_equal(cg, co)),
                                           "pixels_bit_identical": bool(np.array_equal(pxg, pxo, equal_nan=True))}
         out.append(e)

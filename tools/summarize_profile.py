@@ -92,13 +92,14 @@ for case in sorted(os.listdir(src)):
                 fetch_bytes_gfx950_corrected=2.0 * fetch, write_bytes=write, traffic_over_algorithmic=(2.0 * fetch + write) / alg))
         M, Mm, nfm, nfr = 262144, 64 * 800, 64, 256
         pyr5 = 640 * 480 + 320 * 240 + 160 * 120 + 80 * 60 + 40 * 30
-        entry("align2d_kernel", [("align2d_kernel", M // 4 * 256)], M * 197 + 1280 * 960)
-        entry("warp_kernel+align2d_kernel", [("warp_kernel", Mm * 128), ("align2d_kernel", Mm // 4 * 256)],
+        # (round 4: Align2D runs 16 features per 256-thread group, the warp prelude 16 candidates per 128-thread group in batches)
+        entry("align2d_rows_kernel", [("align2d_rows_kernel", M // 16 * 256)], M * 197 + 1280 * 960)
+        entry("warp_kernel+align2d_rows_kernel", [("warp_kernel", Mm // 16 * 128), ("align2d_rows_kernel", Mm // 16 * 256)],
               Mm * (4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1 + 2 * (100 + 64)) + 2 * nfm * 640 * 480)
         strip_tasks = (640 // 4) * ((480 + 3) // 4)
         sel_tasks = (640 // 4) * 480
-        entry("fast_score_strip_kernel+fast_select_kernel+detect_decode_kernel",
-              [("fast_score_strip_kernel", (strip_tasks + 255) // 256 * 256 * 5 * nfr), ("fast_select_kernel", (sel_tasks + 255) // 256 * 256 * 5 * nfr),
+        entry("fast_score_strip_kernel+fast_select_rows_kernel+detect_decode_kernel",
+              [("fast_score_strip_kernel", (strip_tasks + 255) // 256 * 256 * 5 * nfr), ("fast_select_rows_kernel", (strip_tasks + 255) // 256 * 256 * 5 * nfr),
                ("detect_decode_kernel", (nfr * 26 * 20 + 255) // 256 * 256)], nfr * 3 * pyr5)
         for (k, g), cs in sorted(by_grid.items()):
             print("secondary dispatch", k[:60], g, {c: len(v) for c, v in cs.items()})
