@@ -157,43 +157,77 @@ __global__ __launch_bounds__(256) void align2d_kernel(const A2DKernelArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The product kernel: FOUR features per wavefront — one per 16-lane DPP row, four pixels of a patch row per lane.
-// One wavefront per feature (rounds 1-3, the template above, now the DSDTM_A2D_TREE diagnostic only) is bound by the
-// latency of an iteration (footprint loads -> 64 sequential float subtractions -> update) times the waves a compute
-// unit holds: a wave carried one feature through that chain with 16 byte gathers per pixel row. Here a wave carries four
-// features through the same chain at once (the DPP row reductions of H and the twelve sequential Jres chains are
-// row-local), a lane fetches the two footprint rows of its four pixels with two 8-byte loads per iteration instead of
-// sixteen byte loads, and a launch needs a quarter of the waves. Per pixel the arithmetic is the old kernel's, expression
-// for expression; the Jres sums run in the reference's raster order (:389-391) as before: pixels and flags stay
-// bit-identical to the CPU restatement.
+// The product kernel: SEVERAL features per wavefront — 64 / PPL lanes per feature, PPL pixels of a patch row per lane
+// (PPL = 4: four features per wave, one per 16-lane DPP row; PPL = 8: eight features per wave, lane = patch row).
+// One wavefront per feature (rounds 1-3, the template above, now the DSDTM_A2D_TREE diagnostic only) carried ONE feature
+// through an iteration's chain — footprint loads -> 64 bilinear samples -> 64 sequential float subtractions -> update — with
+// 16 byte gathers per pixel row, and issued the sequential part (which only three lanes need) once per feature. Here a wave
+// carries 4 or 8 features through the same chain at once (the reductions of H are group-local DPP sums, the 12 or 24
+// sequential Jres chains run side by side), a lane fetches the two footprint rows of its pixels with two wide loads, and a
+// launch needs a quarter / an eighth of the waves. Per pixel the arithmetic is the old kernel's, expression for expression;
+// the Jres sums run in the reference's raster order (:389-391) as before: pixels and flags stay bit-identical to the CPU
+// restatement. Four features per wave is the product shape (70 VGPRs, 7 waves per SIMD); eight (DSDTM_A2D_GROUP=8: 114
+// VGPRs, 4 waves per SIMD) was measured 7 % slower — the kernel lives on the waves a compute unit holds.
 typedef uint32_t __attribute__((aligned(1))) U32u;
 typedef uint16_t __attribute__((aligned(1))) U16a;
 struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
+__device__ __forceinline__ unsigned long long load64u(const uint8_t* p) {
+    const U64u w = *(const U64u*)p;
+    return (unsigned long long)w.lo | ((unsigned long long)w.hi << 32);
+}
+// up to 12 bytes of a row: byte k of (lo, hi)
+struct RowBytes {
+    unsigned long long lo;
+    uint32_t hi;
+    __device__ __forceinline__ int at(int k) const { return k < 8 ? (int)((lo >> (8 * k)) & 0xff) : (int)((hi >> (8 * (k - 8))) & 0xff); }
+};
+// N bytes at p (N = 4 or 8: one load; N = 5..6: 4 + 2; N = 9..10: 8 + 2), nothing read beyond p + N (rounded up to even)
+template <int N>
+__device__ __forceinline__ RowBytes load_row_bytes(const uint8_t* p) {
+    RowBytes r;
+    r.hi = 0;
+    if constexpr (N <= 4) r.lo = *(const U32u*)p;
+    else if constexpr (N <= 6) r.lo = (unsigned long long)*(const U32u*)p | ((unsigned long long)*(const U16a*)(p + 4) << 32);
+    else if constexpr (N <= 8) r.lo = load64u(p);
+    else { r.lo = load64u(p); r.hi = *(const U16a*)(p + 8); }
+    return r;
+}
 
-// sum over the 16 lanes of a DPP row, result in every lane of the row (integers below 2^22 in float: exact in any order)
-__device__ __forceinline__ float row_sum_f32(float v) {
-    v += dpp_f32<0x128, 0xf>(v);  // row_ror:8
-    v += dpp_f32<0x124, 0xf>(v);  // row_ror:4
-    v += dpp_f32<0x122, 0xf>(v);  // row_ror:2
-    v += dpp_f32<0x121, 0xf>(v);  // row_ror:1
+// sum over the LPF = 16 or 8 lanes of a feature, result in every one of them (integers below 2^22 in float: exact in any order)
+template <int LPF>
+__device__ __forceinline__ float group_sum_f32(float v) {
+    if constexpr (LPF == 16) {
+        v += dpp_f32<0x128, 0xf>(v);  // row_ror:8
+        v += dpp_f32<0x124, 0xf>(v);  // row_ror:4
+        v += dpp_f32<0x122, 0xf>(v);  // row_ror:2
+        v += dpp_f32<0x121, 0xf>(v);  // row_ror:1
+    } else {
+        v += dpp_f32<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+        v += dpp_f32<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+        v += dpp_f32<0x141, 0xf>(v);  // row_half_mirror: lane i <-> 7 - i of every 8
+    }
     return v;
 }
 __device__ __forceinline__ float lane_bcast_f32(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
 
+template <int PPL>
 __global__ __launch_bounds__(256) void align2d_rows_kernel(const A2DKernelArgs a) {
     // no FMA contraction: the reference build has none (CMakeLists.txt:5-8, SSE only) and the
     // 0.03^2 convergence threshold (:400) is compared on float values
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float s_prod[16][192];      // per feature: 3 x 64 products (Jres chains)
+    constexpr int LPF = 64 / PPL;                  // lanes per feature
+    constexpr int FPW = 64 / LPF;                  // features per wave
+    constexpr int FPB = 4 * FPW;                   // features per 256-thread group
+    __shared__ __attribute__((aligned(16))) float s_prod[FPB][192];     // per feature: 3 x 64 products (Jres chains)
     __shared__ LevelGeom s_lv[DSDTM_MAX_LEVELS];
     if (threadIdx.x < DSDTM_MAX_LEVELS) s_lv[threadIdx.x] = a.lv[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int row = lane >> 4, l = lane & 15;                           // feature of the wave, lane of the feature
-    const int slot = (threadIdx.x >> 6) * 4 + row;                      // feature of the workgroup
-    const int f = blockIdx.x * 16 + slot;
+    const int grp = lane / LPF, l = lane % LPF;                         // feature of the wave, lane of the feature
+    const int slot = (threadIdx.x >> 6) * FPW + grp;                    // feature of the workgroup
+    const int f = blockIdx.x * FPB + slot;
     float* const prod = s_prod[slot];
     const bool exists = f < a.m;
     const int lvl = exists ? a.level[f] : -1;
@@ -204,35 +238,34 @@ __global__ __launch_bounds__(256) void align2d_rows_kernel(const A2DKernelArgs a
     const uint8_t* __restrict__ img = a.cur_pyr + (size_t)fr * a.pyr_pitch + lg.off;
     const int img_size = lg.stride * lg.h;
 
-    // this lane's four pixels: q = 4 l .. 4 l + 3 of the 8x8 patch in raster order -> row r, columns c0 .. c0 + 3
-    const int r = l >> 1, c0 = (l & 1) * 4;
-    float dx[4], dy[4], ref[4];
+    // this lane's pixels: q = PPL l .. PPL l + PPL - 1 of the 8x8 patch in raster order -> row r, columns c0 .. c0 + PPL - 1
+    const int r = (PPL * l) >> 3, c0 = (PPL * l) & 7;
+    float dx[PPL], dy[PPL], ref[PPL];
     {
         // bordered-patch rows r, r + 1, r + 2 around the pixels (10x10, the patch sits at (1, 1)):
         // gradients :336-337, 0.5 * (it[1] - it[-1]) is exact in float
-        uint32_t up = 0, dn = 0, mid_lo = 0, mid_hi = 0, pw = 0;
+        RowBytes up, mid, dn, pw;
+        up.lo = mid.lo = dn.lo = pw.lo = 0ull; up.hi = mid.hi = dn.hi = pw.hi = 0;
         if (valid) {
             const uint8_t* __restrict__ bp = a.patch_border + (size_t)f * 100 + r * 10 + c0;
-            up = *(const U32u*)(bp + 1);                                // row r,     columns c0 + 1 .. c0 + 4
-            mid_lo = *(const U32u*)(bp + 10);                           // row r + 1, columns c0 .. c0 + 3
-            mid_hi = *(const U16a*)(bp + 14);                           //            columns c0 + 4, c0 + 5
-            dn = *(const U32u*)(bp + 21);                               // row r + 2, columns c0 + 1 .. c0 + 4
-            pw = *(const U32u*)(a.patch + (size_t)f * 64 + 4 * l);
+            up = load_row_bytes<PPL>(bp + 1);                           // row r,     columns c0 + 1 .. c0 + PPL
+            mid = load_row_bytes<PPL + 2>(bp + 10);                     // row r + 1, columns c0 .. c0 + PPL + 1
+            dn = load_row_bytes<PPL>(bp + 21);                          // row r + 2, columns c0 + 1 .. c0 + PPL
+            pw = load_row_bytes<PPL>(a.patch + (size_t)f * 64 + PPL * l);
         }
-        const unsigned long long mid = (unsigned long long)mid_lo | ((unsigned long long)mid_hi << 32);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int right = (int)((mid >> (8 * (i + 2))) & 0xff), left = (int)((mid >> (8 * i)) & 0xff);
-            dx[i] = 0.5f * (float)(right - left);
-            dy[i] = 0.5f * (float)((int)((dn >> (8 * i)) & 0xff) - (int)((up >> (8 * i)) & 0xff));
-            ref[i] = (float)((pw >> (8 * i)) & 0xff);
+        for (int i = 0; i < PPL; ++i) {
+            dx[i] = 0.5f * (float)(mid.at(i + 2) - mid.at(i));
+            dy[i] = 0.5f * (float)(dn.at(i) - up.at(i));
+            ref[i] = (float)pw.at(i);
         }
     }
-    // H = sum J J^T, J = [dx, dy, 1]  (:341) over the feature's 64 pixels: 4 per lane, then the row
+    // H = sum J J^T, J = [dx, dy, 1]  (:341) over the feature's 64 pixels: PPL per lane, then the lanes of the feature
     float s00 = 0.0f, s01 = 0.0f, s02 = 0.0f, s11 = 0.0f, s12 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { s00 += dx[i] * dx[i]; s01 += dx[i] * dy[i]; s02 += dx[i]; s11 += dy[i] * dy[i]; s12 += dy[i]; }
-    const float h00 = row_sum_f32(s00), h01 = row_sum_f32(s01), h02 = row_sum_f32(s02), h11 = row_sum_f32(s11), h12 = row_sum_f32(s12);
+    for (int i = 0; i < PPL; ++i) { s00 += dx[i] * dx[i]; s01 += dx[i] * dy[i]; s02 += dx[i]; s11 += dy[i] * dy[i]; s12 += dy[i]; }
+    const float h00 = group_sum_f32<LPF>(s00), h01 = group_sum_f32<LPF>(s01), h02 = group_sum_f32<LPF>(s02),
+                h11 = group_sum_f32<LPF>(s11), h12 = group_sum_f32<LPF>(s12);
     const float h22 = 64.0f;
     // Matrix3f::inverse() (:345): Eigen cofactor formula, no conditioning check (quirk A2)
     const float m00 = h00, m01 = h01, m02 = h02, m10 = h01, m11 = h11, m12 = h12, m20 = h02, m21 = h12, m22 = h22;
@@ -256,14 +289,18 @@ __global__ __launch_bounds__(256) void align2d_rows_kernel(const A2DKernelArgs a
     float mean_diff = 0.0f;
     const float min_update_squared = (float)(0.03 * 0.03);
     bool converged = false;
-    bool active = valid;                                               // row-uniform: the four features of a wave end on their own
+    bool active = valid;                                               // group-uniform: the features of a wave end on their own
     for (int it = 0; it < a.max_iters; ++it) {
         if (active && (u != u || v != v)) active = false;                                        // :368 isnan
         const float fu = floorf(u), fv = floorf(v);
         // compare as floats: the int conversion of a huge float would be undefined
         if (active && (fu < 4.0f || fv < 4.0f || fu > (float)(lg.w - 4) || fv > (float)(lg.h - 4))) active = false;   // :367-368
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f, t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        float pr[3][PPL];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) pr[k][i] = 0.0f;
         if (active) {
             const int u_r = (int)fu, v_r = (int)fv;
             const float sx = u - (float)u_r, sy = v - (float)v_r;
@@ -272,38 +309,39 @@ __global__ __launch_bounds__(256) void align2d_rows_kernel(const A2DKernelArgs a
             const float wBL = (float)((1.0 - (double)sx) * (double)sy);          // :375
             const float wBR = sx * sy;                                            // :376
             const int o = (v_r + r - 4) * lg.stride + (u_r + c0 - 4);            // :383, this lane's first pixel
-            // the two footprint rows of the four pixels: bytes o .. o + 4 and o + stride .. o + stride + 4
-            unsigned long long b0, b1;
-            if (o + lg.stride + 8 <= img_size) {
-                const U64u w0 = *(const U64u*)(img + o), w1 = *(const U64u*)(img + o + lg.stride);
-                b0 = (unsigned long long)w0.lo | ((unsigned long long)w0.hi << 32);
-                b1 = (unsigned long long)w1.lo | ((unsigned long long)w1.hi << 32);
+            // the two footprint rows of the lane's pixels: bytes o .. o + PPL and o + stride .. o + stride + PPL
+            RowBytes b0, b1;
+            constexpr int SPAN = PPL + 1 <= 8 ? 8 : 10;                           // bytes the fast path reads per row
+            if (o + lg.stride + SPAN <= img_size) {
+                b0 = load_row_bytes<SPAN>(img + o);
+                b1 = load_row_bytes<SPAN>(img + o + lg.stride);
             } else {
                 // quirk A3: offsets past the level image read as 0 (undefined in the reference)
-                b0 = b1 = 0ull;
+                b0.lo = b1.lo = 0ull; b0.hi = b1.hi = 0;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    if (o + k < img_size) b0 |= (unsigned long long)img[o + k] << (8 * k);
-                    if (o + lg.stride + k < img_size) b1 |= (unsigned long long)img[o + lg.stride + k] << (8 * k);
+                for (int k = 0; k < PPL + 1; ++k) {
+                    const uint32_t x0 = (o + k < img_size) ? (uint32_t)img[o + k] : 0u;
+                    const uint32_t x1 = (o + lg.stride + k < img_size) ? (uint32_t)img[o + lg.stride + k] : 0u;
+                    if (k < 8) { b0.lo |= (unsigned long long)x0 << (8 * k); b1.lo |= (unsigned long long)x1 << (8 * k); }
+                    else { b0.hi |= x0 << (8 * (k - 8)); b1.hi |= x1 << (8 * (k - 8)); }
                 }
             }
-            float res[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float p00 = (float)((b0 >> (8 * i)) & 0xff), p01 = (float)((b0 >> (8 * i + 8)) & 0xff);
-                const float p10 = (float)((b1 >> (8 * i)) & 0xff), p11 = (float)((b1 >> (8 * i + 8)) & 0xff);
+            for (int i = 0; i < PPL; ++i) {
+                const float p00 = (float)b0.at(i), p01 = (float)b0.at(i + 1);
+                const float p10 = (float)b1.at(i), p11 = (float)b1.at(i + 1);
                 const float search = wTL * p00 + wTR * p01 + wBL * p10 + wBR * p11;  // :386
-                res[i] = search - ref[i] + mean_diff;                                // :387
+                const float res = search - ref[i] + mean_diff;                       // :387
+                pr[0][i] = res * dx[i]; pr[1][i] = res * dy[i]; pr[2][i] = res;
             }
-            p0 = res[0] * dx[0]; p1 = res[1] * dx[1]; p2 = res[2] * dx[2]; p3 = res[3] * dx[3];
-            q0 = res[0] * dy[0]; q1 = res[1] * dy[1]; q2 = res[2] * dy[2]; q3 = res[3] * dy[3];
-            t0 = res[0]; t1 = res[1]; t2 = res[2]; t3 = res[3];
         }
-        // Jres[k] -= res * J[k] over the pixels q = 0..63 in order, starting from 0 (:389-391): lane k < 3 of the feature's
-        // row folds chain k over the feature's 64 products (this lane's are q = 4 l .. 4 l + 3)
-        ((float4*)prod)[l] = make_float4(p0, p1, p2, p3);
-        ((float4*)(prod + 64))[l] = make_float4(q0, q1, q2, q3);
-        ((float4*)(prod + 128))[l] = make_float4(t0, t1, t2, t3);
+        // Jres[k] -= res * J[k] over the pixels q = 0..63 in order, starting from 0 (:389-391): lane k < 3 of the feature
+        // folds chain k over the feature's 64 products (this lane's are q = PPL l .. PPL l + PPL - 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < PPL; i += 4)
+                *(float4*)(prod + 64 * k + PPL * l + i) = make_float4(pr[k][i], pr[k][i + 1], pr[k][i + 2], pr[k][i + 3]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -316,7 +354,7 @@ __global__ __launch_bounds__(256) void align2d_rows_kernel(const A2DKernelArgs a
                 acc = acc - w.x; acc = acc - w.y; acc = acc - w.z; acc = acc - w.w;
             }
         }
-        const float j0 = lane_bcast_f32(acc, row * 16), j1 = lane_bcast_f32(acc, row * 16 + 1), j2 = lane_bcast_f32(acc, row * 16 + 2);
+        const float j0 = lane_bcast_f32(acc, grp * LPF), j1 = lane_bcast_f32(acc, grp * LPF + 1), j2 = lane_bcast_f32(acc, grp * LPF + 2);
         __builtin_amdgcn_wave_barrier();      // the next iteration's stores come after every lane's loads
         if (active) {
             const float up0 = (i00 * j0 + i01 * j1) + i02 * j2;                  // :395
@@ -339,7 +377,8 @@ hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream) {
     if (args.m <= 0) return hipSuccess;
     // DSDTM_A2D_TREE=1 (diagnostic, cost comparison only): DPP tree sums instead of the reference's order
     if (options().a2d_tree) hipLaunchKernelGGL(align2d_kernel<true>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL(align2d_rows_kernel, dim3((unsigned)((args.m + 15) / 16)), dim3(256), 0, stream, args);
+    else if (options().a2d_group == 8) hipLaunchKernelGGL(align2d_rows_kernel<8>, dim3((unsigned)((args.m + 31) / 32)), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(align2d_rows_kernel<4>, dim3((unsigned)((args.m + 15) / 16)), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -127,6 +127,7 @@ const OptionKey kOptionKeys[] = {
     {"a2d_tree", "DSDTM_A2D_TREE", &dsdtm::Options::a2d_tree, true},
     {"no_recover", "DSDTM_NO_RECOVER", &dsdtm::Options::no_recover, true},
     {"warp_group", "DSDTM_WARP_GROUP", &dsdtm::Options::warp_group, false},
+    {"a2d_group", "DSDTM_A2D_GROUP", &dsdtm::Options::a2d_group, false},
 };
 std::once_flag g_options_once;
 void options_from_env() {

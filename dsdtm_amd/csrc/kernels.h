@@ -54,6 +54,7 @@ struct Options {
     int no_zero_copy = 0;      // DSDTM_NO_ZERO_COPY: single-call entry points copy instead of mapping the pinned block
     int po_no_cache = 0;       // DSDTM_PO_NO_CACHE: pose refinement without features in registers
     int a2d_tree = 0;          // DSDTM_A2D_TREE: Align2D with DPP tree sums (cost comparison only; not bit-identical)
+    int a2d_group = 4;         // DSDTM_A2D_GROUP: Align2D features per wavefront (4; 8 = diagnostic: 114 VGPRs, measured 7 % slower)
     int warp_group = 0;        // DSDTM_WARP_GROUP: candidates per workgroup of the warp prelude (2, 8, 16, 32, 64; 0: by batch size)
     int no_recover = 0;        // DSDTM_NO_RECOVER: a multi-CU launch that timed out is reported, not re-run (tests)
 };
