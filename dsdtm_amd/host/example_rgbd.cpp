@@ -3,7 +3,8 @@
 // becomes the reference (features detected on it, :127; 3-D points from the depth map, :130-137), every later
 // frame is seeded with the previous pose (:147), aligned with Sprase_ImgAlign(4, 0, 30).Run(cur, ref) (:110,:150)
 // and compared with its ground-truth pose (:153-157). TUM data is not in the image, so the frames come from
-// tests/test_baseline_configs_gpu.py; the flow, the class names and the printed quantities are the reference's.
+// tests/test_baseline_configs_gpu.py — or from a dataset in the TUM RGB-D layout converted by tools/tum_to_rgbd_bin.py;
+// the flow, the class names and the printed quantities are the reference's.
 //   usage: example_rgbd <sequence.bin> <features_out.bin>
 #include <cmath>
 #include <cstdio>
@@ -87,6 +88,14 @@ int main(int argc, char** argv) {
             BlenderDepthToRay(*cam, depthmap);                           // :125
             feature_detector.detect(frame_ref_.get(), (double)hdr[4]);  // :127
             const SE3 T_g_w = inverse(frame_ref_->Get_Pose());
+            // real depth maps have holes (TUM: 0 = no measurement; tools/tum_to_rgbd_bin.py): a feature without a depth cannot
+            // carry a map point and is dropped here (the reference's Tracking leaves such features uninitialised, src/Frame.cpp:176-199)
+            {
+                std::vector<Feature> kept;
+                for (const Feature& it : frame_ref_->mvFeatures)
+                    if (depthmap[(size_t)(int)it.mpx_y * W + (int)it.mpx_x] > 0.0f) kept.push_back(it);
+                frame_ref_->mvFeatures.swap(kept);
+            }
             for (Feature& it : frame_ref_->mvFeatures) {                 // UndistortFeatures (:128) + :130-137
                 std::array<double, 3> n = Pixel2Camera(*cam, it.mpx_x, it.mpx_y);
                 const double nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);

@@ -167,3 +167,36 @@ def test_run_tum_driver_on_a_miniature_dataset(tmp_path, gpu_ctx):
     for k in range(4):
         ang, dt = synth.pose_error(np.linalg.inv(T_back[k])[:3], poses[k])
         assert ang < 2e-3 and dt < 5e-3, (k, ang, dt)
+
+
+@pytest.mark.gpu
+def test_cpp_rgbd_driver_on_a_converted_miniature_dataset(tmp_path, gpu_ctx):
+    """The C++ driver of BASELINE config 1 (dsdtm_amd/host/example_rgbd.cpp, the shape of Test/test_SpraseImg_alignment.cpp) on
+    a dataset in the TUM layout: tools/tum_to_rgbd_bin.py converts PNGs + associations + ground truth (CPU), the driver detects
+    on the first frame, takes depths from its depth image (a hole punched into it: features there are dropped), aligns every
+    later frame against it and prints the error against ground truth."""
+    from tests.test_host_cpp import build_example
+    root = str(tmp_path / "mini")
+    W, Hh = 640, 480
+    cam, poses = _write_dataset(root, n_frames=4, W=W, Hh=Hh)
+    # a hole in the first depth image (no measurement), as real sensors leave
+    seq = tum.TumSequence(root)
+    dpath = os.path.join(root, seq.entries[0][3])
+    d16 = tum.read_png(dpath).copy()
+    d16[100:220, 200:360] = 0
+    tum.write_png(dpath, d16)
+    out = str(tmp_path / "seq.bin")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tum_to_rgbd_bin.py"), root, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exe = build_example("example_rgbd")
+    feats = str(tmp_path / "features.bin")
+    lines = subprocess.run([exe, out, feats], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    n = int(lines[0].split()[1])
+    assert n >= 80, lines[0]
+    raw = np.fromfile(feats, dtype=np.uint8)[4:].reshape(n, 56)
+    px = raw[:, :8].copy().view("<f4").reshape(n, 2)
+    assert not ((px[:, 0] >= 200) & (px[:, 0] < 360) & (px[:, 1] >= 100) & (px[:, 1] < 220)).any()     # none inside the hole
+    for k in range(1, 4):
+        tok = lines[k].split()
+        assert tok[0] == "frame" and int(tok[1]) == k and int(tok[3]) > 60
+        assert float(tok[5]) < 5e-3 and float(tok[7]) < 2e-3, lines[k]       # translation error [m], angular distance [rad] vs ground truth
