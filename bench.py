@@ -897,8 +897,11 @@ def main():
     import torch
     from dsdtm_amd import shard
 
+    # DSDTM_BENCH_FORCE_DIST=1 (tests): the process group, its barrier and reductions also for ONE rank — the RCCL code path of
+    # an N-GPU run exercised on a one-GPU box
+    use_dist = world > 1 or os.environ.get("DSDTM_BENCH_FORCE_DIST") == "1"
     dist = None
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # The data path has no collective; the process group only carries the contract's barrier and the
@@ -914,7 +917,7 @@ def main():
             local_rank = 0
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     if args.stub:
@@ -926,7 +929,7 @@ def main():
             pass
         barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             elapsed = shard.max_over_ranks(elapsed, dist, torch.device("cpu"))
             total = shard.sum_over_ranks(hi - lo, dist, torch.device("cpu"))
         else:
@@ -934,7 +937,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "stub", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "data": "stub (no GPU work)", "pairs_per_step_all_ranks": total, "elapsed_max_s": elapsed}), flush=True)
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -1012,7 +1015,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             el = shard.max_over_ranks(el, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
         return el, ([x.elapsed_time(y) for x, y in ev] if per_kernel else None), (None if per_kernel else span[0].elapsed_time(span[1]))
 
@@ -1108,7 +1111,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "patches": args.patches, "levels": args.levels,
                        "max_iters": args.iters, "launch_streams": n_streams,
                        "parallelism": f"independent pairs x{world} (no collective)",
-                       **({"barrier_backend": dist.get_backend()} if world > 1 else {})},
+                       **({"barrier_backend": dist.get_backend()} if use_dist else {})},
             "roofline": roofline_block("sparse_align_reg_kernel", args.pairs * b_alg, k_avg, k_min, args.pairs, b_alg, "alignment",
                                        {"kernel_time_basis": k_basis, **k_extra}),
             "fp64": fp64_block(args, k_avg),
@@ -1142,7 +1145,7 @@ def main():
         if rc == 0 and world == 1 and not args.no_secondary:
             out["secondary"] = secondary_entries(torch, dev, ctx, cam_struct, stream, args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     sys.exit(rc)
 

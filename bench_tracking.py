@@ -112,9 +112,28 @@ def single_pair_entries(torch, dev, ctx, stream):
         To, no, so = oracle_lib.sparse_align(sc, *prm)
         cpu_ms = (time.perf_counter() - t0) * 1e3
         ang, dt = synth.pose_error(Tg, To)
+        # the same Run through the C++ host layer (dsdtm_host.hpp over the C ABI: what a C++ Tracking waits for; the Python mirror
+        # above adds its own marshalling) — dsdtm_amd/host/example_align, built with g++ on this box; None if that fails
+        cpp_ms = None
+        try:
+            import os, subprocess, tempfile
+            from tests.test_host_cpp import build_example, dump_scene
+            exe = build_example("example_align")
+            pbx, ppx = helpers.make_border_patches(sc.cur_pyr[0], [(150.3, 101.6)])
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "scene.bin")
+                dump_scene(path, sc, prm, 15, pbx[0], ppx[0], (151.0, 101.0))
+                lines = subprocess.run([exe, path], capture_output=True, text=True, check=True, timeout=120).stdout.split("\n")
+            cpp_ms = float([l for l in lines if l.startswith("run_resident_ms")][0].split()[1])
+        except Exception:
+            cpp_ms = None
         e = {"workload": f"ONE pair per call, resident frames — Sprase_ImgAlign::Run, {name}",
              "unit": "ms per call (median)", "calls": 60,
              "run_wall_ms": wall, "run_wall_ms_min": wall_min, "run_device_ms": dev_ms, "run_device_ms_min": dev_min,
+             "run_wall_ms_cpp": cpp_ms,
+             "run_wall_note": "run_wall_ms: through the Python mirror of the class (ctypes + numpy marshalling included); run_wall_ms_cpp: "
+                              "the same call through the C++ host layer, median of 101 calls in a g++-built driver; run_device_ms includes "
+                              "the ~6 us floor of an event pair around a launch",
              "new_frame_wall_ms": new_ms,
              "new_frame_note": "dsdtm_frame_create_from_image: level-0 upload + pyramid on the device (one launch), per new frame",
              "frame_wall_ms": wall + new_ms, "value": 1e3 / (wall + new_ms), "value_unit": "frames/s of one tracker (Run + new frame, wall)",

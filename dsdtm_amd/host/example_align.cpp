@@ -107,5 +107,19 @@ int main(int argc, char** argv) {
         std::sort(ms.begin(), ms.end());
         std::printf("detect_ms %.4f features %zu\n", ms[ms.size() / 2], cur->mvFeatures.size());
     }
+    // wall time of Sprase_ImgAlign::Run through the C++ layer on resident frames (what Tracking::TrackWithLastFrame waits for,
+    // src/Tracking.cpp:199-217), median of 101 calls
+    {
+        cur->mvFeatures.clear();
+        std::vector<double> ms;
+        for (int rep = 0; rep < 101; ++rep) {
+            cur->Set_Pose(Tc);
+            const auto t0 = std::chrono::steady_clock::now();
+            align.Run(cur, ref);
+            ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        std::sort(ms.begin(), ms.end());
+        std::printf("run_resident_ms %.4f min %.4f\n", ms[ms.size() / 2], ms[0]);
+    }
     return 0;
 }

@@ -34,3 +34,20 @@ def test_bench_two_ranks_share_one_gpu():
     # rank 0's own results are sane (64 synthetic pairs converge to their ground truth)
     assert out["err_vs_ground_truth_median"]["rad"] < 1e-3 and out["n_tracked_mean"] > 250
     assert out["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_over_rccl():
+    """The backend an N-GPU run uses — RCCL ("nccl") with one device per rank — exercised with ONE rank: process group with
+    device_id, the contract's barrier on both sides of the timed region and the max-over-ranks all-reduce on the GPU
+    (DSDTM_BENCH_FORCE_DIST=1 makes bench.py set them up for a world of 1; the two-rank test above has to use gloo because
+    RCCL refuses two ranks on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(DSDTM_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pairs", "64",
+                        "--preroll", "4", "--no-cpu", "--no-secondary"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["config"]["barrier_backend"] == "nccl"
+    assert out["value"] > 0 and abs(out["value"] - 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-6 * out["value"]
