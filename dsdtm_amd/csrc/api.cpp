@@ -143,7 +143,7 @@ dsdtm::Options& dsdtm::options() {
 
 extern "C" {
 
-const char* dsdtm_version(void) { return "dsdtm_amd 0.3 (gfx950, HIP; FP64 reference grid)"; }
+const char* dsdtm_version(void) { return "dsdtm_amd 0.4 (gfx950, HIP; FP64 reference grid)"; }
 
 int dsdtm_device_count(void) {
     int n = 0;
@@ -439,6 +439,7 @@ static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_c
             ctx->rings[ri].last_recorded = false;
             ctx->rings[ri].stream = stream;
             ctx->rings[ri].seq = 0;
+            ctx->h_flags[ri] = 0;                      // (the previous owner's launches have drained: its word starts clean)
         }
         ctx->rings[ri].last_use = ++ctx->ring_tick;
         a.pair_counter = ctx->d_counter + ri * dsdtm_ctx::COUNTERS_PER_STREAM + (ctx->rings[ri].seq++ % dsdtm_ctx::COUNTERS_PER_STREAM);
