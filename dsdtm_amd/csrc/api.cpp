@@ -207,6 +207,7 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
         hipMalloc((void**)&ctx->d_counter, counter_bytes) != hipSuccess ||
         hipMalloc((void**)&ctx->d_team, 8 * sparse_align_team_bytes(64)) != hipSuccess ||
         hipMemset(ctx->d_counter, 0, counter_bytes) != hipSuccess ||
+        hipMemset(ctx->d_team, 0, 8 * sparse_align_team_bytes(64)) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->team_event, hipEventDisableTiming) != hipSuccess) {
         if (ctx->d_counter) (void)hipFree(ctx->d_counter);
         if (ctx->d_team) (void)hipFree(ctx->d_team);
@@ -506,9 +507,12 @@ static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_c
             if (ctx->team_last_stream == ctx->stream) HIP_TRY(ctx, hipEventRecord(ctx->team_event, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->team_event, 0));
         }
-        uint8_t* tslot = ctx->d_team + (size_t)(ctx->team_seq++ & 7u) * sparse_align_team_bytes(64);
+        // (the exchange words carry the launch's epoch in their tags — never 0, the buffers were zeroed when the context
+        // was created — so a ring slot is reused without clearing it)
+        ctx->team_seq += 1;
+        uint8_t* tslot = ctx->d_team + (size_t)(ctx->team_seq & 7u) * sparse_align_team_bytes(64);
         a.workspace = (double*)tslot;
-        HIP_TRY(ctx, hipMemsetAsync(tslot, 0, sparse_align_team_bytes(b->n_pairs), stream));
+        a.team_epoch = (ctx->team_seq & 0xfffffu) ? ctx->team_seq : ++ctx->team_seq;
         if (g_team_drop_members) a.spin_limit = 1u << 12;      // the test's waits give up after ~4 k polls
         HIP_TRY(ctx, sparse_align_launch_team(a, k, stream, g_team_drop_members));
         if (int rc = launched_multi_cu()) return rc;

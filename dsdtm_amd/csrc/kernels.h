@@ -31,6 +31,7 @@ struct SAKernelArgs {
     unsigned* timeout_flag;     // host-mapped word of the launching context (multi-CU launches: a word of their own): set
                                 // to 1 by a wave whose bounded wait ran out; read by the host once the stream has drained
     unsigned spin_limit;        // team kernel: polls before a wait gives up (0 = the default, 2^24); tests shorten it
+    unsigned team_epoch;        // team kernel: number of this launch among the context's team launches (part of the exchange tags)
     int debug_drop;             // tests only: member 1 of every two-member pair exits at once (its partner's waits run out)
     unsigned long long pyr_pitch;
     int n_pairs, max_features;

@@ -1719,6 +1719,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
 // ---------------------------------------------------------------------------------------------
 // The exchange buffer holds TAGGED WORDS: every 64-bit word carries 32 bits of payload and, in its upper
 // half, the number of the iteration it belongs to. 64-bit atomic stores and loads are single-copy atomic, so
+// (with the launch's epoch, so that the words of earlier launches in the same buffer never match: no memset per launch);
 // a reader that finds the expected tag in a word holds that iteration's payload — no flag, no fence and no
 // second round trip: the writer fires its stores and goes on, a reader polls the words themselves until
 // every tag matches. Two banks (iteration parity): a member can only overwrite the bank of iteration g at
@@ -1783,7 +1784,9 @@ __global__ __launch_bounds__((NPW + 1) * 64) void sparse_align_team_kernel(const
                     ctrl = 1;
                     if (lane == 0) s.ctrl = 1;
                 } else {
-                    const unsigned long long tag = (unsigned long long)(g + 1u) << 32;
+                    // tag = launch epoch (20 bits) | iteration (12 bits): words a previous launch left in this ring slot never
+                    // match, so the buffer needs no memset per launch (one stream operation less in front of every Run)
+                    const unsigned long long tag = (unsigned long long)(((a.team_epoch & 0xfffffu) << 12) | ((g + 1u) & 0xfffu)) << 32;
                     unsigned long long* const bank = twords + (size_t)(g & 1u) * TEAM_MAX_MEMBERS * WPD * 2;
                     // this member's partial: lane i < WPD folds double i of its wave partials in wave order
                     // (doubles 7 and 8 are the packed counters: cnt | h_changed and n_ref | pad)
