@@ -263,3 +263,57 @@ def test_restated_third_party_arithmetic_against_scipy(oracle):
         acc = correlate1d(correlate1d(img.astype(np.int64), k, axis=0, mode="mirror"), k, axis=1, mode="mirror")
         want = ((acc + 128) >> 8)[::2, ::2].astype(np.uint8)
         assert np.array_equal(oracle.pyrdown(img), want)
+
+
+def _test1_scene(n_features=300, levels=4):
+    """The reference's own test image (Thirdparty/fast/test/data/test1.png, committed as data in the FAST fixtures) with the
+    corners ITS FAST build found at barrier 20 (`test1_b20`: pinned reference output) as features, seen again through a
+    plane-warp at the Config/Rpg_uzh.yaml intrinsics."""
+    d = np.load(H.golden_path("fast_reference.npz"))
+    img = np.ascontiguousarray(d["test1"])
+    corners = d["test1_b20"][:, :2].astype(np.float32)                   # (x, y) of the reference detector's corners
+    rng = np.random.default_rng(17)
+    inside = (corners[:, 0] > 30) & (corners[:, 0] < 752 - 30) & (corners[:, 1] > 30) & (corners[:, 1] < 480 - 30)
+    px = corners[inside][rng.choice(int(inside.sum()), n_features, replace=False)]
+    cam = synth.Camera(315.5, 315.5, 376.0, 240.0, 315.5, 752, 480)
+    T_cr = synth.se3_exp((0.012, -0.007, 0.005, 0.004, -0.003, 0.006))
+    depth = 2.0
+    cur = synth.warp_plane(img.astype(np.float64), cam, T_cr, depth)
+    bearing = synth.bearing_from_px(cam, px)
+    T_ref = synth.random_pose(rng)
+    X_r = bearing * (depth / bearing[:, 2:3])
+    p_world = (X_r - T_ref[:, 3]) @ T_ref[:, :3]
+    T4 = np.vstack([T_ref, [0, 0, 0, 1]])
+    return synth.AlignScene(cam, synth.build_pyramid(img, levels), synth.build_pyramid(cur, levels), px, bearing, p_world,
+                            np.ones(len(px), np.uint8), T_ref.copy(), T_ref.copy(), (T_cr @ T4)[:3], depth)
+
+
+def test_oracle_matches_numpy_restatement_on_the_reference_image(oracle):
+    """The two independent CPU restatements agree on REAL image statistics too: Run on test1 at the reference detector's own
+    corners (clustered on structure, some on saturated edges) — same pose to 1e-9, same iteration counts; and the warp is
+    recovered."""
+    sc = _test1_scene()
+    To, no, so = oracle.sparse_align(sc, 4, 0, 10)
+    Tn, nn, itn = NP.sparse_align(sc, 4, 0, 10)
+    ang, dt = synth.pose_error(To, Tn)
+    assert ang < 1e-9 and dt < 1e-9, (ang, dt)
+    assert no == nn and so["iters"] == itn and no > 250
+    ea, et = synth.pose_error(To, sc.T_cur_w_true)
+    assert ea < 2e-3 and et < 5e-3, (ea, et)
+
+
+def test_align2d_restatements_agree_on_the_reference_image(oracle):
+    """Align2DGaussNewton at the reference detector's corners of test1: oracle and numpy restatement, pixel for pixel."""
+    d = np.load(H.golden_path("fast_reference.npz"))
+    img = np.ascontiguousarray(d["test1"])
+    corners = d["test1_b75"][:, :2].astype(np.float64)                   # the 167 corners of the reference's own test
+    rng = np.random.default_rng(4)
+    n_ok = 0
+    for c in corners[(corners[:, 0] > 14) & (corners[:, 0] < 752 - 14) & (corners[:, 1] > 14) & (corners[:, 1] < 480 - 14)][:40]:
+        pb, p = H.make_border_patches(img, [tuple(c + rng.uniform(0, 1, 2))])
+        px0 = c + rng.uniform(-1.5, 1.5, 2)
+        oko, pxo = oracle.align2d(img, pb[0], p[0], 10, px0)
+        okn, pxn = NP.align2d(img, pb[0], p[0], 10, px0)
+        assert oko == okn and np.allclose(pxo, pxn, rtol=0, atol=1e-4, equal_nan=True), (c, pxo, pxn)
+        n_ok += oko
+    assert n_ok >= 25
