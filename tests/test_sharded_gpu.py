@@ -309,6 +309,18 @@ def test_streamed_batch_padded_rows_ragged_counts_and_bad_arguments(gpu_ctx, ora
         assert a["nt"][i] == no
         H.assert_pose_close(a["Tc"][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"pair {i}")
     assert a["nt"][2] == 0 and np.array_equal(a["Tc"][2], scenes[2].T_cur_w_seed.reshape(12))
+    # an empty batch is a no-op; a one-level "pyramid" (nothing to build on the device) works
+    empty = capi.StreamDesc.from_buffer_copy(bytes(s))
+    empty.n_pairs = 0
+    assert gpu_ctx.lib.dsdtm_sparse_align_batch_streamed(arr, 5, C.byref(empty), 4, C.byref(cam), C.byref(prm)) == 0
+    a1, _, _ = _host_batch(scenes, L, W, Hh)
+    s1 = _stream_desc(a1, fr, fc, 3, N, 1, W, Hh, row_stride=RS, image_pitch=RS * Hh)
+    prm1 = capi.AlignParams(1, 0, 10, 15)
+    assert gpu_ctx.lib.dsdtm_sparse_align_batch_streamed(arr, 2, C.byref(s1), 2, C.byref(cam), C.byref(prm1)) == 0
+    for i, sc in enumerate(scenes):
+        To, no, _ = oracle.sparse_align(sc, 1, 0, 10)
+        assert a1["nt"][i] == no
+        H.assert_pose_close(a1["Tc"][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"one level, pair {i}")
     # refused up front: negative feature count, no levels, rows shorter than the image, a context listed twice
     for field, value in (("max_features", -1), ("levels", 0), ("row_stride", W - 1), ("image_pitch", 10)):
         bad = capi.StreamDesc.from_buffer_copy(bytes(s))
