@@ -139,13 +139,16 @@ def test_detect_honours_the_moving_object_mask(gpu_ctx):
     assert all(200 - 26 <= x < 500 + 26 and 100 - 26 <= y < 300 + 26 for x, y in extra) and len(extra) < 20
 
 
-@pytest.mark.parametrize("size,levels,n", [((640, 480), 5, 6), ((752, 480), 4, 3), ((640, 480), 5, 9), ((320, 240), 3, 12), ((752, 480), 3, 8)])
+@pytest.mark.parametrize("size,levels,n", [((640, 480), 5, 6), ((752, 480), 4, 3), ((640, 480), 5, 9), ((320, 240), 3, 12), ((752, 480), 3, 8),
+                                           ((656, 490), 3, 8), ((640, 482), 3, 9)])
 def test_batch_entry_equals_the_oracle_frame_by_frame(gpu_ctx, oracle, size, levels, n):
     """dsdtm_detect_cells_batch_device: n packed device pyramids in one call (strip kernel where the level rows are whole
     dwords, one thread per pixel where they are not: 752 -> 94 -> 47 columns), every frame with its own occupancy
     grid, against the oracle's cells frame by frame. From 8 frames the select pass is the batch kernel (4 x 4 pixels per
     thread, four survivors scored per round) when every level is whole dwords wide: 9 x 640x480x5, 12 x 320x240x3 and
-    8 x 752x480x3 (the reference's test1.png among them) run it; 6 and 3 frames run the one-pixel-per-thread kernel."""
+    8 x 752x480x3 (the reference's test1.png among them) run it; 6 and 3 frames run the one-pixel-per-thread kernel.
+    656x490 and 640x482 end the kernel's 4 x 4 strips inside the image: level heights 490 / 245 / 123 and 482 / 241 / 121, a
+    level width (164) that is not a multiple of its 16-column thread groups."""
     import torch
     from dsdtm_amd.feature_detection import Feature_detector
     from dsdtm_amd.frame import Config

@@ -208,3 +208,16 @@ def test_match_candidates_batch_device_equals_per_frame_calls(gpu_ctx):
     assert not conv2[badn].any() and (sl2[badn] == -1).all() and np.array_equal(px2[badn], px_in[badn])
     keep = np.ones(M, bool); keep[badn] = False
     assert np.array_equal(conv2[keep], conv[keep]) and np.array_equal(sl2[keep], sl[keep]) and np.array_equal(px2[keep], px[keep], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_match_candidates_batch_device_equals_the_oracle_across_group_boundaries():
+    """Candidate counts on both sides of the warp prelude's group sizes (2 and 16 per group, switched at 8192) and Align2D's
+    16 features per group, with random invalid candidates mixed in: search level, flag and refined pixel equal the CPU
+    oracle's warp + Align2D bit for bit (tools/soak_fmd.py runs the long list)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("soak_fmd", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_fmd.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main((1, 17, 127, 8193)) == 0
