@@ -128,7 +128,7 @@ def single_pair_entries(torch, dev, ctx, stream):
         except Exception:
             cpp_ms = None
         e = {"workload": f"ONE pair per call, resident frames — Sprase_ImgAlign::Run, {name}",
-             "unit": "ms per call (median)", "calls": 60,
+             "times_unit": "ms per call (median)", "calls": 60,
              "run_wall_ms": wall, "run_wall_ms_min": wall_min, "run_device_ms": dev_ms, "run_device_ms_min": dev_min,
              "run_wall_ms_cpp": cpp_ms,
              "run_wall_note": "run_wall_ms: through the Python mirror of the class (ctypes + numpy marshalling included); run_wall_ms_cpp: "
@@ -136,7 +136,7 @@ def single_pair_entries(torch, dev, ctx, stream):
                               "the ~6 us floor of an event pair around a launch",
              "new_frame_wall_ms": new_ms,
              "new_frame_note": "dsdtm_frame_create_from_image: level-0 upload + pyramid on the device (one launch), per new frame",
-             "frame_wall_ms": wall + new_ms, "value": 1e3 / (wall + new_ms), "value_unit": "frames/s of one tracker (Run + new frame, wall)",
+             "frame_wall_ms": wall + new_ms, "value": 1e3 / (wall + new_ms), "unit": "frames/s of one tracker (Run + new frame, wall)",
              "cpu_oracle_ms": cpu_ms, "cpu_note": "the CPU oracle on the same pair, one thread (the reference's tracking thread)",
              "device_entry_pose_equals_host_entry": same,
              "pose_delta_vs_cpu": {"rad": ang, "m": dt, "n_tracked_equal": bool(n_g == no),

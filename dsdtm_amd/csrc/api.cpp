@@ -603,8 +603,8 @@ extern "C" void dsdtm_shard_range(int n_pairs, int n_shards, int shard, int* lo,
 // One shard: pairs [lo, hi) of the host batch on `ctx` (its device, its stream). Device scratch comes from the
 // context's staging buffer (device side only: the caller's arrays may be pageable, the copies are then staged by
 // the runtime; pinned arrays are copied directly).
-static int sharded_one(dsdtm_ctx* ctx, const dsdtm_batch_desc* hb, const dsdtm_camera* cam, const dsdtm_align_params* prm,
-                       int lo, int hi) {
+static int sharded_issue(dsdtm_ctx* ctx, const dsdtm_batch_desc* hb, const dsdtm_camera* cam, const dsdtm_align_params* prm,
+                         int lo, int hi) {
     const int n = hi - lo;
     if (n <= 0) return DSDTM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -647,6 +647,15 @@ static int sharded_one(dsdtm_ctx* ctx, const dsdtm_batch_desc* hb, const dsdtm_c
     HIP_TRY(ctx, hipMemcpyAsync(hb->n_tracked + lo, d + o_nt, n * 4, hipMemcpyDeviceToHost, st));
     if (hb->stats) HIP_TRY(ctx, hipMemcpyAsync(hb->stats + lo, d + o_st, n * sizeof(dsdtm_align_stats), hipMemcpyDeviceToHost, st));
     return dsdtm_sparse_align_check(ctx, st);
+}
+
+// A shard that fails half-way still has copies from / into the caller's arrays in flight: they are waited for before
+// the error is returned, so the caller may free or reuse its memory as after any other return.
+static int sharded_one(dsdtm_ctx* ctx, const dsdtm_batch_desc* hb, const dsdtm_camera* cam, const dsdtm_align_params* prm,
+                       int lo, int hi) {
+    const int rc = sharded_issue(ctx, hb, cam, prm, lo, hi);
+    if (rc != DSDTM_OK) (void)hipStreamSynchronize(ctx->stream);
+    return rc;
 }
 
 extern "C" int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx, const dsdtm_batch_desc* hb,
@@ -704,8 +713,8 @@ extern "C" int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx
 // aligned on the context's stream behind the copy's event, the results come back behind the alignment — the upload of
 // chunk j + 1 overlaps pyramids + alignment + download of chunk j. Device memory holds the whole shard (0.41 MB per
 // 640x480 frame: thousands of frames are a few GB of 288).
-static int streamed_one(dsdtm_ctx* ctx, const dsdtm_stream_desc* s, const dsdtm_camera* cam, const dsdtm_align_params* prm,
-                        int chunk, int lo, int hi) {
+static int streamed_issue(dsdtm_ctx* ctx, const dsdtm_stream_desc* s, const dsdtm_camera* cam, const dsdtm_align_params* prm,
+                          int chunk, int lo, int hi) {
     const int n = hi - lo;
     if (n <= 0) return DSDTM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -812,6 +821,18 @@ static int streamed_one(dsdtm_ctx* ctx, const dsdtm_stream_desc* s, const dsdtm_
         HIP_TRY(ctx, hipStreamSynchronize(comp));
     }
     return DSDTM_OK;
+}
+
+// As sharded_one: no copy touches the caller's arrays after an error return.
+static int streamed_one(dsdtm_ctx* ctx, const dsdtm_stream_desc* s, const dsdtm_camera* cam, const dsdtm_align_params* prm,
+                        int chunk, int lo, int hi) {
+    const int rc = streamed_issue(ctx, s, cam, prm, chunk, lo, hi);
+    if (rc != DSDTM_OK) {
+        for (int i = 0; i < 2; ++i)
+            if (ctx->copy_stream[i]) (void)hipStreamSynchronize(ctx->copy_stream[i]);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    return rc;
 }
 
 extern "C" int dsdtm_sparse_align_batch_streamed(dsdtm_ctx* const* ctx, int n_ctx, const dsdtm_stream_desc* s, int chunk_pairs,
