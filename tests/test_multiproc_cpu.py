@@ -81,3 +81,19 @@ def test_bench_refuses_a_world_that_contradicts_the_flag():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_under_the_drivers_launcher():
+    """The command line the driver uses for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` — with the stub steps: the ranks take RANK / LOCAL_RANK / WORLD_SIZE from the
+    launcher's environment (no second spawn), and rank 0 alone prints the line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "4",
+                        "--warmup", "1", "--pairs", "1024"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["pairs_per_step_all_ranks"] == 2048 and out["value"] is None

@@ -51,3 +51,21 @@ def test_bench_one_rank_over_rccl():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["config"]["barrier_backend"] == "nccl"
     assert out["value"] > 0 and abs(out["value"] - 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-6 * out["value"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_under_the_drivers_launcher():
+    """The same two ranks started the way the driver starts them (`python -m torch.distributed.run ... bench.py --gpus 2`), sharing
+    device 0: environment from the launcher, one line from rank 0, whole-job rate over the max-over-ranks time."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["DSDTM_BENCH_SHARE_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "64",
+                        "--preroll", "4", "--no-cpu", "--no-secondary"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["pairs_per_gpu"] == 64 and out["value"] > 0
+    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-6 * out["value"]
