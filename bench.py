@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import bench_line  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -435,6 +437,7 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
         dl = np.array([synth.pose_error(Tg[i], hb.T[i]) for i in range(sample)])
         stats = np.frombuffer(d["stats"][:sample].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
         out.append({
+            "key": f"align_{n_pairs}x{n_patches}_{width}x{height}",
             "workload": f"{n_pairs} independent pairs per launch, {name}",
             "value": n_pairs / (ms_avg * 1e-3), "unit": "alignments/s",
             "value_note": "one launch at a time (HIP events around every launch)",
@@ -465,7 +468,7 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
     ms_avg, ms_min = hip_event_ms(torch, stream, pyr_launch, 20)
     b_pyr = sum(ws[l] * hs[l] + ws[l + 1] * hs[l + 1] for l in range(levels - 1))     # level l read once, level l+1 written once
     out.append({
-        "workload": f"Frame::ComputeImagePyramid: levels 1..{levels - 1} of {n_img} {width}x{height} pyramids per call",
+        "key": "pyramid", "workload": f"Frame::ComputeImagePyramid: levels 1..{levels - 1} of {n_img} {width}x{height} pyramids per call",
         "value": n_img / (ms_avg * 1e-3), "unit": "pyramids/s",
         "roofline": roofline_block("pyrdown", n_img * b_pyr, ms_avg, ms_min, n_img, b_pyr, "pyramid")})
     del pyr
@@ -534,7 +537,7 @@ def tracked_frame_entries(torch, dev, ctx, stream):
     ms = timed(a2d)
     b_feat = 100 + 64 + 16 + 17                      # bordered patch + patch + pixel in/out + level and flag
     alg = M * b_feat + ws[0] * hs[0]                 # + the level image the features sit on, once
-    out.append({"workload": f"Feature_Alignment::Align2DGaussNewton: {M} features per call on one {Wa}x{Ha} level, cap 10 iterations "
+    out.append({"key": "align2d", "workload": f"Feature_Alignment::Align2DGaussNewton: {M} features per call on one {Wa}x{Ha} level, cap 10 iterations "
                             f"(four features per wavefront, float sums in the reference's order)",
                 "value": M / (ms * 1e-3), "unit": "features/s", "converged_fraction": float(d_cv.float().mean().item()),
                 "roofline": roofline_block("align2d", alg, ms, None, M, b_feat, "feature",
@@ -568,7 +571,7 @@ def tracked_frame_entries(torch, dev, ctx, stream):
     blocks = np.array([q.n_residual_blocks for q in sms])
     flops = float(((its + 1) * blocks).sum()) * 330.0       # block evaluations x ~330 FP64 flops each
     tf = flops / (ms * 1e-3) / 1e12
-    out.append({"workload": f"Optimizer::PoseOptimization: {F_} frames x {N_} features per call (Ceres trust-region LM restated, "
+    out.append({"key": "pose_opt", "workload": f"Optimizer::PoseOptimization: {F_} frames x {N_} features per call (Ceres trust-region LM restated, "
                             f"{its.mean():.1f} iterations on average), one wavefront per frame",
                 "value": F_ / (ms * 1e-3), "unit": "refinements/s",
                 "roofline": {"bound": "fp64_vector", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -619,7 +622,7 @@ def tracked_frame_entries(torch, dev, ctx, stream):
     ms = timed(fmd)
     b_cand = 4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1 + 2 * (100 + 64)   # candidate columns in, pixel in/out, level + flag out, patches through scratch
     alg = Mm * b_cand + 2 * nfm * ws[0] * hs[0]                            # + level 0 of every keyframe and current frame once
-    out.append({"workload": f"Feature_Alignment::FindMatchDirect: {Mm} candidates of {nfm} current frames per call ({ncand} each, {Wm}x{Hm}): "
+    out.append({"key": "find_match_direct", "workload": f"Feature_Alignment::FindMatchDirect: {Mm} candidates of {nfm} current frames per call ({ncand} each, {Wm}x{Hm}): "
                             f"SolveAffineMatrix, GetBestSearchLevel, WarpAffine, GetPatchNoBoarder, Align2DGaussNewton (cap 10)",
                 "value": Mm / (ms * 1e-3), "unit": "candidates/s", "us_per_frame": ms * 1e3 / nfm,
                 "matched_fraction": float(d_cv.float().mean().item()),
@@ -655,7 +658,7 @@ def tracked_frame_entries(torch, dev, ctx, stream):
                                                           d_lv.data_ptr(), stream.cuda_stream))
     ms = timed(det)
     b_fr = 3 * sum(ws[l] * hs[l] for l in range(Ld))     # pyramid read by the score pass, score map written, then read by the select pass
-    out.append({"workload": f"Feature_detector::detect, image part: {nfr} frames of {Wd}x{Hd}x{Ld} levels per call (FAST-10 score map, non-max, "
+    out.append({"key": "detector", "workload": f"Feature_detector::detect, image part: {nfr} frames of {Wd}x{Hd}x{Ld} levels per call (FAST-10 score map, non-max, "
                             f"Shi-Tomasi, best corner per {cell}-px cell)",
                 "value": nfr / (ms * 1e-3), "unit": "frames/s", "us_per_frame": ms * 1e3 / nfr,
                 "cells_with_a_corner_per_frame": float((d_s > 5.0).sum().item()) / nfr,
@@ -793,7 +796,7 @@ def streamed_entry(torch, dev, ctx, cam, cam_struct, args, n_frames=2049, chunk=
     dl = np.array([synth.pose_error(T_pipe[i], Tor[i]) for i in range(sample)])
     err = np.array([synth.pose_error(T_pipe[i], T[i + 1, :3]) for i in range(P)])
     return {
-        "workload": f"streamed: {n_frames} chained {W}x{Hh} frames from pinned host memory ({P} pairs, {N} patches, {L} levels, cap "
+        "key": "streamed_host_fed", "workload": f"streamed: {n_frames} chained {W}x{Hh} frames from pinned host memory ({P} pairs, {N} patches, {L} levels, cap "
                     f"{args.iters}) through ONE call of dsdtm_sparse_align_batch_streamed (C ABI): chunks of {chunk} pairs, H2D of level 0 + "
                     f"feature columns on 2 copy streams -> pyramids on the device -> chained alignment -> results D2H per chunk",
         "value": n_frames / t_pipe, "unit": "frames/s (PCIe-inclusive, end to end; = alignments/s + 1 frame)",
@@ -927,16 +930,24 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             pass
+        local = time.perf_counter() - t0
         barrier()
         elapsed = time.perf_counter() - t0
+        per_rank = [[local, float(hi - lo)]]
         if use_dist:
             elapsed = shard.max_over_ranks(elapsed, dist, torch.device("cpu"))
             total = shard.sum_over_ranks(hi - lo, dist, torch.device("cpu"))
+            per_rank = shard.gather_over_ranks([local, float(hi - lo)], dist, torch.device("cpu"))
         else:
             total = hi - lo
         if rank == 0:
-            print(json.dumps({"metric": "stub", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "data": "stub (no GPU work)", "pairs_per_step_all_ranks": total, "elapsed_max_s": elapsed}), flush=True)
+            # compact line only: the stub writes no bench_secondary.json (never a measurement)
+            print(bench_line.compact_line({
+                "metric": "stub", "value": None, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "data": "stub (no GPU work)", "pairs_per_step_all_ranks": total, "elapsed_max_s": elapsed,
+                "per_rank_ms_per_step": [r[0] / max(1, args.steps) * 1e3 for r in per_rank],
+                "per_rank_value": [None for _ in per_rank], "ranks_seen": len(per_rank),
+                **({"barrier_backend": dist.get_backend()} if use_dist else {})}), flush=True)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -1013,10 +1024,12 @@ def main():
         for s in streams:
             s.synchronize()
         torch.cuda.synchronize()
+        el_local = time.perf_counter() - t0       # this rank's own K steps (before it waits for the others)
         barrier()
         el = time.perf_counter() - t0
         if use_dist:
             el = shard.max_over_ranks(el, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
+        timed_region.local = el_local
         return el, ([x.elapsed_time(y) for x, y in ev] if per_kernel else None), (None if per_kernel else span[0].elapsed_time(span[1]))
 
     # For the record, the same W + K steps BEFORE the pre-roll, i.e. on a GPU that sat idle while the host prepared the
@@ -1049,6 +1062,11 @@ def main():
         preroll_ms = (time.perf_counter() - tp) * 1e3
 
     elapsed, kernel_ms, span_ms = timed_region()
+    # every rank's own figure, gathered AFTER the timed region: a straggler shows in the line (value itself stays the
+    # whole job over the max-over-ranks time)
+    per_rank = [[timed_region.local, float(args.pairs * args.steps)]]
+    if use_dist:
+        per_rank = shard.gather_over_ranks(per_rank[0], dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
     ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, stream.cuda_stream))   # no hand-over wait timed out in any launch
     d["T_cur_w"] = d["T_steps"][n_slots - 1].clone()  # the last step's results are the ones checked below
     if per_kernel:
@@ -1105,13 +1123,16 @@ def main():
             "value": value, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 4 per-GPU share of config 2's shape: {args.pairs} independent "
-                                   f"{args.width}x{args.height} frame pairs per GPU per step, {args.levels} pyramid "
-                                   f"levels, {args.patches} patches, cap {args.iters} GN iterations, one launch per step",
+            "config": {"workload": f"{args.pairs} independent {args.width}x{args.height} pairs per GPU per step (BASELINE config 4 share of "
+                                   f"config 2's shape), {args.levels} levels, {args.patches} patches, cap {args.iters}, one launch per step",
                        "pairs_per_gpu": args.pairs, "patches": args.patches, "levels": args.levels,
                        "max_iters": args.iters, "launch_streams": n_streams,
                        "parallelism": f"independent pairs x{world} (no collective)",
                        **({"barrier_backend": dist.get_backend()} if use_dist else {})},
+            "per_rank_ms_per_step": [r[0] / args.steps * 1e3 for r in per_rank],
+            "per_rank_value": [r[1] / r[0] for r in per_rank],
+            "ranks_seen": dist.get_world_size() if use_dist else 1,
+            **({"barrier_backend": dist.get_backend()} if use_dist else {}),
             "roofline": roofline_block("sparse_align_reg_kernel", args.pairs * b_alg, k_avg, k_min, args.pairs, b_alg, "alignment",
                                        {"kernel_time_basis": k_basis, **k_extra}),
             "fp64": fp64_block(args, k_avg),
@@ -1119,7 +1140,7 @@ def main():
             "executed_iterations_total_mean": float(iters.sum(axis=1).mean()),
             "n_tracked_mean": float(ntg.mean()),
             "err_vs_ground_truth_median": {"rad": float(np.median(err[:, 0])), "m": float(np.median(err[:, 1]))},
-            "library": ctx.lib.dsdtm_version().decode(),
+            "library": ctx.lib.dsdtm_version().decode(), "library_sha": library_sha(),
             "value_from_idle": (n_total / elapsed_idle) if elapsed_idle else None,
             "preroll": {"launches": args.preroll, "ms": preroll_ms,
                         "note": "untimed launches of the same step before the 'warmup' steps, on pose buffers of their own: the GPU "
@@ -1143,8 +1164,14 @@ def main():
                 out["parity_failed"] = True
                 rc = 1
         if rc == 0 and world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_entries(torch, dev, ctx, cam_struct, stream, args)
-        print(json.dumps(out), flush=True)
+            try:
+                out["secondary"] = secondary_entries(torch, dev, ctx, cam_struct, stream, args)
+            except Exception as e:          # the headline was measured before this: it is printed whatever happens here
+                out["secondary_error"] = f"{type(e).__name__}: {e}"
+                rc = 3
+        # secondary entries: one short line each, BEFORE the headline; full objects (with their notes) -> bench_secondary.json;
+        # the LAST stdout line is the compact headline, < 4 KB (bench_line.py asserts it)
+        bench_line.emit(out, ROOT)
     if use_dist:
         dist.destroy_process_group()
     sys.exit(rc)

@@ -127,7 +127,8 @@ def single_pair_entries(torch, dev, ctx, stream):
             cpp_ms = float([l for l in lines if l.startswith("run_resident_ms")][0].split()[1])
         except Exception:
             cpp_ms = None
-        e = {"workload": f"ONE pair per call, resident frames — Sprase_ImgAlign::Run, {name}",
+        e = {"key": "run_one_pair_" + name.split(":")[0].replace(" shape", "").replace(" ", ""),
+             "workload": f"ONE pair per call, resident frames — Sprase_ImgAlign::Run, {name}",
              "times_unit": "ms per call (median)", "calls": 60,
              "run_wall_ms": wall, "run_wall_ms_min": wall_min, "run_device_ms": dev_ms, "run_device_ms_min": dev_min,
              "run_wall_ms_cpp": cpp_ms,
@@ -303,7 +304,7 @@ def tracked_frame_entry(torch, dev, ctx, stream):
     steps.append((f"Optimizer::PoseOptimization ({nobs} observations, {sm['iterations']} trust-region iterations)", w4, d4, c4))
 
     wall, devt, cpu = (sum(x[i] for x in steps) for i in (1, 2, 3))
-    return {"workload": "ONE tracked frame of the front end (src/Tracking.cpp:199-256) on device-resident frames, 640x480, 5 levels: new frame -> "
+    return {"key": "tracked_frame", "workload": "ONE tracked frame of the front end (src/Tracking.cpp:199-256) on device-resident frames, 640x480, 5 levels: new frame -> "
                         "Run -> FindMatchDirect for every candidate of SearchLocalPoints -> PoseOptimization; medians of 60 calls per step",
             "value": 1e3 / wall, "unit": "tracked frames/s of one tracker (sum of the four library calls, wall)",
             "frame_wall_ms": wall, "frame_device_ms": devt, "frame_cpu_oracle_ms": cpu,

@@ -26,3 +26,12 @@ def sum_over_ranks(value: int, dist, device) -> int:
     t = torch.tensor([value], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def gather_over_ranks(values, dist, device) -> list:
+    """Every rank's list of floats, in rank order, on every rank (bench.py: per-rank elapsed time and pair count)."""
+    import torch
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.cpu()] for o in out]

@@ -58,3 +58,84 @@ def test_fp64_block_reads_the_committed_counter_pass(monkeypatch):
     assert abs(b["achieved"] - b["flops_per_launch"] / 0.2e-3 / 1e12) < 1e-9 and 0 < b["frac"] < 1
     a.patches = 1000
     assert bench.fp64_block(a, 0.2)["achieved"] is None
+
+
+def _full_size_result():
+    """Round 4's own 20 KB line (profiles/r04_bench.json.log — the one the driver could not parse) as the emitter's input,
+    plus the fields later rounds added."""
+    with open(os.path.join(ROOT, "profiles", "r04_bench.json.log")) as f:
+        full = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1])
+    assert len(json.dumps(full)) > 16000 and len(full["secondary"]) >= 12
+    for i, e in enumerate(full["secondary"]):               # later rounds key their entries
+        e.setdefault("key", f"entry_{i}")
+    full.update(per_rank_ms_per_step=[0.1786] * 8, per_rank_value=[5.73e6] * 8, ranks_seen=8, barrier_backend="nccl",
+                library_sha="0123456789abcdef")
+    return full
+
+
+def test_last_line_is_compact_and_complete(tmp_path, capsys):
+    """The driver parses the LAST stdout line: it must be one JSON object under 4 KB that carries the contract's keys and the
+    `roofline` / `cpu_baseline` objects with numbers only; the secondary entries precede it, one short line each, and the
+    full objects land in bench_secondary.json."""
+    import bench_line
+    full = _full_size_result()
+    bench_line.emit(full, str(tmp_path))
+    lines = capsys.readouterr().out.splitlines()
+    assert all(len(l) < bench_line.SECONDARY_LINE_LIMIT for l in lines[:-1]) and len(lines) == len(full["secondary"]) + 1
+    last = lines[-1]
+    assert len(last) < bench_line.COMPACT_LIMIT == 4096
+    out = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["value"] == float(f"{full['value']:.6g}") and out["config"]["workload"]
+    r = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg", "hbm_frac_measured", "frac_overlapped"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    c = out["cpu_baseline"]
+    assert c["cores"] == 1 and c["kind"] == "port" and c["value"] > 0 and c["sample"] and c["host_cpu"]
+    assert out["cpu_baseline_all_cores"]["cores"] >= 1 and out["pose_delta_vs_cpu"]["n_tracked_equal"] is True
+    assert len(out["per_rank_ms_per_step"]) == len(out["per_rank_value"]) == out["ranks_seen"] == 8
+    # no prose anywhere in the line: no *_note keys, no string longer than the workload's 160 characters
+
+    def walk(o, key=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                assert k != "note" and not k.endswith("_note"), k
+                walk(v, k)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v, key)
+        elif isinstance(o, str):
+            assert len(o) <= 160, (key, len(o))
+    walk(out)
+    # the secondary entries: one keyed line each, and the file holds the full objects
+    keys = [json.loads(l)["secondary"] for l in lines[:-1]]
+    assert len(set(keys)) == len(keys)
+    with open(tmp_path / bench_line.SECONDARY_FILE) as f:
+        d = json.load(f)
+    assert len(d["secondary"]) == len(full["secondary"]) and "roofline" in d["headline"]
+    assert out["secondary"]["entries"] == len(full["secondary"]) and out["secondary"]["file"] == bench_line.SECONDARY_FILE
+
+
+def test_compact_line_sheds_extras_but_never_the_required_objects():
+    import bench_line
+    full = _full_size_result()
+    for i in range(200):                                    # far more secondary entries than any run produces
+        full["secondary"].append({"key": f"extra_entry_number_{i}", "value": 1.0 + i, "unit": "x/s"})
+    line = bench_line.compact_line(full)
+    out = json.loads(line)
+    assert len(line) < 4096 and "roofline" in out and "cpu_baseline" in out and out["secondary"]["entries"] == len(full["secondary"])
+    assert "values" not in out["secondary"]
+    # a result whose required part alone cannot fit is a bug, reported as such
+    full["config"]["workload"] = "x" * 100
+    full["roofline"] = {k: "y" * 150 for k in bench_line.ROOFLINE_KEYS}
+    full["cpu_baseline"] = {k: "z" * 120 for k in bench_line.CPU_KEYS}
+    full["metric"] = "m" * 1500
+    try:
+        bench_line.compact_line(full)
+    except AssertionError as e:
+        assert "limit 4096" in str(e)
+    else:
+        raise AssertionError("an oversized line must not be printed")

@@ -74,6 +74,9 @@ def test_bench_gpus_flag_spawns_one_worker_per_rank():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["pairs_per_step_all_ranks"] == 2048
     assert out["value"] is None and "stub" in out["data"]          # never mistaken for a measurement
+    # one entry per rank, gathered after the timed region (all_gather over the process group)
+    assert out["ranks_seen"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and out["barrier_backend"] == "gloo"
+    assert len(lines[0]) < 4096
 
 
 def test_bench_refuses_a_world_that_contradicts_the_flag():
@@ -97,3 +100,4 @@ def test_bench_under_the_drivers_launcher():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["pairs_per_step_all_ranks"] == 2048 and out["value"] is None
+    assert out["ranks_seen"] == 2 and len(out["per_rank_ms_per_step"]) == 2
