@@ -22,6 +22,21 @@
 #endif
 
 /* ===================================================================================
+ * Mutation switches (oracle/mutants.h): with -DORACLE_MUTANTS (make mutants -> liboracle_mut.so) every quirk
+ * of SURVEY.md §8.1 can be "fixed" one at a time at run time, so that the parity suite can show it notices
+ * (tests/test_mutants_*.py). In the faithful build MUT(x) is the constant 0 and none of this exists.
+ * =================================================================================== */
+#include "mutants.h"
+#ifdef ORACLE_MUTANTS
+static int oracle_mutant = MUT_NONE;
+void oracle_set_mutant(int id) { oracle_mutant = id; }
+int oracle_get_mutant(void) { return oracle_mutant; }
+#define MUT(id) (oracle_mutant == (id))
+#else
+#define MUT(id) 0
+#endif
+
+/* ===================================================================================
  * Sophus (non-templated) SE3 / SO3 and the Eigen quaternion operations they use.
  * Third-party, not under /root/reference; restated from the published implementation
  * (sophus/so3.cpp, sophus/se3.cpp of the strasdat/Sophus "a621ff" lineage that SVO and
@@ -298,23 +313,26 @@ typedef struct {
 static void get_jacobian_mat(const dsdtm_pyramid* ref, const dsdtm_camera* cam,
                              const float* px_xy, const double* bearing, const double* p_world,
                              const uint8_t* initial, int n_features,
-                             const double ref_cnt[3], int level, level_cache* c) {
+                             const double ref_cnt[3], const oracle_se3* T_ref, int level, level_cache* c) {
+    (void)T_ref;
     const uint8_t* img = ref->data[level];
     const int cols = ref->width[level], rows = ref->height[level];
     const float tScale = (float)(1.0 / (1 << level));          /* :65 */
     const int tRefStep = ref->stride[level];                   /* :66 */
     const int boarder = (int)(0.5 * 4 + 1);                    /* :67, mHalf_PatchSize = 4 */
-    const float tFocalth = cam->f;                             /* :70 */
+    const float tFocalth = MUT(MUT_Q1_FX) ? cam->fx : cam->f;  /* :70 */
+    const int po = MUT(MUT_Q4_SHIFT) ? 1 : 2;                  /* patch spans -po .. 3-po from floor(px): -2..+1 (:143) */
 
     double* pts = (double*)malloc(sizeof(double) * 2 * (size_t)(n_features > 0 ? n_features : 1));
     double* depth_pts = (double*)malloc(sizeof(double) * 3 * (size_t)(n_features > 0 ? n_features : 1));
     int tNum = 0;
     for (int i = 0; i < n_features; ++i) {                     /* :84-103 */
-        if (!initial[i]) continue;
+        if (!initial[i] && !MUT(MUT_Q3_INITIAL)) continue;
         double px = (double)px_xy[2 * i] * tScale;             /* float mpx -> double, * float scale */
         double py = (double)px_xy[2 * i + 1] * tScale;
         const double* P = p_world + 3 * i;
         int is_zero = (P[0] == 0.0 && P[1] == 0.0 && P[2] == 0.0); /* isZero(0) */
+        if (MUT(MUT_Q3_ZERO)) is_zero = 0;
         if (is_zero || px - boarder < 0 || py - boarder < 0 ||
             px + boarder >= cols || py + boarder >= rows)
             continue;
@@ -334,6 +352,7 @@ static void get_jacobian_mat(const dsdtm_pyramid* ref, const dsdtm_camera* cam,
         double dz_ = depth_pts[3 * j + 2] - ref_cnt[2];
         double depth = sqrt(dx_ * dx_ + dy_ * dy_ + dz_ * dz_);
         c->normals[3 * j] *= depth; c->normals[3 * j + 1] *= depth; c->normals[3 * j + 2] *= depth;
+        if (MUT(MUT_Q6_TREF)) oracle_se3_act(T_ref, depth_pts + 3 * j, c->normals + 3 * j);   /* "fixed": X = T_ref * P_w */
 
         /* :123-132 bilinear coefficients */
         const double u = pts[2 * j], v = pts[2 * j + 1];
@@ -347,7 +366,7 @@ static void get_jacobian_mat(const dsdtm_pyramid* ref, const dsdtm_camera* cam,
 
         int tNum1 = 0;
         for (int i = 0; i < 4; ++i) {                          /* :141-162 */
-            const uint8_t* it = img + (fv - 2 + i) * tRefStep + (fu - 2);
+            const uint8_t* it = img + (fv - po + i) * tRefStep + (fu - po);
             for (int k = 0; k < 4; ++k, ++it, ++tNum1) {
                 c->ref_patch[j * 16 + tNum1] =
                     w00 * it[0] + w01 * it[1] + w10 * it[tRefStep] + w11 * it[tRefStep + 1];
@@ -355,6 +374,10 @@ static void get_jacobian_mat(const dsdtm_pyramid* ref, const dsdtm_camera* cam,
                                    (w00 * it[-1] + w01 * it[0] + w10 * it[tRefStep - 1] + w11 * it[tRefStep]));
                 double dy = 0.5 * ((w00 * it[tRefStep] + w01 * it[tRefStep + 1] + w10 * it[2 * tRefStep] + w11 * it[2 * tRefStep + 1]) -
                                    (w00 * it[-tRefStep] + w01 * it[-tRefStep + 1] + w10 * it[0] + w11 * it[1]));
+                if (MUT(MUT_Q5_RAWGRAD)) {                     /* "fixed": central differences of the raw pixels */
+                    dx = 0.5 * ((double)it[1] - (double)it[-1]);
+                    dy = 0.5 * ((double)it[tRefStep] - (double)it[-tRefStep]);
+                }
                 double* Jrow = c->jac + ((size_t)j * 16 + tNum1) * 6;
                 for (int q = 0; q < 6; ++q)                    /* :160 */
                     Jrow[q] = (dx * Jt[q] + dy * Jt[6 + q]) * tFocalth * tScale;
@@ -371,7 +394,8 @@ static double compute_residuals(const oracle_se3* T, const dsdtm_pyramid* cur, c
     const uint8_t* img = cur->data[level];
     const int cols = cur->width[level], rows = cur->height[level];
     const float tScale = (float)(1.0 / (1 << level));          /* :244 */
-    const int mnboarder = 4 - 1;                               /* :245 */
+    const int mnboarder = MUT(MUT_Q3_TIGHT) ? 2 : 4 - 1;       /* :245 */
+    const int po = MUT(MUT_Q4_SHIFT) ? 1 : 2;                  /* :278 */
     const int tStep = cur->stride[level];                      /* :272 */
     double chi2 = 0.0;
     int tResNum = 0;
@@ -387,6 +411,7 @@ static double compute_residuals(const oracle_se3* T, const dsdtm_pyramid* cur, c
         if (u_i < 0 || v_i < 0 || u_i - mnboarder < 0 || v_i - mnboarder < 0 ||
             u_i + mnboarder >= cols || v_i + mnboarder >= rows)
             continue;                                          /* :262 */
+        if (MUT(MUT_Q3_ZTEST) && !(p[2] > 0.0)) continue;      /* "fixed": points behind the camera are not visible */
         /* NaN pixel coordinates: floor(NaN)->int is UB in the reference; treat as not visible */
         if (!(u == u) || !(v == v)) continue;
         const double su = u - u_i, sv = v - v_i;
@@ -398,7 +423,7 @@ static double compute_residuals(const oracle_se3* T, const dsdtm_pyramid* cur, c
         int tNum = 0;
         for (int i = 0; i < 4; ++i) {
             /* :278 — rows indexed with `cols`, the +1 row neighbour with `step` (quirk Q7) */
-            const uint8_t* it = img + (v_i + i - 2) * cols + u_i - 2;
+            const uint8_t* it = img + (v_i + i - po) * cols + u_i - po;
             for (int j = 0; j < 4; ++j, ++it, ++tNum) {
                 double tCurPx = tl * it[0] + trw * it[1] + bl * it[tStep] + br * it[tStep + 1];
                 double res = -(c->ref_patch[tPtnum + tNum] - tCurPx);
@@ -413,6 +438,7 @@ static double compute_residuals(const oracle_se3* T, const dsdtm_pyramid* cur, c
         }
         (*tnPts)++;
     }
+    if (MUT(MUT_Q9_SUM)) return chi2;                          /* "fixed": not normalised by the visible pixel count */
     return chi2 / tResNum;                                     /* :298 (0/0 -> NaN) */
 }
 
@@ -420,7 +446,7 @@ static double compute_residuals(const oracle_se3* T, const dsdtm_pyramid* cur, c
 static void gauss_newton(oracle_se3* T, const dsdtm_pyramid* cur, const dsdtm_camera* cam, int level,
                          const level_cache* c, int max_iters, int* tnPts, dsdtm_align_stats* stats) {
     int stop = 0;
-    const double eps = 1e-8;
+    const double eps = MUT(MUT_Q9_EPS) ? 1e-6 : 1e-8;
     double chi2 = 0.0;
     oracle_se3 Told = *T;
     int iters = 0, exit_code = 0;
@@ -432,13 +458,15 @@ static void gauss_newton(oracle_se3* T, const dsdtm_pyramid* cur, const dsdtm_ca
         iters++;
         oracle_ldlt6_solve(H, JRes, x);                        /* :318 */
         if (isnan(x[0])) stop = 1;                             /* :321-326 */
-        if ((i > 0 && chi2New > chi2) || stop) {               /* :328-332 */
+        if ((i > 0 && (MUT(MUT_Q9_GE) ? chi2New >= chi2 : chi2New > chi2)) || stop) {   /* :328-332 */
             *T = Told;
             exit_code = stop ? 3 : 1;
             break;
         }
         oracle_se3 dT, Tnew;
         oracle_se3_exp(x, &dT);
+        if (MUT(MUT_Q8_LEFT)) oracle_se3_mul(&dT, T, &Tnew);   /* "fixed": left-multiplied update */
+        else
         oracle_se3_mul(T, &dT, &Tnew);                         /* :335 right-multiply */
         Told = *T;
         *T = Tnew;
@@ -469,6 +497,11 @@ int oracle_sparse_align(const dsdtm_pyramid* ref, const dsdtm_pyramid* cur, cons
         return DSDTM_ERR_INVALID;
     if (stats) memset(stats, 0, sizeof *stats);
     *n_tracked = 0;
+    if (MUT(MUT_Q10_MINFTS)) {                                 /* "fixed": only initialised features count */
+        int ni = 0;
+        for (int i = 0; i < n_features; ++i) ni += initial[i] ? 1 : 0;
+        if (ni < prm->min_fts) return DSDTM_OK;
+    }
     if (n_features < prm->min_fts) return DSDTM_OK;            /* :34-38 "Too few features" */
 
     oracle_se3 Tc, Tr, TrInv, T;
@@ -488,8 +521,10 @@ int oracle_sparse_align(const dsdtm_pyramid* ref, const dsdtm_pyramid* cur, cons
 
     int mnPts = 0;
     for (int lvl = prm->max_level - 1; lvl >= prm->min_level; --lvl) {      /* :45-55 */
-        get_jacobian_mat(ref, cam, px_xy, bearing, p_world, initial, n_features, ref_cnt, lvl, &c);
-        gauss_newton(&T, cur, cam, lvl, &c, prm->max_iters, &mnPts, stats);
+        get_jacobian_mat(ref, cam, px_xy, bearing, p_world, initial, n_features, ref_cnt, &Tr, lvl, &c);
+        int lvlPts = 0;
+        gauss_newton(&T, cur, cam, lvl, &c, prm->max_iters, &lvlPts, stats);
+        if (!(MUT(MUT_Q10_COARSE) && lvl != prm->max_level - 1)) mnPts = lvlPts;   /* "fixed": the coarsest level's count */
     }
     oracle_se3 Tout;
     oracle_se3_mul(&T, &Tr, &Tout);                            /* :57 */
@@ -562,9 +597,17 @@ static inline float a2d_px(const uint8_t* img, long off, long size) {
     return (off >= 0 && off < size) ? (float)img[off] : 0.0f;
 }
 
+#ifdef ORACLE_MUTANTS
+static int align2d_in_double(const uint8_t* img, int width, int height, int stride,
+                             const uint8_t* border, const uint8_t* patch, int max_iters, double px[2]);
+#endif
+
 int oracle_align2d(const uint8_t* img, int width, int height, int stride,
                    const uint8_t* border, const uint8_t* patch, int max_iters, double px[2]) {
     enum { HP = 4, PS = 8, LPS = 10 };
+#ifdef ORACLE_MUTANTS
+    if (MUT(MUT_A1_DOUBLE)) return align2d_in_double(img, width, height, stride, border, patch, max_iters, px);
+#endif
     const long img_size = (long)stride * height;
     float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Hinv[9];
     float dxs[PS * PS], dys[PS * PS];
@@ -594,6 +637,7 @@ int oracle_align2d(const uint8_t* img, int width, int height, int stride,
         int u_r = (int)floor(u);
         int v_r = (int)floor(v);
         if (u_r < HP || v_r < HP || u_r > width - HP || v_r > height - HP) break;
+        if (MUT(MUT_A3_STRICT) && (u_r >= width - HP || v_r >= height - HP)) break;   /* "fixed": footprint inside the image */
         float subpix_x = u - u_r;
         float subpix_y = v - v_r;
         float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));  /* double arithmetic, :373 */
@@ -605,14 +649,20 @@ int oracle_align2d(const uint8_t* img, int width, int height, int stride,
         int q = 0;
         for (int j = 0; j < PS; ++j) {
             long it = (long)(v_r + j - HP) * stride + u_r - HP;             /* :383 */
+            float row[3] = {0, 0, 0};                                       /* only used by MUT_A1_ROWSUMS */
             for (int k = 0; k < PS; ++k, ++it, ++it_ref, ++q) {
                 float tSearchPx = wTL * a2d_px(img, it, img_size) + wTR * a2d_px(img, it + 1, img_size) +
                                   wBL * a2d_px(img, it + stride, img_size) + wBR * a2d_px(img, it + stride + 1, img_size);
-                float tRes = tSearchPx - *it_ref + mean_diff;
+                float tRes = tSearchPx - *it_ref + (MUT(MUT_A4_NOMEAN) ? 0.0f : mean_diff);
+                if (MUT(MUT_A1_ROWSUMS)) {       /* "parallelised": per-row partial sums, then the rows (float is not associative) */
+                    row[0] -= tRes * dxs[q]; row[1] -= tRes * dys[q]; row[2] -= tRes;
+                    continue;
+                }
                 Jres[0] -= tRes * dxs[q];
                 Jres[1] -= tRes * dys[q];
                 Jres[2] -= tRes;
             }
+            if (MUT(MUT_A1_ROWSUMS)) { Jres[0] += row[0]; Jres[1] += row[1]; Jres[2] += row[2]; }
         }
         float upd[3];
         for (int a = 0; a < 3; ++a)                            /* :395 Hinv*Jres */
@@ -622,10 +672,67 @@ int oracle_align2d(const uint8_t* img, int width, int height, int stride,
         mean_diff += upd[2];
         if (upd[0] * upd[0] + upd[1] * upd[1] < min_update_squared) { converged = 1; break; }
     }
+    if (MUT(MUT_A4_NOWRITE) && !converged) return converged;   /* "fixed": px untouched on failure */
     px[0] = u;                                                 /* :414 written back always */
     px[1] = v;
     return converged;
 }
+
+#ifdef ORACLE_MUTANTS
+/* MUT_A1_DOUBLE: the same algorithm with every float of the reference promoted to double (quirk A1 "fixed") */
+static int align2d_in_double(const uint8_t* img, int width, int height, int stride,
+                             const uint8_t* border, const uint8_t* patch, int max_iters, double px[2]) {
+    enum { HP = 4, PS = 8, LPS = 10 };
+    const long img_size = (long)stride * height;
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Hinv[9];
+    double dxs[PS * PS], dys[PS * PS];
+    int n = 0;
+    for (int l = 0; l < PS; ++l) {
+        const uint8_t* it = border + (l + 1) * LPS + 1;
+        for (int i = 0; i < PS; ++i, ++it, ++n) {
+            double J[3] = {0.5 * (it[1] - it[-1]), 0.5 * (it[LPS] - it[-LPS]), 1.0};
+            dxs[n] = J[0];
+            dys[n] = J[1];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) H[a * 3 + b] += J[a] * J[b];
+        }
+    }
+    {   /* cofactor inverse, as mat3f_inverse */
+        double c0 = H[4] * H[8] - H[5] * H[7], c1 = H[7] * H[2] - H[8] * H[1], c2 = H[1] * H[5] - H[2] * H[4];
+        double invdet = 1.0 / (c0 * H[0] + (c1 * H[3] + c2 * H[6]));
+        Hinv[0] = c0 * invdet; Hinv[1] = c1 * invdet; Hinv[2] = c2 * invdet;
+        Hinv[3] = (H[5] * H[6] - H[3] * H[8]) * invdet; Hinv[4] = (H[8] * H[0] - H[6] * H[2]) * invdet; Hinv[5] = (H[2] * H[3] - H[0] * H[5]) * invdet;
+        Hinv[6] = (H[3] * H[7] - H[4] * H[6]) * invdet; Hinv[7] = (H[6] * H[1] - H[7] * H[0]) * invdet; Hinv[8] = (H[0] * H[4] - H[1] * H[3]) * invdet;
+    }
+    double mean_diff = 0.0, u = px[0], v = px[1];
+    int converged = 0;
+    for (int it_n = 0; it_n < max_iters; ++it_n) {
+        if (isnan(u) || isnan(v)) break;
+        int u_r = (int)floor(u), v_r = (int)floor(v);
+        if (u_r < HP || v_r < HP || u_r > width - HP || v_r > height - HP) break;
+        double sx = u - u_r, sy = v - v_r;
+        double wTL = (1.0 - sx) * (1.0 - sy), wTR = sx * (1.0 - sy), wBL = (1.0 - sx) * sy, wBR = sx * sy;
+        double Jres[3] = {0, 0, 0};
+        const uint8_t* it_ref = patch;
+        int q = 0;
+        for (int j = 0; j < PS; ++j) {
+            long it = (long)(v_r + j - HP) * stride + u_r - HP;
+            for (int k = 0; k < PS; ++k, ++it, ++it_ref, ++q) {
+                double s = wTL * a2d_px(img, it, img_size) + wTR * a2d_px(img, it + 1, img_size) +
+                           wBL * a2d_px(img, it + stride, img_size) + wBR * a2d_px(img, it + stride + 1, img_size);
+                double r = s - *it_ref + mean_diff;
+                Jres[0] -= r * dxs[q]; Jres[1] -= r * dys[q]; Jres[2] -= r;
+            }
+        }
+        double upd[3];
+        for (int a = 0; a < 3; ++a) upd[a] = (Hinv[a * 3] * Jres[0] + Hinv[a * 3 + 1] * Jres[1]) + Hinv[a * 3 + 2] * Jres[2];
+        u += upd[0]; v += upd[1]; mean_diff += upd[2];
+        if (upd[0] * upd[0] + upd[1] * upd[1] < 0.03 * 0.03) { converged = 1; break; }
+    }
+    px[0] = u; px[1] = v;
+    return converged;
+}
+#endif
 
 int oracle_align2d_batch(const dsdtm_pyramid* cur, const uint8_t* patch_border, const uint8_t* patch,
                          const int32_t* level, double* px_xy, uint8_t* converged, int max_iters, int m) {
@@ -746,7 +853,7 @@ int oracle_warp_patches(const dsdtm_pyramid* kf_pyr, int n_kf, const dsdtm_camer
         /* --- GetBestSearchLevel :192-204 --- */
         int tSearch_Level = 0;
         double D = A[0] * A[3] - A[1] * A[2];
-        while (D > 3.0 && tSearch_Level < max_search_level) { tSearch_Level++; D = D * 0.25; }
+        while (D > (MUT(MUT_A13_DET) ? 2.0 : 3.0) && tSearch_Level < max_search_level) { tSearch_Level++; D = D * 0.25; }
         search_level[c] = tSearch_Level;
         /* --- WarpAffine :206-259 --- */
         /* Matrix2d::inverse(): Eigen compute_inverse size 2: invdet = 1/det; [d -b; -c a]*invdet */
@@ -757,15 +864,17 @@ int oracle_warp_patches(const dsdtm_pyramid* kf_pyr, int n_kf, const dsdtm_camer
         const dsdtm_pyramid* pyr = &kf_pyr[k];
         const uint8_t* img = pyr->data[tLevel];
         const int cols = pyr->width[tLevel], rows = pyr->height[tLevel], tStep = pyr->stride[tLevel];
-        const float refx = rx / (float)(1 << tLevel), refy = ry / (float)(1 << tLevel);   /* :215-216 */
+        float refx = rx / (float)(1 << tLevel), refy = ry / (float)(1 << tLevel);   /* :215-216 */
+        if (MUT(MUT_W2_REFLEVEL)) { refx = rx; refy = ry; }    /* "fixed" the other way: level-0 pixel on the level image */
         const int int_scale = 1 / (1 << tSearch_Level);       /* :231 integer division bug W1 */
         uint8_t* out = patch_border + 100 * (size_t)c;
         int j = 0;
         for (int iy = -5; iy < 5; ++iy) {
             for (int ix = -5; ix < 5; ++ix, ++j) {
                 /* tWrapMat = tA_r2c*tWrapMat*(1/(1<<lvl)): (A*g) then * float(int) */
-                float gx = (Ai[0] * (float)ix + Ai[1] * (float)iy) * (float)int_scale;
-                float gy = (Ai[2] * (float)ix + Ai[3] * (float)iy) * (float)int_scale;
+                const float wscale = MUT(MUT_W1_FLOATDIV) ? 1.0f / (float)(1 << tSearch_Level) : (float)int_scale;
+                float gx = (Ai[0] * (float)ix + Ai[1] * (float)iy) * wscale;
+                float gy = (Ai[2] * (float)ix + Ai[3] * (float)iy) * wscale;
                 float wx = gx + refx, wy = gy + refy;          /* :232 */
                 int fx_ = (int)floor((double)wx), fy_ = (int)floor((double)wy);   /* Eigenfloor(double) */
                 float sx = wx - (float)fx_, sy = wy - (float)fy_;
@@ -783,7 +892,7 @@ int oracle_warp_patches(const dsdtm_pyramid* kf_pyr, int n_kf, const dsdtm_camer
                     float p00 = img[o], p01 = (o + tStep < sz) ? img[o + tStep] : 0.0f;
                     float p10 = (o + 1 < sz) ? img[o + 1] : 0.0f, p11 = (o + tStep + 1 < sz) ? img[o + tStep + 1] : 0.0f;
                     float val = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
-                    out[j] = (uint8_t)val;                     /* float -> uchar truncation :254 */
+                    out[j] = MUT(MUT_W2_ROUND) ? (uint8_t)(val + 0.5f) : (uint8_t)val;   /* float -> uchar truncation :254 */
                 }
             }
         }

@@ -1,0 +1,52 @@
+/*
+ * mutants.h — one identifier per quirk of SURVEY.md §8.1 that the mutation build of the oracle
+ * (make -C oracle mutants -> _build/liboracle_mut.so, -DORACLE_MUTANTS) can "fix" at run time with
+ * oracle_set_mutant(id). TEST INFRASTRUCTURE ONLY: tests/test_mutants_cpu.py shows each mutant differs
+ * from the faithful restatement on the committed fixtures, tests/test_mutants_gpu.py that the HIP path
+ * agrees with the faithful build and disagrees with every mutant. The faithful liboracle.so contains
+ * none of this (MUT(x) == 0 at compile time). Citations: /root/reference/src/... lines of the quirk.
+ */
+#ifndef DSDTM_ORACLE_MUTANTS_H
+#define DSDTM_ORACLE_MUTANTS_H
+
+enum oracle_mutant_id {
+    MUT_NONE = 0,
+    /* sparse alignment — src/Sprase_ImageAlign.cpp */
+    MUT_Q1_FX = 1,        /* :70,160  Jacobian scale from fx instead of the single focal Camera.f          */
+    MUT_Q3_TIGHT = 2,     /* :245,262 current-side border 2 (the footprint) instead of mnboarder = 3        */
+    MUT_Q3_ZTEST = 3,     /* :254-262 a z > 0 visibility test the reference does not have                    */
+    MUT_Q3_INITIAL = 4,   /* :86      features with !mbInitial not skipped                                   */
+    MUT_Q3_ZERO = 5,      /* :93-100  map points that are exactly zero not skipped                           */
+    MUT_Q4_SHIFT = 6,     /* :143,278 patch spans -1..+2 instead of -2..+1 from floor(px)                    */
+    MUT_Q5_RAWGRAD = 7,   /* :150-158 gradients of the raw pixels instead of the interpolated image          */
+    MUT_Q6_TREF = 8,      /* :117-119 X = T_ref * P_w instead of bearing * |P_w - C_ref|                     */
+    MUT_Q8_LEFT = 9,      /* :335     T <- exp(x) * T instead of T * exp(x)                                  */
+    MUT_Q9_GE = 10,       /* :328     revert on chi2New >= chi2 instead of >                                 */
+    MUT_Q9_SUM = 11,      /* :298     chi2 not divided by the visible pixel count                            */
+    MUT_Q9_EPS = 12,      /* :305,341 exit at max|x| <= 1e-6 instead of 1e-8                                 */
+    MUT_Q10_COARSE = 13,  /* :59      returned count taken at the coarsest level instead of the finest       */
+    MUT_Q10_MINFTS = 14,  /* :34      Min_fts compared with the initialised features only                    */
+    /* Align2D — src/Feature_alignment.cpp:318-417 */
+    MUT_A1_DOUBLE = 20,   /* :330-398 double arithmetic instead of float                                     */
+    MUT_A1_ROWSUMS = 21,  /* :386-392 Jres summed row by row and then over rows, not in one raster-order chain    */
+    MUT_A3_STRICT = 22,   /* :367-368 u_r == cols-4 / v_r == rows-4 rejected                                 */
+    MUT_A4_NOWRITE = 23,  /* :414     px not written back when the alignment fails                           */
+    MUT_A4_NOMEAN = 24,   /* :386     no mean-offset term in the residual                                    */
+    /* warp prelude — src/Feature_alignment.cpp:160-275 */
+    MUT_W1_FLOATDIV = 30, /* :231     1.0f/(1<<level) instead of the integer division                        */
+    MUT_W2_ROUND = 31,    /* :254     rounding instead of truncation to u8                                   */
+    MUT_W2_REFLEVEL = 32, /* :215-216 reference pixel not divided by its level's scale                       */
+    MUT_A13_DET = 33      /* :198     search level raised at det > 2 instead of det > 3                      */
+};
+
+#ifdef ORACLE_MUTANTS
+#ifdef __cplusplus
+extern "C" {
+#endif
+void oracle_set_mutant(int id);
+int oracle_get_mutant(void);
+#ifdef __cplusplus
+}
+#endif
+#endif
+#endif

@@ -5,6 +5,7 @@ product package.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -44,19 +45,7 @@ def build(native: bool = False):
     subprocess.run(["make", "-s", "-C", _ORACLE_DIR] + (["native", "NATIVE_TAG=" + _cpu_tag()] if native else []), check=True)
 
 
-def load(native: bool = False):
-    key = "native" if native else "ref"
-    if key in _LIBS:
-        return _LIBS[key]
-    name = f"liboracle_native_{_cpu_tag()}.so" if native else "liboracle.so"
-    path = os.path.join(_ORACLE_DIR, "_build", name)
-    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("dsdtm_oracle.c", "pose_opt_oracle.c", "dsdtm_oracle.h")]
-    override = os.environ.get("DSDTM_ORACLE_LIB")       # the sanitizer job (tests/test_sanitizers_cpu.py) runs the oracle's own
-    if override and not native:                          # CPU tests against an ASan/UBSan build of the same sources
-        path = override
-    elif not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
-        build(native)
-    lib = C.CDLL(path)
+def _declare(lib):
     capi.declare_signatures(lib, "oracle_", with_ctx=False)
     dp = C.POINTER(C.c_double)
     lib.oracle_align2d.restype = C.c_int
@@ -89,6 +78,22 @@ def load(native: bool = False):
     lib.oracle_pose_plus.argtypes = [dp, dp, dp]
     lib.oracle_chol6_solve.restype = C.c_int
     lib.oracle_chol6_solve.argtypes = [dp, dp, dp]
+
+
+def load(native: bool = False):
+    key = "native" if native else "ref"
+    if key in _LIBS:
+        return _LIBS[key]
+    name = f"liboracle_native_{_cpu_tag()}.so" if native else "liboracle.so"
+    path = os.path.join(_ORACLE_DIR, "_build", name)
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("dsdtm_oracle.c", "pose_opt_oracle.c", "dsdtm_oracle.h")]
+    override = os.environ.get("DSDTM_ORACLE_LIB")       # the sanitizer job (tests/test_sanitizers_cpu.py) runs the oracle's own
+    if override and not native:                          # CPU tests against an ASan/UBSan build of the same sources
+        path = override
+    elif not os.path.exists(path) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
+        build(native)
+    lib = C.CDLL(path)
+    _declare(lib)
     _LIBS[key] = lib
     return lib
 
@@ -118,6 +123,43 @@ def pose_optimization(bearing, p_world, level, use, T_cur_w, max_iterations=100,
     if trace:
         out += (tr[:d["iterations"] + 1].copy(),)
     return out
+
+
+# ---- the mutation build (oracle/mutants.h): the quirks of SURVEY.md §8.1 "fixed" one at a time ----
+def _mutant_ids():
+    """{name: id} parsed from oracle/mutants.h (one source of truth for the C build and the tests)."""
+    import re
+    with open(os.path.join(_ORACLE_DIR, "mutants.h")) as f:
+        return {m.group(1): int(m.group(2)) for m in re.finditer(r"^\s*(MUT_[A-Z0-9_]+)\s*=\s*(\d+)", f.read(), re.M)}
+
+
+MUTANTS = _mutant_ids()
+
+
+def load_mutants():
+    if "mut" not in _LIBS:
+        subprocess.run(["make", "-s", "-C", _ORACLE_DIR, "mutants"], check=True)
+        lib = C.CDLL(os.path.join(_ORACLE_DIR, "_build", "liboracle_mut.so"))
+        _declare(lib)
+        lib.oracle_set_mutant.argtypes = [C.c_int]
+        lib.oracle_get_mutant.restype = C.c_int
+        _LIBS["mut"] = lib
+    return _LIBS["mut"]
+
+
+@contextlib.contextmanager
+def mutant(name_or_id):
+    """Every wrapper of this module runs on the mutation build with ONE quirk switched inside the block
+    (MUT_NONE / 0: the mutation build with nothing switched — must equal the faithful library bit for bit)."""
+    mid = MUTANTS[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+    lib, faithful = load_mutants(), load()
+    lib.oracle_set_mutant(mid)
+    _LIBS["ref"] = lib
+    try:
+        yield lib
+    finally:
+        lib.oracle_set_mutant(0)
+        _LIBS["ref"] = faithful
 
 
 # ---- the reference's own FAST build (oracle/_ref/libfast_ref.so, `make -C oracle ref`) ------------

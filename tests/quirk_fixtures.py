@@ -1,0 +1,216 @@
+"""Inputs built to EXERCISE every quirk of SURVEY.md §8.1, and the comparators the parity suite uses on them.
+
+The reference holds no vectors for this path, so nothing external can show that the suite would notice a wrong
+restatement of one of its quirks. These fixtures + oracle/mutants.h do it from the inside: each quirk has a mutant of the
+oracle that "fixes" it, tests/test_mutants_cpu.py shows every mutant changes the outputs below by more than the
+suite's tolerances, tests/test_mutants_gpu.py that the HIP path agrees with the faithful oracle and with no mutant.
+The arrays are committed as tests/golden/quirks.npz (tests/golden/make_golden_quirks.py writes it from this module).
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+from dsdtm_amd import synth
+from tests import helpers
+
+ALIGN_PARAMS = (3, 0, 10)          # (max_level, min_level, max_iters) of every sparse case below
+TOL = 10 * helpers.TIGHT_RAD       # the suite's FP64 pose tolerance (tests/test_sparse_align_gpu.py): 1e-8 rad / m
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sparse alignment cases: {name: (scene, params, min_fts, T_seed or None)}
+# ---------------------------------------------------------------------------------------------------------------
+def base_scene():
+    """320x240, 3 levels, 160 features on a textured plane, with everything §8.1 singles out present at once:
+    uninitialised features (Q3), map points that are exactly zero (Q3), features 3.1-3.6 px (x 2^level) from every border
+    so that some cross the current-side border test during the iterations (Q3, Q10), map points that a bundle adjustment
+    moved off their feature's ray (Q6: bearing * |P - C| != T_ref * P), f = 525 against fx = 517.3 (Q1)."""
+    sc = copy.deepcopy(synth.make_scene(width=320, height=240, levels=3, n_patches=160, seed=0x51C, margin=14,
+                                        xi=(0.012, -0.007, 0.005, 0.004, -0.003, 0.006),
+                                        T_ref_w=synth.random_pose(np.random.default_rng(77), 0.4, 0.2)))
+    rng = np.random.default_rng(0xB0D)
+    W, H = 320, 240
+    k = 0
+    for lvl in range(3):                                       # four features per side and level, just inside the ref-side test
+        s = 1 << lvl
+        for d in (3.05, 3.2, 3.4, 3.6):
+            sc.px[k] = (d * s, rng.uniform(40, 200)); k += 1
+            sc.px[k] = (W - d * s, rng.uniform(40, 200)); k += 1
+            sc.px[k] = (rng.uniform(40, 280), d * s); k += 1
+            sc.px[k] = (rng.uniform(40, 280), H - d * s); k += 1
+    sc.px = sc.px.astype(np.float32)
+    sc.bearing = synth.bearing_from_px(sc.cam, sc.px)
+    Xr = sc.bearing * (sc.depth / sc.bearing[:, 2:3])
+    Rr, tr = sc.T_ref_w[:, :3], sc.T_ref_w[:, 3]
+    # every third map point moved 1-3 cm off its ray (what LocalBundleAdjustment does to MapPoint::mPose)
+    off = rng.normal(0, 0.02, Xr.shape)
+    off[np.arange(len(Xr)) % 3 != 0] = 0.0
+    sc.p_world = (Xr + off - tr) @ Rr
+    sc.initial[:] = 1
+    sc.initial[50::7] = 0
+    sc.p_world[53::11] = 0.0
+    return sc
+
+
+def sparse_cases():
+    base = base_scene()
+    cases = {"main": (base, ALIGN_PARAMS, 15, None)}
+    # a dark current frame: every interpolated intensity is exactly 0, the residual does not depend on the pose, chi2 repeats
+    # EXACTLY from one iteration to the next — the only input on which `chi2New > chi2` (:328) and `>=` part ways
+    # (interior features only: the visible set must not change while the pose drifts)
+    dark = copy.copy(base)
+    dark.cur_pyr = [np.zeros_like(a) for a in base.cur_pyr]
+    inner = np.where((base.px[:, 0] > 60) & (base.px[:, 0] < 260) & (base.px[:, 1] > 60) & (base.px[:, 1] < 180))[0]
+    dark.px, dark.bearing, dark.p_world, dark.initial = (a[inner].copy() for a in (base.px, base.bearing, base.p_world, base.initial))
+    cases["dark"] = (dark, (3, 1, 4), 15, None)
+    # the current camera seeded looking the other way (rotation by pi about the y axis of the reference camera): every point
+    # has z < 0 and still projects into the image — the reference has no z > 0 test (:254-262)
+    Ry = np.diag([-1.0, 1.0, -1.0])
+    T4 = np.vstack([base.T_ref_w, [0, 0, 0, 1]])
+    flip = np.eye(4)
+    flip[:3, :3] = Ry
+    cases["behind"] = (base, (3, 2, 2), 15, (flip @ T4)[:3].copy())
+    # 20 features of which 8 are initialised, Min_fts = 15: Run counts ALL features (:34) and goes on
+    few = copy.copy(base)
+    sel = np.r_[60:80]
+    few.px, few.bearing, few.p_world = base.px[sel].copy(), base.bearing[sel].copy(), base.p_world[sel].copy()
+    few.initial = np.zeros(20, np.uint8)
+    few.initial[:8] = 1
+    few.p_world[few.p_world[:, 0] == 0.0] = base.p_world[0]
+    cases["minfts"] = (few, ALIGN_PARAMS, 15, None)
+    return cases
+
+
+def sparse_outputs(run, case):
+    """run(scene, max_level, min_level, max_iters, min_fts=, T_seed=) -> (T, n, stats): the oracle wrapper or the GPU helper."""
+    sc, prm, min_fts, T_seed = case
+    T, n, st = run(sc, *prm, min_fts=min_fts, T_seed=T_seed)
+    return dict(T=np.asarray(T, np.float64).copy(), n=int(n), iters=list(st["iters"]), exit_code=list(st["exit_code"]),
+                n_ref=list(st["n_ref"]), n_vis=list(st["n_vis"]), chi2=[float(x) for x in st["chi2"]])
+
+
+def sparse_first_difference(a, b, tol=TOL):
+    """The first check of the suite's parity assertions (tests/test_sparse_align_gpu.py: pose, n_tracked, iterations, exit
+    codes, n_ref / n_vis, chi2) that `b` fails against `a`; None when `b` passes them all."""
+    if a["n"] != b["n"]:
+        return "n_tracked"
+    for k in ("iters", "exit_code", "n_ref", "n_vis"):
+        if a[k] != b[k]:
+            return k
+    if not (np.all(np.isfinite(a["T"])) and np.all(np.isfinite(b["T"]))):
+        if not np.array_equal(np.isfinite(a["T"]), np.isfinite(b["T"])):
+            return "pose"
+    else:
+        ang, dt = synth.pose_error(a["T"], b["T"])
+        if not (ang <= tol and dt <= tol):
+            return "pose"
+    ca, cb = np.array(a["chi2"]), np.array(b["chi2"])
+    if not np.allclose(ca, cb, rtol=1e-9, atol=0, equal_nan=True):
+        return "chi2"
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Align2D cases
+# ---------------------------------------------------------------------------------------------------------------
+def align2d_cases():
+    """One 128x96 image, 3 levels. Rows: ordinary converging features; features under a brightness offset (the mean term, A4);
+    features whose start lies too far to converge in 10 iterations or that leave the image (failure: px still written, A4);
+    features whose window reaches u_r == cols - 4 / v_r == rows - 4 (admitted by the reference's bounds test, A3)."""
+    rng = np.random.default_rng(0xA2D)
+    tex = np.clip(np.rint(synth.make_texture(96, 128, 31)), 0, 255).astype(np.uint8)
+    pyr = synth.build_pyramid(tex, 3)
+    rows = []
+
+    def add(level, centre, start, offset=0):
+        img = pyr[level]
+        pb, p = helpers.make_border_patches(img, [centre])
+        pb = np.clip(pb[0].astype(np.int32) + offset, 0, 255).astype(np.uint8)
+        rows.append((level, pb, pb.reshape(10, 10)[1:9, 1:9].reshape(64).copy(), np.array(start, np.float64)))
+
+    for i in range(16):
+        lv = i % 2
+        h, w = pyr[lv].shape
+        c = (rng.uniform(12, w - 12), rng.uniform(12, h - 12))
+        add(lv, c, (c[0] + rng.uniform(-1.2, 1.2), c[1] + rng.uniform(-1.2, 1.2)))
+    for i in range(6):                                         # brightness offset +-25 grey levels
+        c = (rng.uniform(20, 108), rng.uniform(20, 76))
+        add(0, c, (c[0] + rng.uniform(-1.0, 1.0), c[1] + rng.uniform(-1.0, 1.0)), offset=25 if i % 2 else -25)
+    for i in range(6):                                         # hopeless starts: 6-9 px away
+        c = (rng.uniform(30, 98), rng.uniform(30, 66))
+        a = rng.uniform(0, 2 * np.pi)
+        add(0, c, (c[0] + 7.5 * np.cos(a), c[1] + 7.5 * np.sin(a)))
+    h, w = pyr[0].shape
+    for i in range(6):                                         # the admitted last column / row
+        if i % 2:
+            c = (w - 4 + 0.3 + 0.1 * i, rng.uniform(20, 70))
+        else:
+            c = (rng.uniform(20, 100), h - 4 + 0.2 + 0.1 * i)
+        add(0, (min(c[0], w - 6.0), min(c[1], h - 6.0)), c)
+    level = np.array([r[0] for r in rows], np.int32)
+    return dict(pyr=pyr, level=level, patch_border=np.array([r[1] for r in rows]), patch=np.array([r[2] for r in rows]),
+                px0=np.array([r[3] for r in rows]))
+
+
+def align2d_first_difference(a, b):
+    """a, b = (converged flags, pixels): flags and pixels must be bit-identical (tests/test_align2d_gpu.py)."""
+    if not np.array_equal(a[0], b[0]):
+        return "converged"
+    if not np.array_equal(a[1], b[1], equal_nan=True):
+        return "px"
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# warp prelude cases (SolveAffineMatrix / GetBestSearchLevel / WarpAffine / GetPatchNoBoarder)
+# ---------------------------------------------------------------------------------------------------------------
+def warp_cases():
+    """Candidates seen from a current camera at 1x, 0.62x and 0.45x of the keyframe's distance to the point: det(A) ~ 1, ~2.6
+    (between the mutant's threshold 2 and the reference's 3) and ~4.9 (search level 1, where the integer division W1 collapses
+    the warp); reference features on levels 0 and 1 (W2)."""
+    rng = np.random.default_rng(0x3A9)
+    tex = np.clip(np.rint(synth.make_texture(96, 128, 33)), 0, 255).astype(np.uint8)
+    pyr = synth.build_pyramid(tex, 3)
+    cam = synth.Camera.tum(128, 96)
+    m = 36
+    T_kf = np.array([np.eye(4)[:3], synth.random_pose(rng, 0.05, 0.03)])
+    ck = (np.arange(m) % 2).astype(np.int32)
+    rl = ((np.arange(m) // 2) % 2).astype(np.int32)
+    rp = np.stack([rng.uniform(24, 104, m), rng.uniform(24, 72, m)], 1).astype(np.float32)
+    rb = synth.bearing_from_px(cam, rp)
+    depth = rng.uniform(1.5, 2.5, m)
+    pw = np.array([T_kf[ck[i]][:, :3].T @ (rb[i] * depth[i] - T_kf[ck[i]][:, 3]) for i in range(m)])
+    # one current pose per group of 12 candidates: the camera advanced along its optical axis
+    groups = []
+    for g, frac in enumerate((1.0, 0.62, 0.45)):
+        T = np.eye(4)
+        T[:3] = synth.random_pose(rng, 0.02, 0.02)
+        T[2, 3] -= (1.0 - frac) * 2.0
+        groups.append((T[:3].copy(), np.arange(g * 12, (g + 1) * 12)))
+    return dict(pyr=pyr, cam=cam, T_kf=T_kf, groups=groups, cand_kf=ck, ref_level=rl, ref_px=rp, ref_bearing=rb, p_world=pw,
+                max_search_level=2)
+
+
+def warp_outputs(fn, w):
+    """fn(kf_pyrs, cam, T_kf_w, T_cur_w, cand_kf, ref_px, ref_level, ref_bearing, p_world, max_search_level) ->
+    (affine, search_level, patch_border, patch), per group of the fixture; concatenated."""
+    outs = []
+    for T_cur, idx in w["groups"]:
+        outs.append(fn([w["pyr"], w["pyr"]], w["cam"], w["T_kf"], T_cur, w["cand_kf"][idx], w["ref_px"][idx], w["ref_level"][idx],
+                       w["ref_bearing"][idx], w["p_world"][idx], w["max_search_level"]))
+    return tuple(np.concatenate([o[i] for o in outs]) for i in range(4))
+
+
+def warp_first_difference(a, b):
+    """affine bit-identical, levels equal, patch bytes equal (tests/test_search_gpu.py::test_warp_patches_match_oracle)."""
+    if not np.array_equal(a[1], b[1]):
+        return "search_level"
+    if not np.array_equal(a[0], b[0]):
+        return "affine"
+    if not np.array_equal(a[2], b[2]):
+        return "patch_border bytes"
+    if not np.array_equal(a[3], b[3]):
+        return "patch bytes"
+    return None

@@ -30,7 +30,7 @@ def test_bench_two_ranks_share_one_gpu():
     assert out["config"]["pairs_per_gpu"] == 64 and out["config"]["barrier_backend"] == "gloo"
     # whole-job rate: both ranks' pairs over the max-over-ranks time
     assert out["value"] is not None and out["value"] > 0
-    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-6 * out["value"]
+    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 2e-5 * out["value"]
     # rank 0's own results are sane (64 synthetic pairs converge to their ground truth)
     assert out["err_vs_ground_truth_median"]["rad"] < 1e-3 and out["n_tracked_mean"] > 250
     assert out["roofline"]["frac"] > 0
@@ -57,7 +57,7 @@ def test_bench_one_rank_over_rccl():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["config"]["barrier_backend"] == "nccl" and out["barrier_backend"] == "nccl"
     assert out["ranks_seen"] == 1 and len(out["per_rank_ms_per_step"]) == 1          # gathered on the GPU over RCCL
-    assert out["value"] > 0 and abs(out["value"] - 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-6 * out["value"]
+    assert out["value"] > 0 and abs(out["value"] - 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 2e-5 * out["value"]
 
 
 @pytest.mark.gpu
@@ -75,7 +75,7 @@ def test_bench_two_ranks_under_the_drivers_launcher():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["pairs_per_gpu"] == 64 and out["value"] > 0
-    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-6 * out["value"]
+    assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 2e-5 * out["value"]
 
 
 @pytest.mark.gpu
