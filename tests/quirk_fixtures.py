@@ -214,3 +214,62 @@ def warp_first_difference(a, b):
     if not np.array_equal(a[3], b[3]):
         return "patch bytes"
     return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SearchLocalPoints worlds (tests/test_search_gpu.py::make_world): the standard one and two dense ones whose matches hit the
+# 200-cell cap, with features down to 3 px from their level's border and 15-px cells
+# ---------------------------------------------------------------------------------------------------------------
+SEARCH_WORLDS = {
+    "std": dict(seed=3, n_points=900, cell=25),
+    "dense": dict(seed=5, n_points=2000, cell=15, obs_margin=3),
+    "dense_border": dict(seed=5, n_points=2000, cell=15, obs_margin=3, uv_margin=4),
+}
+
+
+def search_world(name):
+    """(cam, keyframes, current frame, map points, cell size) of a named world; the grid is filled by the caller."""
+    from dsdtm_amd.frame import Config
+    from tests.test_search_gpu import make_world
+    kw = dict(SEARCH_WORLDS[name])
+    Config.Set("Camera.CellSize", kw["cell"])
+    Config.Set("Camera.MaxPyraLevels", 5)
+    cam, kfs, cur, mps = make_world(kw.pop("seed"), **kw)
+    return cam, kfs, cur, mps, kw["cell"]
+
+
+def search_restated(name, mutant=None):
+    """The sequential CPU restatement (tests/search_restatement.py) on a named world: ([(cell, map point index, px, level)], mask)."""
+    from dsdtm_amd import search
+    from tests import search_restatement as SR
+    cam, kfs, cur, mps, cell = search_world(name)
+    s = search.LocalPointSearch.__new__(search.LocalPointSearch)         # the grid bookkeeping only: no GPU context
+    search.FA.Feature_Alignment.__init__(s, cam, None)
+    s.mCell_size = cell
+    s.mGrid_Rows, s.mGrid_Cols = int(np.ceil(cam.height / cell)), int(np.ceil(cam.width / cell))
+    s.mCells = [[] for _ in range(s.mGrid_Rows * s.mGrid_Cols)]
+    for mp in mps:
+        s.ReprojectPoint(cur, mp)
+    mask = np.full((cam.height, cam.width), 255, np.uint8)
+    idx = {id(mp): i for i, mp in enumerate(mps)}
+    out = SR.search_local_points(s.mCells, cur, kfs, cam, cell, 5, mask, mutant=mutant)
+    return [(int(o[0]), idx[id(o[1])], float(o[2][0]), float(o[2][1]), int(o[3])) for o in out], mask
+
+
+def search_first_difference(a, b):
+    """a, b = (match list, mask): same cells in the same order, same map point, level and refined pixel per cell, same mask
+    (tests/test_search_gpu.py::test_search_local_points_matches_sequential_reference_flow)."""
+    (la, ma), (lb, mb) = a, b
+    if len(la) != len(lb):
+        return "match count"
+    if [x[0] for x in la] != [x[0] for x in lb]:
+        return "cells"
+    if [x[1] for x in la] != [x[1] for x in lb]:
+        return "map points"
+    if [x[4] for x in la] != [x[4] for x in lb]:
+        return "search level"
+    if [x[2:4] for x in la] != [x[2:4] for x in lb]:
+        return "px"
+    if not np.array_equal(ma, mb):
+        return "mask"
+    return None

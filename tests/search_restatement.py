@@ -35,17 +35,37 @@ def circle_filled(mask, cx, cy, r):
             mask[y, max(x1, 0):min(x2, w - 1) + 1] = 0
 
 
-def search_local_points(cells, frame, keyframes, cam, cell_size, max_levels, mask):
+# The order-dependent rules of SURVEY.md §8.1 S1 / W3 "fixed" one at a time (tests/test_mutants_*.py: the parity suite must
+# tell each of these from the faithful flow)
+SEARCH_MUTANTS = {
+    "S1_SHUFFLE": "cells visited in the shuffled mCellOrder (:38-43) instead of index order (:75)",
+    "S1_NOCAP": "no stop after 200 matched cells (:80)",
+    "S1_NOSORT": "candidates of a cell not sorted by Get_FoundNums() (:88,123-126)",
+    "S1_NOMASK": "the mask test before matching dropped (:96)",
+    "S1_NOBAD": "bad map points not skipped (:93)",
+    "S1_ALLCANDS": "no break after the first success in a cell (:115)",
+    "W3_BORDER": "reference pixel kept 8 px (the grid's border, :62) instead of 5 px inside its level image (:138-140)",
+    "W3_FIRSTOBS": "the first observation instead of the closest view (src/MapPoint.cpp:148-171)",
+}
+
+
+def search_local_points(cells, frame, keyframes, cam, cell_size, max_levels, mask, mutant=None):
     """cells: list of lists of [MapPoint, px]. Returns [(cell, mp, px float32, level)]."""
+    assert mutant is None or mutant in SEARCH_MUTANTS, mutant
     out = []
     matches = 0
-    for ci, cell in enumerate(cells):
-        cell.sort(key=lambda c: -c[0].mnFound)
+    order = list(range(len(cells)))
+    if mutant == "S1_SHUFFLE":
+        np.random.default_rng(0).shuffle(order)
+    for ci in order:
+        cell = cells[ci]
+        if mutant != "S1_NOSORT":
+            cell.sort(key=lambda c: -c[0].mnFound)
         for cand in cell:
             mp, px = cand
-            if mp.mbBad:
+            if mp.mbBad and mutant != "S1_NOBAD":
                 continue
-            if mask[cv_round(px[1]), cv_round(px[0])] != 255:
+            if mask[cv_round(px[1]), cv_round(px[0])] != 255 and mutant != "S1_NOMASK":
                 continue
             # --- FindMatchDirect ---
             if not mp.mObservations:
@@ -58,12 +78,14 @@ def search_local_points(cells, frame, keyframes, cam, cell_size, max_levels, mas
                 r /= np.linalg.norm(r)
                 if float(r @ v) > best_cos:
                     best_cos, best = float(r @ v), k
+                    if mutant == "W3_FIRSTOBS":
+                        break
             if best is None or best_cos < 0.5:
                 continue
             kf = keyframes[best]
             f = mp.mObservations[best]
             rpx, rlv = kf.px[f], int(kf.level[f])
-            if not in_image(cam, rpx[0] / (1 << rlv), rpx[1] / (1 << rlv), 5, rlv):
+            if not in_image(cam, rpx[0] / (1 << rlv), rpx[1] / (1 << rlv), 8 if mutant == "W3_BORDER" else 5, rlv):
                 continue
             aff, sl, pb, pp = oracle_lib.warp_patches([kf.mvImg_Pyr], cam, [kf.Get_Pose()], frame.Get_Pose(), [0],
                                                       [rpx], [rlv], [kf.bearing[f]], [mp.mPose], max_levels - 3)
@@ -77,7 +99,8 @@ def search_local_points(cells, frame, keyframes, cam, cell_size, max_levels, mas
             circle_filled(mask, cv_round(cand[1][0]), cv_round(cand[1][1]), cell_size)
             out.append((ci, mp, cand[1].astype(np.float32), lvl))
             matches += 1
-            break
-        if matches >= 200:
+            if mutant != "S1_ALLCANDS":
+                break
+        if matches >= 200 and mutant != "S1_NOCAP":
             break
     return out

@@ -9,7 +9,7 @@ from dsdtm_amd.frame import Config, Frame
 from tests import search_restatement as SR
 
 
-def make_world(seed, n_points=900, n_kf=3, width=640, height=480, cell=25):
+def make_world(seed, n_points=900, n_kf=3, width=640, height=480, cell=25, obs_margin=12, uv_margin=20):
     """A textured plane seen by n_kf keyframes and one current frame; map points on the plane with
     observations in the keyframes."""
     rng = np.random.default_rng(seed)
@@ -22,7 +22,7 @@ def make_world(seed, n_points=900, n_kf=3, width=640, height=480, cell=25):
     kfs = [search.KeyFrame(cam, synth.build_pyramid(imgs[i], 5), poses[i][:3], i) for i in range(n_kf)]
     cur = Frame(cam, synth.build_pyramid(imgs[n_kf], 5), poses[n_kf][:3])
     # map points: plane points (world == first keyframe's camera frame)
-    uv = np.stack([rng.uniform(20, width - 20, n_points), rng.uniform(20, height - 20, n_points)], 1)
+    uv = np.stack([rng.uniform(uv_margin, width - uv_margin, n_points), rng.uniform(uv_margin, height - uv_margin, n_points)], 1)
     ray = np.stack([(uv[:, 0] - cam.cx) / cam.fx, (uv[:, 1] - cam.cy) / cam.fy, np.ones(n_points)], 1)
     P = ray * depth
     feats = [[] for _ in range(n_kf)]
@@ -33,7 +33,7 @@ def make_world(seed, n_points=900, n_kf=3, width=640, height=480, cell=25):
             if rng.random() < 0.7:
                 px = kfs[k].World2Pixel(P[i])
                 lvl = int(rng.integers(0, 2))
-                if 12 * (1 << lvl) < px[0] < width - 12 * (1 << lvl) and 12 * (1 << lvl) < px[1] < height - 12 * (1 << lvl):
+                if obs_margin * (1 << lvl) < px[0] < width - obs_margin * (1 << lvl) and obs_margin * (1 << lvl) < px[1] < height - obs_margin * (1 << lvl):
                     obs[k] = len(feats[k])
                     feats[k].append((px.astype(np.float32), lvl))
         mps.append(search.MapPoint(P[i].copy(), obs, mnFound=int(rng.integers(1, 6)), mbBad=bool(rng.random() < 0.03)))
