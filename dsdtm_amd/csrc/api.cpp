@@ -51,6 +51,7 @@ struct dsdtm_ctx {
     // members of a team spin on each other and must all be resident at once.
     uint8_t* d_team = nullptr;
     unsigned team_seq = 0;
+    unsigned long long team_wraps = 0;    // times the 20-bit launch epoch of the exchange tags wrapped (ring re-zeroed each time)
     hipEvent_t team_event = nullptr;      // recorded behind the last team launch that ran on a caller's stream
     hipStream_t team_last_stream = nullptr;
     bool team_any = false;
@@ -81,6 +82,7 @@ struct dsdtm_ctx {
     Recover rec[RECOVER_SLOTS];
     unsigned long long rec_tick = 0;
     unsigned long long recovered = 0;     // launches re-run on the one-CU kernels so far (dsdtm_debug_recovered_launches)
+    bool evicted_timeout = false;         // a stream ring was handed to another stream while its timeout word was set
     bool multi_cu_ok = true;              // the dispatch assumptions of the multi-CU kernels hold on this device
     // dsdtm_sparse_align_batch_streamed: two copy streams and one event per chunk, created on first use
     hipStream_t copy_stream[2] = {nullptr, nullptr};
@@ -126,6 +128,7 @@ const OptionKey kOptionKeys[] = {
     {"po_no_cache", "DSDTM_PO_NO_CACHE", &dsdtm::Options::po_no_cache, true},
     {"a2d_tree", "DSDTM_A2D_TREE", &dsdtm::Options::a2d_tree, true},
     {"no_recover", "DSDTM_NO_RECOVER", &dsdtm::Options::no_recover, true},
+    {"team_no_wrap_clear", "DSDTM_TEAM_NO_WRAP_CLEAR", &dsdtm::Options::team_no_wrap_clear, true},
     {"warp_group", "DSDTM_WARP_GROUP", &dsdtm::Options::warp_group, false},
     {"a2d_group", "DSDTM_A2D_GROUP", &dsdtm::Options::a2d_group, false},
 };
@@ -324,6 +327,15 @@ struct LaunchMode {
 static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam, const dsdtm_align_params* prm,
                         void* hip_stream, const LaunchMode& mode, bool* multi_cu_used);
 static int recover_settle(dsdtm_ctx* ctx, int slot, hipStream_t rerun_stream);
+// Drops the re-run records of `stream` without settling them: for entry points that return an error and whose device
+// buffers (the records hold raw pointers into them) may be freed or regrown before the next check on that stream.
+static void recover_forget_stream(dsdtm_ctx* ctx, hipStream_t stream) {
+    for (int i = 0; i < dsdtm_ctx::RECOVER_SLOTS; ++i)
+        if (ctx->rec[i].used && ctx->rec[i].stream == stream) {
+            ctx->rec[i].used = false;
+            ctx->h_flags[dsdtm_ctx::FLAG_RECOVER + i] = 0;
+        }
+}
 
 extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_camera* cam,
                                                const dsdtm_align_params* prm, void* hip_stream) {
@@ -331,15 +343,17 @@ extern "C" int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch
 }
 
 // A free recovery slot. When all are taken, the oldest launch is settled first (its event is waited for; a launch
-// that timed out is re-run on the context's stream): at most RECOVER_SLOTS unchecked multi-CU launches are in flight.
+// that timed out is re-run on its own stream): at most RECOVER_SLOTS unchecked multi-CU launches are in flight.
 static int recover_acquire(dsdtm_ctx* ctx, int* slot_out) {
     int oldest = -1;
     for (int i = 0; i < dsdtm_ctx::RECOVER_SLOTS; ++i) {
         if (!ctx->rec[i].used) { *slot_out = i; return DSDTM_OK; }
         if (oldest < 0 || ctx->rec[i].order < ctx->rec[oldest].order) oldest = i;
     }
+    // (settled on the stream it was launched on: a re-run must stay ordered with the later work queued there on the same
+    // pose / count buffers; those buffers and the stream stay the caller's to keep alive until its check — dsdtm_amd.h)
     HIP_TRY(ctx, hipEventSynchronize(ctx->rec[oldest].done));
-    if (int rc = recover_settle(ctx, oldest, ctx->stream)) return rc;
+    if (int rc = recover_settle(ctx, oldest, ctx->rec[oldest].stream)) return rc;
     *slot_out = oldest;
     return DSDTM_OK;
 }
@@ -440,7 +454,10 @@ static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_c
             ctx->rings[ri].last_recorded = false;
             ctx->rings[ri].stream = stream;
             ctx->rings[ri].seq = 0;
-            ctx->h_flags[ri] = 0;                      // (the previous owner's launches have drained: its word starts clean)
+            // (the previous owner's launches have drained: its word starts clean — a timeout it raised and nobody checked for
+            // is not lost with it: the next check on any stream of this context reports it)
+            if (ctx->h_flags[ri]) ctx->evicted_timeout = true;
+            ctx->h_flags[ri] = 0;
         }
         ctx->rings[ri].last_use = ++ctx->ring_tick;
         a.pair_counter = ctx->d_counter + ri * dsdtm_ctx::COUNTERS_PER_STREAM + (ctx->rings[ri].seq++ % dsdtm_ctx::COUNTERS_PER_STREAM);
@@ -508,11 +525,21 @@ static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_c
             HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->team_event, 0));
         }
         // (the exchange words carry the launch's epoch in their tags — never 0, the buffers were zeroed when the context
-        // was created — so a ring slot is reused without clearing it)
+        // was created — so a ring slot is reused without clearing it.) The tags hold 20 bits of epoch: ring slot and epoch
+        // repeat together every 2^20 team launches, and a word that member m of pair p last wrote exactly then (team sizes
+        // vary from frame to frame) would carry a tag this launch accepts. So when the epoch wraps, all eight ring slots
+        // are zeroed on the launch stream — behind every earlier team launch (they are totally ordered, above) — once per
+        // 2^20 launches; the reference's Run is stateless across calls (src/Sprase_ImageAlign.cpp:22-27).
         ctx->team_seq += 1;
+        if ((ctx->team_seq & 0xfffffu) == 0u) {
+            ctx->team_seq += 1;                           // epoch 0 = "never written"
+            if (!options().team_no_wrap_clear)
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_team, 0, 8 * sparse_align_team_bytes(64), stream));
+            ctx->team_wraps += 1;
+        }
         uint8_t* tslot = ctx->d_team + (size_t)(ctx->team_seq & 7u) * sparse_align_team_bytes(64);
         a.workspace = (double*)tslot;
-        a.team_epoch = (ctx->team_seq & 0xfffffu) ? ctx->team_seq : ++ctx->team_seq;
+        a.team_epoch = ctx->team_seq;
         if (g_team_drop_members) a.spin_limit = 1u << 12;      // the test's waits give up after ~4 k polls
         HIP_TRY(ctx, sparse_align_launch_team(a, k, stream, g_team_drop_members));
         if (int rc = launched_multi_cu()) return rc;
@@ -580,6 +607,7 @@ extern "C" int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream) {
         bad = true;
     }
     if (ctx->h_flags[dsdtm_ctx::FLAG_GRAPH]) { ctx->h_flags[dsdtm_ctx::FLAG_GRAPH] = 0; bad = true; }   // (graph launches zero their own counters)
+    if (ctx->evicted_timeout) { ctx->evicted_timeout = false; bad = true; }
     if (bad) {
         set_err(ctx, "sparse-align kernel: a hand-over wait inside a workgroup timed out (results of this stream since the last check are invalid)");
         return DSDTM_ERR_HIP;
@@ -588,6 +616,14 @@ extern "C" int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream) {
 }
 
 extern "C" long long dsdtm_debug_recovered_launches(dsdtm_ctx* ctx) { return ctx ? (long long)ctx->recovered : -1; }
+// Tests: the context's team-launch counter (its low 20 bits are the epoch of the exchange tags, its low 3 bits the ring slot),
+// so that the epoch wrap — 2^20 team launches away in real use — can be crossed by a handful of launches. Returns the number
+// of wraps seen so far. The caller's team launches must have drained.
+extern "C" long long dsdtm_debug_team_seq(dsdtm_ctx* ctx, long long set_to) {
+    if (!ctx) return -1;
+    if (set_to >= 0) ctx->team_seq = (unsigned)set_to;
+    return (long long)ctx->team_wraps;
+}
 
 // ---- the batch from host memory over several contexts / devices ------------------------------
 extern "C" void dsdtm_shard_range(int n_pairs, int n_shards, int shard, int* lo, int* hi) {
@@ -643,10 +679,23 @@ static int sharded_issue(dsdtm_ctx* ctx, const dsdtm_batch_desc* hb, const dsdtm
     b.T_ref_w = (const double*)(d + o_tr); b.T_cur_w = (double*)(d + o_tc);
     b.n_tracked = (int32_t*)(d + o_nt); b.stats = hb->stats ? (dsdtm_align_stats*)(d + o_st) : nullptr;
     if (int rc = dsdtm_sparse_align_batch_device(ctx, &b, cam, prm, st)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(hb->T_cur_w + (size_t)lo * 12, d + o_tc, n * 96, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(hb->n_tracked + lo, d + o_nt, n * 4, hipMemcpyDeviceToHost, st));
-    if (hb->stats) HIP_TRY(ctx, hipMemcpyAsync(hb->stats + lo, d + o_st, n * sizeof(dsdtm_align_stats), hipMemcpyDeviceToHost, st));
-    return dsdtm_sparse_align_check(ctx, st);
+    auto download = [&]() -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(hb->T_cur_w + (size_t)lo * 12, d + o_tc, n * 96, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(hb->n_tracked + lo, d + o_nt, n * 4, hipMemcpyDeviceToHost, st));
+        if (hb->stats) HIP_TRY(ctx, hipMemcpyAsync(hb->stats + lo, d + o_st, n * sizeof(dsdtm_align_stats), hipMemcpyDeviceToHost, st));
+        return DSDTM_OK;
+    };
+    // the downloads overlap nothing when queued before the check, but the check may re-seed and re-run a multi-CU launch whose
+    // wait for a partner workgroup ran out (recover_settle): the host arrays then hold the aborted launch's poses and are
+    // fetched again
+    const unsigned long long rerun0 = ctx->recovered;
+    if (int rc = download()) return rc;
+    if (int rc = dsdtm_sparse_align_check(ctx, st)) return rc;
+    if (ctx->recovered != rerun0) {
+        if (int rc = download()) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    return DSDTM_OK;
 }
 
 // A shard that fails half-way still has copies from / into the caller's arrays in flight: they are waited for before
@@ -654,7 +703,10 @@ static int sharded_issue(dsdtm_ctx* ctx, const dsdtm_batch_desc* hb, const dsdtm
 static int sharded_one(dsdtm_ctx* ctx, const dsdtm_batch_desc* hb, const dsdtm_camera* cam, const dsdtm_align_params* prm,
                        int lo, int hi) {
     const int rc = sharded_issue(ctx, hb, cam, prm, lo, hi);
-    if (rc != DSDTM_OK) (void)hipStreamSynchronize(ctx->stream);
+    if (rc != DSDTM_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        recover_forget_stream(ctx, ctx->stream);      // their records point into the staging buffer, which the next call may regrow
+    }
     return rc;
 }
 
@@ -686,6 +738,7 @@ extern "C" int dsdtm_sparse_align_batch_sharded(dsdtm_ctx* const* ctx, int n_ctx
     std::vector<int> rc(n_ctx, DSDTM_OK);
     std::vector<std::thread> th;
     bool spawn_failed = false;
+    try { th.reserve((size_t)n_ctx); } catch (...) { set_err(ctx[0], "sharded batch: out of memory"); return DSDTM_ERR_NOMEM; }
     for (int g = 1; g < n_ctx && !spawn_failed; ++g) {
         int lo, hi;
         dsdtm_shard_range(hb->n_pairs, n_ctx, g, &lo, &hi);
@@ -831,6 +884,7 @@ static int streamed_one(dsdtm_ctx* ctx, const dsdtm_stream_desc* s, const dsdtm_
         for (int i = 0; i < 2; ++i)
             if (ctx->copy_stream[i]) (void)hipStreamSynchronize(ctx->copy_stream[i]);
         (void)hipStreamSynchronize(ctx->stream);
+        recover_forget_stream(ctx, ctx->stream);      // as sharded_one
     }
     return rc;
 }
@@ -855,6 +909,7 @@ extern "C" int dsdtm_sparse_align_batch_streamed(dsdtm_ctx* const* ctx, int n_ct
     std::vector<int> rc(n_ctx, DSDTM_OK);
     std::vector<std::thread> th;
     bool spawn_failed = false;
+    try { th.reserve((size_t)n_ctx); } catch (...) { set_err(ctx[0], "streamed batch: out of memory"); return DSDTM_ERR_NOMEM; }
     for (int g = 1; g < n_ctx && !spawn_failed; ++g) {
         int lo, hi;
         dsdtm_shard_range(s->n_pairs, n_ctx, g, &lo, &hi);

@@ -57,6 +57,7 @@ struct Options {
     int a2d_tree = 0;          // DSDTM_A2D_TREE: Align2D with DPP tree sums (cost comparison only; not bit-identical)
     int a2d_group = 4;         // DSDTM_A2D_GROUP: Align2D features per wavefront (4; 8 = diagnostic: 114 VGPRs, measured 7 % slower)
     int warp_group = 0;        // DSDTM_WARP_GROUP: candidates per workgroup of the warp prelude (2, 8, 16, 32, 64; 0: by batch size)
+    int team_no_wrap_clear = 0;  // DSDTM_TEAM_NO_WRAP_CLEAR: the team ring is NOT re-zeroed when the tag epoch wraps (A/B of that hazard only)
     int no_recover = 0;        // DSDTM_NO_RECOVER: a multi-CU launch that timed out is reported, not re-run (tests)
 };
 Options& options();

@@ -382,7 +382,8 @@ int dsdtm_sparse_align_batch_streamed(dsdtm_ctx* const* ctx, int n_ctx, const ds
  * inside one workgroup (a broken protocol; never observed) and for a re-run that failed as well. Timeout words,
  * counters and re-run records are per context (host-mapped words read without a copy): a check never synchronises
  * the device or touches another context's state. At most 64 multi-compute-unit launches of a context are kept
- * unsettled; the 65th first waits for the oldest. On devices that are not one 8-XCD / 256-CU partition, and inside
+ * unsettled; the 65th first waits for the oldest and settles it on the stream it was launched on — so the device
+ * buffers a launch names (T_cur_w, n_tracked, stats) and its stream must stay alive until that stream's check. On devices that are not one 8-XCD / 256-CU partition, and inside
  * a stream capture, those shapes run the one-compute-unit kernels from the start. The reference has no counterpart
  * (its path is one CPU thread); the single-pair host entry points above settle their launch themselves. */
 int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream);

@@ -361,3 +361,39 @@ def test_sharded_large_pairs_take_the_big_lds_kernels_on_every_context(gpu_ctx, 
             To, no, _ = want[i % 2]
             H.assert_pose_close(a["Tc"][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"N={N} pair {i}")
             assert a["nt"][i] == no
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,P", [(600, 2), (1900, 18)])
+def test_sharded_entry_fetches_the_results_again_after_a_transparent_rerun(oracle, N, P):
+    """dsdtm_sparse_align_batch_sharded queues its downloads before it checks the launch. When that check re-seeds and re-runs a
+    team / two-member launch whose wait for a partner workgroup ran out, the host arrays hold the aborted launch's poses: they
+    must be fetched again (round-4 advice). The debug switch keeps a member of every pair away, so the first attempt always
+    times out; the caller must still see DSDTM_OK and the oracle's results."""
+    W, Hh, L = 320, 240, 3
+    base = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=1300 + N + i, margin=12) for i in range(min(P, 3))]
+    scenes = [base[i % len(base)] for i in range(P)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in base]
+    ctx = capi.Context(0)
+    lib = ctx.lib
+    drop = lib.dsdtm_debug_drop_team_members
+    drop.restype, drop.argtypes = None, [C.c_int]
+    rec = lib.dsdtm_debug_recovered_launches
+    rec.restype, rec.argtypes = C.c_longlong, [C.c_void_p]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    a, b, _ = _host_batch(scenes, L, W, Hh)
+    arr = (C.c_void_p * 1)(ctx.handle)
+    n0 = rec(ctx.handle)
+    try:
+        drop(1)
+        rc = lib.dsdtm_sparse_align_batch_sharded(arr, 1, C.byref(b), C.byref(cam), C.byref(prm))
+    finally:
+        drop(0)
+    assert rc == 0, lib.dsdtm_last_error(ctx.handle)
+    assert rec(ctx.handle) == n0 + 1                                   # the launch did time out and was re-run
+    for i in range(P):
+        To, no, so = want[i % len(base)]
+        H.assert_pose_close(a["Tc"][i].reshape(3, 4), To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"pair {i} after the re-run")
+        assert a["nt"][i] == no and list(a["st"]["iters"][i][:L]) == list(so["iters"][:L])
+    ctx.close()

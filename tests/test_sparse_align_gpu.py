@@ -800,6 +800,51 @@ def test_single_pair_run_recovers_from_a_team_timeout(gpu_ctx, oracle):
     assert ng == no and sg["iters"] == so["iters"]
 
 
+def test_team_exchange_survives_the_wrap_of_its_tag_epoch(oracle):
+    """The team kernel's exchange words are tagged with 20 bits of launch epoch and never cleared between launches: ring slot
+    and epoch repeat together every 2^20 team launches, and a word member m of pair p wrote exactly then would be accepted
+    as this launch's partial. The library re-zeroes the ring when the epoch wraps. Here the counter is moved next to the wrap
+    (dsdtm_debug_team_seq): teams of mixed sizes (5 members, 2, 5 again, other scenes) run on either side of it — after a
+    launch with the SAME epoch and ring slot as the one behind the wrap left its words in the buffer — and every launch
+    gives the oracle's results (Run is stateless across calls, src/Sprase_ImageAlign.cpp:22-27)."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    ctx = capi.Context(0)                                    # a context of its own: the counter is per context
+    dev = torch.device("cuda", 0)
+    W, Hh, L = 320, 240, 3
+    seq = ctx.lib.dsdtm_debug_team_seq
+    seq.restype, seq.argtypes = C.c_longlong, [C.c_void_p, C.c_longlong]
+    cam = None
+    prm = capi.AlignParams(L, 0, 10, 15)
+    big = [cached_scene(width=W, height=Hh, levels=L, n_patches=1000, seed=900 + i, margin=12) for i in range(2)]
+    big2 = [cached_scene(width=W, height=Hh, levels=L, n_patches=1000, seed=902 + i, margin=12) for i in range(2)][::-1]
+    small = [cached_scene(width=W, height=Hh, levels=L, n_patches=500, seed=1900 + i, margin=12) for i in range(2)]
+    cam = capi.camera_struct(big[0].cam)
+
+    def run(scenes):
+        t, b = _device_batch(torch, dev, scenes, L, W, Hh)
+        ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), None))
+        ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, None))
+        Tg, ng = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+        for i, sc in enumerate(scenes):
+            To, no, _ = oracle.sparse_align(sc, L, 0, 10)
+            H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"{len(sc.px)} features, pair {i}")
+            assert ng[i] == no
+
+    assert seq(ctx.handle, 0) == 0
+    run(big)                                                 # counter 1: epoch 1, ring slot 1 — its words stay behind
+    seq(ctx.handle, 0xffffd)
+    run(big)                                                 # 0xffffe
+    run(small)                                               # 0xfffff: smaller teams, fewer words rewritten
+    assert seq(ctx.handle, -1) == 0
+    run(big2)                                                # wraps: epoch 1, ring slot 1 again, other scenes in the same words
+    assert seq(ctx.handle, -1) == 1                          # the wrap was seen (and the ring re-zeroed)
+    run(small)
+    run(big)
+    ctx.close()
+
+
 def test_workspace_launches_in_flight_on_two_streams(gpu_ctx, oracle):
     """Many pairs of more than 704 features run the workspace kernel, whose scratch belongs to the launch's
     STREAM: two such launches in flight on two streams of one context do not share it (round 1 had one
