@@ -1156,7 +1156,8 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
             const int next_raw = claim_issue();                        // latency hidden under this pair
             unsigned long long t_wait = 0, t_solve = 0, t_first = 0, n_it = 0, t_begin = 0, t_refresh = 0;
             unsigned long long t_sub[3] = {0, 0, 0};
-            if (STAMPS) t_begin = __builtin_amdgcn_s_memtime();
+            unsigned long long rt_begin = 0;
+            if (STAMPS) { t_begin = __builtin_amdgcn_s_memtime(); rt_begin = __builtin_amdgcn_s_memrealtime(); }
             if (staged) commit_next(*(LdsBlockState*)&s, lane);        // prepared while the previous pair was running
             else solver_init(a.T_ref_w + 12 * (size_t)pair, a.T_cur_w + 12 * (size_t)pair, (LdsBlockState*)&s, lane);
             if (lane == 0) stats_clear(a, pair);
@@ -1220,6 +1221,10 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
                 o[6] = t_sub[1];
                 o[7] = t_sub[2];
                 ((unsigned long long*)a.workspace)[(size_t)a.n_pairs * 48 + pair] = t_refresh;
+                // the device-wide 100 MHz clock at the pair's begin and end + the slot that ran it: which slots sit idle, and
+                // for how long, once the pair counter has run dry (tools/stamps.py: the tail of a solo launch)
+                unsigned long long* rt = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 49 + (size_t)pair * 3;
+                rt[0] = rt_begin; rt[1] = __builtin_amdgcn_s_memrealtime(); rt[2] = (unsigned long long)blockIdx.x * PPW + slot;
             }
             pair = claim_taken(claim_value(next_raw));
         }

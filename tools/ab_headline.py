@@ -15,5 +15,5 @@ if r.returncode or not line:
     sys.exit(1)
 d = json.loads(line[-1])
 rf = d["roofline"]
-print(f"{label:16s} value {d['value'] / 1e6:6.3f} M/s  ms_per_step {d['ms_per_step']:.4f}  kernel alone {rf['kernel_ms_solo']:.4f} ms  frac {rf['frac']:.3f}"
+print(f"{label:16s} value {d['value'] / 1e6:6.3f} M/s  ms_per_step {d['ms_per_step']:.4f}  kernel alone {rf['kernel_ms_avg']:.4f} ms  frac {rf['frac']:.3f}"
       f"  pose delta vs cpu {d.get('pose_delta_vs_cpu')}", flush=True)

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0); ctx = capi.Context(0)
 cam = synth.Camera.tum(640, 480); cs = capi.camera_struct(cam); prm = capi.AlignParams(4, 0, 10, 15)
 st = torch.cuda.Stream(device=dev)
 d = bench.build_batch(torch, dev, ctx, cam, a.pairs, 640, 480, 4, 300, seed=0xD5D7, stream=st)
-stamps = torch.zeros((a.pairs * 49,), dtype=torch.int64, device=dev)
+stamps = torch.zeros((a.pairs * 52,), dtype=torch.int64, device=dev)
 f = ctx.lib.dsdtm_debug_sparse_align_stamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.POINTER(capi.BatchDesc), C.POINTER(capi.Camera), C.POINTER(capi.AlignParams), C.c_void_p, C.c_void_p]
 for rep in range(3):
@@ -24,7 +24,8 @@ w = allst[a.pairs*8:a.pairs*20].reshape(a.pairs, 12)
 pw = allst[a.pairs*20:a.pairs*36].reshape(a.pairs, 16)
 lv = allst[a.pairs*36:a.pairs*44].reshape(a.pairs, 8)
 bf = allst[a.pairs*44:a.pairs*48].reshape(a.pairs, 4)
-rf = allst[a.pairs*48:]
+rf = allst[a.pairs*48:a.pairs*49]
+rt = allst[a.pairs*49:a.pairs*52].reshape(a.pairs, 3)
 n_it = s[:, 3]
 print("pairs", a.pairs, "iterations/pair mean", n_it.mean())
 print("cycles per block: total %.0f | first-pass waits (4 levels) %.0f | later-pass waits %.0f | solve %.0f" % (s[:,4].mean(), s[:,0].mean(), s[:,1].mean(), s[:,2].mean()))
@@ -79,3 +80,34 @@ def makespan_levels(slots=512):
     return t_end
 print("model makespan / ideal: whole pairs %.3f | level-granular FIFO %.3f" % (
     makespan(range(n)) / (n / 512 * dur.mean()), makespan_levels() / (n / 512 * dur.mean())))
+
+# ---- the tail of a solo launch: which slots idle once the pair counter has run dry (device-wide 100 MHz clock)
+t0, t1, slot = rt[:, 0], rt[:, 1], rt[:, 2].astype(int)
+T0, T1 = t0.min(), t1.max()
+span = T1 - T0
+n_slots = 2 * 256
+slots = np.unique(slot)
+last_end = np.array([t1[slot == k].max() for k in slots])
+first_begin = np.array([t0[slot == k].min() for k in slots])
+busy = np.array([(t1[slot == k] - t0[slot == k]).sum() for k in slots])
+dry = t0.max()                                        # the last claim: after it no slot finds a pair
+idle_tail = (T1 - last_end).sum() + (n_slots - len(slots)) * span
+print("solo launch, %d pairs on %d of %d slots: span %.1f us (first begin -> last end, 100 MHz clock)" % (a.pairs, len(slots), n_slots, span / 100.0))
+print("  pairs per slot: " + " ".join("%d:%d" % (k, (np.bincount(slot)[slots] == k).sum()) for k in range(1, 6)))
+print("  counter dry (last claim) at %.1f us = %.3f of the span" % ((dry - T0) / 100.0, (dry - T0) / span))
+print("  slot-time idle after a slot's last pair: %.3f of slots x span (mean %.1f us per slot, max %.1f us)" % (
+    idle_tail / (n_slots * span), (T1 - last_end).mean() / 100.0, (T1 - last_end).max() / 100.0))
+print("  slot-time idle before a slot's first pair: %.4f; between pairs: %.4f" % (
+    (first_begin - T0).sum() / (n_slots * span), ((last_end - first_begin) - busy).sum() / (n_slots * span)))
+h, edges = np.histogram((T1 - last_end) / 100.0, bins=[0, 5, 10, 20, 30, 40, 60, 80, 120, 1e9])
+print("  histogram of a slot's idle tail [us]: " + " ".join("%s:%d" % ("<%g" % edges[i + 1] if edges[i + 1] < 1e8 else ">=%g" % edges[i], h[i]) for i in range(len(h))))
+# per-pair duration by whether its slot-mate was still running: pairs that END after the mate's last end ran part of their time alone
+dur_rt = (t1 - t0) / 100.0
+order = np.argsort(t0)
+second = np.array([t0[i] > first_begin[np.searchsorted(slots, slot[i])] for i in range(a.pairs)])
+print("  pair duration: first of a slot %.1f us, later pairs %.1f us (mean); p95 %.1f, max %.1f" % (
+    dur_rt[~second].mean(), dur_rt[second].mean() if second.any() else float("nan"), np.percentile(dur_rt, 95), dur_rt.max()))
+# CUs where both slots finished vs. one slot alone at the end
+cu = slots // 2
+alone = np.array([abs(last_end[cu == c][0] - last_end[cu == c][-1]) for c in np.unique(cu)]) / 100.0
+print("  per CU, time one slot runs alone at the end: mean %.1f us, p95 %.1f us" % (alone.mean(), np.percentile(alone, 95)))
