@@ -194,6 +194,8 @@ def build_batch(torch, dev, ctx, cam, n_pairs, width, height, levels, n_patches,
                        rng.uniform(height / 2 - ch / 2, height / 2 + ch / 2, (n_pairs, n_patches))], axis=2).astype(np.float32)
     if os.environ.get("DSDTM_BENCH_SORT"):      # diagnostic: spatially coherent feature order (128-px strips, then rows)
         key = (px[:, :, 0] // 128).astype(np.int64) * 100000 + px[:, :, 1].astype(np.int64)
+        if os.environ["DSDTM_BENCH_SORT"] == "row":
+            key = px[:, :, 1].astype(np.int64) * 4096 + px[:, :, 0].astype(np.int64)
         order = np.argsort(key, axis=1, kind="stable")
         px = np.take_along_axis(px, order[:, :, None], axis=1)
     bearing = synth.bearing_from_px(cam, px.reshape(-1, 2)).reshape(n_pairs, n_patches, 3)

@@ -122,6 +122,7 @@ const OptionKey kOptionKeys[] = {
     {"ws_from", "DSDTM_WS_FROM", &dsdtm::Options::ws_from, false},
     {"ws_no_windows", "DSDTM_WS_NO_WINDOWS", &dsdtm::Options::ws_no_windows, true},
     {"ws_no_duo", "DSDTM_WS_NO_DUO", &dsdtm::Options::ws_no_duo, true},
+    {"ws_no_sort", "DSDTM_WS_NO_SORT", &dsdtm::Options::ws_no_sort, true},
     {"pyr_fused", "DSDTM_PYR_FUSED", &dsdtm::Options::pyr_fused, false},
     {"pyr_band", "DSDTM_PYR_BAND", &dsdtm::Options::pyr_band, false},
     {"no_zero_copy", "DSDTM_NO_ZERO_COPY", &dsdtm::Options::no_zero_copy, true},
@@ -413,6 +414,7 @@ static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_c
     a.pyr_pitch = b->pyr_pitch; a.n_pairs = b->n_pairs; a.max_features = b->max_features;
     a.max_level = prm->max_level; a.min_level = prm->min_level; a.max_iters = prm->max_iters; a.min_fts = prm->min_fts;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy; a.f = cam->f;
+    a.ws_sort = options().ws_no_sort ? 0 : 1;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)hip_stream;
     int ring = -1;                                     // this stream's entry of ctx->rings (not while capturing)

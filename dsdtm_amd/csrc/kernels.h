@@ -33,6 +33,7 @@ struct SAKernelArgs {
     unsigned spin_limit;        // team kernel: polls before a wait gives up (0 = the default, 2^24); tests shorten it
     unsigned team_epoch;        // team kernel: number of this launch among the context's team launches (part of the exchange tags)
     int debug_drop;             // tests only: member 1 of every two-member pair exits at once (its partner's waits run out)
+    int ws_sort;                // workspace kernels with LDS windows: the pair's features are walked in image-row order
     unsigned long long pyr_pitch;
     int n_pairs, max_features;
     int max_level, min_level, max_iters, min_fts;
@@ -49,6 +50,7 @@ struct Options {
     int team_spread_min = 33;  // DSDTM_TEAM_SPREAD_MIN: team size from which members are spread over all XCDs
     int ws_from = 704;         // DSDTM_WS_FROM: feature counts above this run the workspace kernel in batches
     int ws_no_windows = 0;     // DSDTM_WS_NO_WINDOWS
+    int ws_no_sort = 0;        // DSDTM_WS_NO_SORT: the workspace kernels walk a pair's features in list order (A/B, tests)
     int ws_no_duo = 0;         // DSDTM_WS_NO_DUO: 1025..2048 patches on one compute unit (HBM workspace) instead of two
     int pyr_fused = 1;         // DSDTM_PYR_FUSED: 0 never / 1 up to 32 images / 2 whenever the shape allows
     int pyr_band = 0;          // DSDTM_PYR_BAND: rows of the coarsest level per workgroup of the fused kernel (0: auto)

@@ -1407,6 +1407,27 @@ __device__ __forceinline__ void ws_store(WP ws, size_t npad, int p, const WsPatc
     }
 }
 
+// The same in two parts (kernels with LDS windows): the seven footprint rows are parked at every level start, the feature —
+// pixel and normalised point, which do not depend on the level — once per pair; an unusable FEATURE (!mbInitial, zero map
+// point: :86, :95) is parked with the sign bit of its pixel's x set (a negative x fails every level's border test anyway) and,
+// as in ws_store, a NaN depth; whether a usable feature passes a level's border test is a bit in its thread.
+template <typename WP>
+__device__ __forceinline__ void ws_store_rows(WP ws, size_t npad, int p, const uint32_t* rlo, const uint32_t* rhi) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) { ws[(size_t)r * npad + p] = rlo[r]; ws[(size_t)(7 + r) * npad + p] = rhi[r]; }
+}
+template <typename WP>
+__device__ __forceinline__ void ws_store_feature(WP ws, size_t npad, int p, const FeatureRegs& F) {
+    ws[(size_t)14 * npad + p] = __float_as_uint(F.px) | (F.ok ? 0u : 0x80000000u);
+    ws[(size_t)15 * npad + p] = __float_as_uint(F.py);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double v = F.ok ? F.X[i] : __longlong_as_double(0x7ff8000000000000ll);
+        ws[(size_t)(16 + 2 * i) * npad + p] = (uint32_t)__double2loint(v);
+        ws[(size_t)(17 + 2 * i) * npad + p] = (uint32_t)__double2hiint(v);
+    }
+}
+
 // The HBM workspace is streamed: every parked dword is read exactly once per pass, by the thread that wrote it, and a
 // pass reads far more than the L2 keeps until the next one — non-temporal loads leave the cache to the footprint gathers.
 __device__ __forceinline__ uint32_t ws_word(const uint32_t* p) { return __builtin_nontemporal_load(p); }
@@ -1423,6 +1444,18 @@ __device__ __forceinline__ void ws_load(WP ws, size_t npad, int p, WsPatch& w) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) w.F.X[i] = __hiloint2double((int)d[17 + 2 * i], (int)d[16 + 2 * i]);
     w.F.ok = (w.F.X[2] == w.F.X[2]);
+}
+
+template <typename WP>
+__device__ __forceinline__ void ws_load_feature(WP ws, size_t npad, int p, FeatureRegs& F) {
+    uint32_t d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = ws_word(ws + (size_t)(14 + i) * npad + p);
+    F.px = __uint_as_float(d[0]);
+    F.py = __uint_as_float(d[1]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) F.X[i] = __hiloint2double((int)d[3 + 2 * i], (int)d[2 + 2 * i]);
+    F.ok = (d[0] >> 31) == 0u;
 }
 
 // the register-resident patch state of one parked patch (what precompute_patch leaves behind in the register kernels)
@@ -1505,7 +1538,98 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
     unsigned long long* const twords = MEMBERS == 2 ? (unsigned long long*)((char*)a.workspace + (size_t)pair * DUO_BYTES) : nullptr;
     unsigned g_it = 0;                                                 // iterations so far, over all levels (tag of the exchange)
     bool dead = false;                                                 // a wait for the partner ran out: drain, keep the barriers matched
+    // FEATURE ORDER. The reference walks mvFeatures in list order (src/Sprase_ImageAlign.cpp:84-103) and sums in that order;
+    // here a thread's patches are the entries tid, tid + PT, .. of the pair's list ORDERED BY IMAGE ROW (then column, then
+    // list index: a total order, so the result depends neither on timing nor on the order the caller handed the list in):
+    // the lanes of a wave then gather their footprint rows from neighbouring image rows and share cache lines (measured on
+    // the caller's side in round 4: +7 % on 1000- and 2000-patch pairs, poses equal to 2e-15). One counting sort per pair in
+    // the LDS the level starts fill later: rows are the bins (counts and bin starts are order-free), a feature's place inside
+    // its bin is its rank among the bin's keys. n_tracked and the statistics are order-free; both members of a two-member
+    // pair order the same list and take their halves of it.
+    // Everything in LDS (PARK_LDS): the sort leaves place[i] (scratch), the features are then loaded in LIST order — coalesced
+    // columns — and each is parked at its place, once per pair. Parked in HBM: the thread of a place gathers its feature (s_perm).
+    __shared__ uint16_t s_perm[(WCAP > 0 && !PARK_LDS) ? WCAP : 1];
+    uint32_t* const s_place = ws_win + 2 * 1024 + 2048 + 64;           // [npad], scratch, valid until the first level start
+    const bool ordered = WCAP > 0 && a.ws_sort;
+    if constexpr (WCAP > 0) {
+        if (ordered) {
+            constexpr int BINS = 1024, KPT = (2048 + PT - 1) / PT;     // row bins; keys per thread (WCAP > 0: at most 2048 patches)
+            uint32_t* const start = ws_win;                            // [BINS] first place of a bin (then: its end)
+            uint32_t* const cur = ws_win + BINS;                       // [BINS] next free place of a bin
+            uint32_t* const tmp = ws_win + 2 * BINS;                   // [npad] keys in bin order, arbitrary inside a bin
+            uint32_t* const wtot = ws_win + 2 * BINS + 2048;           // [NPW] bin counts per wave of the scan
+            const float ysc = a.lv[0].h <= BINS ? 1.0f : (float)BINS / (float)a.lv[0].h;
+            const float xsc = a.lv[0].w <= 2047 ? 1.0f : 2047.0f / (float)a.lv[0].w;
+            for (int i = tid; i < BINS; i += PT) start[i] = 0u;
+            uint32_t key[KPT];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const int i = tid + k * PT;
+                key[k] = 0xffffffffu;
+                if (i < nf) {
+                    const size_t fi = (size_t)pair * a.max_features + i;
+                    const float x = a.px_xy[2 * fi], y = a.px_xy[2 * fi + 1];
+                    const int yk = (int)fminf(fmaxf(y == y ? y * ysc : 0.0f, 0.0f), (float)(BINS - 1));
+                    const int xk = (int)fminf(fmaxf(x == x ? x * xsc : 0.0f, 0.0f), 2047.0f);
+                    key[k] = ((uint32_t)yk << 22) | ((uint32_t)xk << 11) | (uint32_t)i;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KPT; ++k)
+                if (key[k] != 0xffffffffu) atomicAdd(&start[key[k] >> 22], 1u);
+            __syncthreads();
+            {   // exclusive scan of the BINS counts: BINS / PT consecutive bins per thread, wave scan, wave totals
+                constexpr int BPT = BINS / PT;
+                static_assert(BINS % PT == 0 && BPT >= 1, "bins per thread");
+                uint32_t c[BPT], sum = 0;
+#pragma unroll
+                for (int q = 0; q < BPT; ++q) { c[q] = start[tid * BPT + q]; sum += c[q]; }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)inc, d);
+                    if (lane >= d) inc += up;
+                }
+                if (lane == 63) wtot[wave] = inc;
+                __syncthreads();
+                uint32_t base = inc - sum;
+                for (int w = 0; w < wave; ++w) base += wtot[w];
+#pragma unroll
+                for (int q = 0; q < BPT; ++q) { start[tid * BPT + q] = base; cur[tid * BPT + q] = base; base += c[q]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KPT; ++k)
+                if (key[k] != 0xffffffffu) tmp[atomicAdd(&cur[key[k] >> 22], 1u)] = key[k];
+            __syncthreads();
+            for (int q = tid; q < (int)npad; q += PT) {
+                if (q >= nf) {                                         // not a feature: stays where it is (fi >= nf: dead)
+                    if constexpr (PARK_LDS) s_place[q] = (uint32_t)q;
+                    else if (q >= p0 && q < p1) s_perm[q - p0] = (uint16_t)q;
+                    continue;
+                }
+                const uint32_t kq = tmp[q];
+                const uint32_t bin = kq >> 22, s0 = start[bin], e0 = cur[bin];
+                uint32_t rank = 0;
+                for (uint32_t r = s0; r < e0; ++r) rank += tmp[r] < kq ? 1u : 0u;
+                const int place = (int)(s0 + rank);
+                if constexpr (PARK_LDS) s_place[kq & 0x7ffu] = (uint32_t)place;
+                else if (place >= p0 && place < p1) s_perm[place - p0] = (uint16_t)(kq & 0x7ffu);
+            }
+        }
+    }
     __syncthreads();                                                   // B0
+    if constexpr (PARK_LDS) {
+        // the pair's features, read in list order (every column coalesced), each parked at its place of this workgroup's half
+        const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
+        for (int i = tid; i < (int)npad; i += PT) {
+            const FeatureRegs F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + (i < a.max_features ? i : 0), i < nf), Cref);
+            const int place = ordered ? (int)s_place[i] : i;
+            if (place >= p0 && place < p1) ws_store_feature(ws, pstride, place - p0, F);
+        }
+        __syncthreads();
+    }
 
     for (int level = a.max_level - 1; level >= a.min_level; --level) {
         const LevelGeom lg = a.lv[level];
@@ -1519,21 +1643,36 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) s.to[i] = s.u.t[i];
         }
+        // bit k: the thread's k-th patch passed this level's reference-side border test (kernels with LDS windows: <= 4 per thread)
+        unsigned long long lvl_valid = 0ull;
         {
             const double Cref[3] = {s.u.Cref[0], s.u.Cref[1], s.u.Cref[2]};
-            for (int p = p0 + tid; p < p1; p += PT) {
+            unsigned long long kbit = 1ull;
+            for (int p = p0 + tid; p < p1; p += PT, kbit <<= 1) {
                 const int lp = p - p0;
+                const int slot = PARK_LDS ? lp : p;
                 if constexpr (WCAP > 0) ws_win[15 * WCAP + lp] = WIN_EMPTY;     // the level's windows are filled by its first pass
                 WsPatch w;
-                w.F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + p, p < nf), Cref);
+                if (!PARK_LDS && (WCAP == 0 || level == a.max_level - 1)) {
+                    const int fi = ordered ? (int)s_perm[lp] : p;     // the pair's fi-th feature sits in this thread's slot p
+                    w.F = make_feature(load_feature_raw(a, (size_t)pair * a.max_features + (fi < a.max_features ? fi : 0), fi < nf), Cref);
+                    if constexpr (WCAP > 0) ws_store_feature(ws, pstride, slot, w.F);      // once per pair: read back at the finer levels
+                } else {
+                    ws_load_feature(ws, pstride, slot, w.F);          // parked once per pair (above / at the coarsest level)
+                }
                 const RefGeom g = ref_geom(w.F, lg, level);
                 {
                     U32x3 rows[7];
                     ref_rows_issue(a, lg, ref_base, g, rows);
                     ref_rows_unpack(a, lg, g, rows, w.rlo, w.rhi);
                 }
-                w.F.ok = g.valid;
-                ws_store(ws, pstride, PARK_LDS ? lp : p, w);          // read back only by this same thread
+                if constexpr (WCAP > 0) {
+                    ws_store_rows(ws, pstride, slot, w.rlo, w.rhi);
+                    if (g.valid) lvl_valid |= kbit;
+                } else {
+                    w.F.ok = g.valid;
+                    ws_store(ws, pstride, slot, w);                   // read back only by this same thread
+                }
                 n_valid_lane += g.valid ? 1 : 0;
             }
         }
@@ -1555,6 +1694,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                 {
                     WsPatch w;
                     ws_load(ws, pstride, PARK_LDS ? lp : p, w);
+                    if constexpr (WCAP > 0) w.F.ok = w.F.ok && (lvl_valid & bit) != 0ull;
                     ws_patch_regs(w, lg, level, P);
                 }
                 double c2, bp[6];
@@ -1590,7 +1730,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                     if (maskable) {
                         if (!(vis_new & bit)) continue;
                         WsPatch w;
-                        ws_load(ws, pstride, lp, w);
+                        ws_load(ws, pstride, lp, w);                   // (visible => it passed the level's border test)
                         ws_patch_regs(w, lg, level, P);
                     } else {                                           // more patches per lane than mask bits: project again
                         WsPatch w;

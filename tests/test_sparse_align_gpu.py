@@ -845,6 +845,66 @@ def test_team_exchange_survives_the_wrap_of_its_tag_epoch(oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("N,P,size", [(1000, 9, (320, 240)), (2000, 10, (640, 480)), (1500, 3, (320, 240))])
+def test_workspace_kernels_walk_features_in_row_order_with_the_same_results(gpu_ctx, oracle, N, P, size):
+    """Batches of large pairs order a pair's features by image row on the device (one LDS sort per pair) before the lanes take
+    them: the reference sums in list order (src/Sprase_ImageAlign.cpp:84-103), so only the rounding of the sums may differ —
+    the oracle's poses to 1e-8, identical n_tracked / iterations / exit codes / n_ref / n_vis, with the ordering on and off
+    (debug option ws_no_sort), for ragged feature counts, uninitialised features, and feature pixels that are NaN, negative or
+    far outside the image (the sort key is a hint: it must never become an index)."""
+    import ctypes as C
+    import copy
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh = size
+    L = 3
+    base = []
+    for i in range(3):
+        sc = copy.deepcopy(cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=5200 + N + i, margin=12))
+        sc.initial[7::13] = 0
+        sc.px[3] = (np.nan, 40.0); sc.px[4] = (-1e9, 1e9); sc.px[5] = (W + 500.0, -3.0); sc.px[6] = (np.inf, np.nan)
+        sc.initial[3:7] = 0                                      # (the reference never reads the pixel of an uninitialised feature, :86)
+        base.append(sc)
+    scenes = [base[i % 3] for i in range(P)]
+    nf = np.array([N - (37 * i) % 300 for i in range(P)], np.int32)
+    nf[0] = N
+    t, b = _device_batch(torch, dev, scenes, L, W, Hh)
+    t["nf"] = torch.from_numpy(nf).to(dev)
+    b.n_features = t["nf"].data_ptr()
+    t["st"] = torch.zeros((P, capi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    b.stats = t["st"].data_ptr()
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    seeds = torch.from_numpy(np.stack([s_.T_cur_w_seed.reshape(12) for s_ in scenes])).to(dev)
+    outs = []
+    for no_sort in (0, 1):
+        with capi.debug_options(ws_no_sort=no_sort):
+            t["Tc"].copy_(seeds)
+            torch.cuda.synchronize()
+            gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), None))
+            gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, None))
+        outs.append((t["Tc"].cpu().numpy().copy(), t["nt"].cpu().numpy().copy(),
+                     np.frombuffer(t["st"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE).copy()))
+    for i, sc in enumerate(scenes):
+        sub = type("S", (), {})()
+        for k in ("cam", "ref_pyr", "cur_pyr", "T_ref_w", "T_cur_w_seed"):
+            setattr(sub, k, getattr(sc, k))
+        sub.px, sub.bearing, sub.p_world, sub.initial = sc.px[:nf[i]], sc.bearing[:nf[i]], sc.p_world[:nf[i]], sc.initial[:nf[i]]
+        To, no, so = oracle.sparse_align(sub, L, 0, 10)
+        for (Tg, ng, sg), what in zip(outs, ("row order", "list order")):
+            H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"{what}, pair {i}")
+            assert ng[i] == no and list(sg["iters"][i][:L]) == list(so["iters"][:L]) and list(sg["exit_code"][i][:L]) == list(so["exit_code"][:L])
+            assert list(sg["n_ref"][i][:L]) == list(so["n_ref"][:L]) and list(sg["n_vis"][i][:L]) == list(so["n_vis"][:L])
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-9             # the two orders differ by rounding only
+    # and the ordered launch is deterministic: the same bits again
+    t["Tc"].copy_(seeds)
+    torch.cuda.synchronize()
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), None))
+    gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_check(gpu_ctx.handle, None))
+    assert np.array_equal(t["Tc"].cpu().numpy(), outs[0][0])
+
+
 def test_workspace_launches_in_flight_on_two_streams(gpu_ctx, oracle):
     """Many pairs of more than 704 features run the workspace kernel, whose scratch belongs to the launch's
     STREAM: two such launches in flight on two streams of one context do not share it (round 1 had one
