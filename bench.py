@@ -579,6 +579,9 @@ def tracked_frame_entries(torch, dev, ctx, stream):
                 "roofline": {"bound": "fp64_vector", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "kernel": "pose_opt_kernel", "kernel_ms_avg": ms,
                              "flops_per_launch": flops,
+                             # HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes of this launch size (case poseopt)
+                             "traffic": pmc_traffic("pose_opt_kernel", F_ * (N_ * 61 + 2 * 96 + 64)),
+                             "algorithmic_bytes_per_launch": F_ * (N_ * 61 + 2 * 96 + 64),
                              "note": "~330 FP64 flops per residual-block evaluation x (iterations + 1) x blocks; the features of a frame "
                                      "(11 KB) stay in L1/L2: bound by the latency of its dependent FP64 chain, not by HBM"}})
     del d_b, d_w, d_l, d_u, d_T0, d_T, d_rn, d_sm

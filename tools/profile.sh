@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/r04_*: kernel trace + stats, then one counter group per pass (never --pmc
+# rocprofv3 passes behind profiles/r05_*: kernel trace + stats, then one counter group per pass (never --pmc
 # together with other trace domains). Usage on the GPU box: tools/profile.sh <outdir-under-gpurun_out>
 # Each "case" is one command line; cases: main (bench defaults: 8 launch streams), solo (one stream), n1000, n2000, the
 # secondary kernels (tools/kernels.py: pyrDown, Align2D), one tracked frame (tools/track_step.py: pyramid, single-pair
@@ -35,7 +35,7 @@ for c in $CASES; do
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$c/pmc_write" -- python3 ${CASE[$c]} > "$OUT/$c/pmc_write.log" 2>&1 || echo "pmc write $c failed"
   echo "counted $c"
 done
-for c in solo n1000 n2000; do
+for c in solo n1000 n2000 poseopt; do
   has $c || continue
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/$c/pmc_sq" -- python3 ${CASE[$c]} > "$OUT/$c/pmc_sq.log" 2>&1 || echo "pmc sq $c failed"
 done

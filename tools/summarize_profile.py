@@ -1,7 +1,7 @@
 """Folds the rocprofv3 output of tools/profile.sh (per case: kernel-trace stats, kernel trace, one --pmc pass per
 counter group) into the summaries kept under profiles/:
-    <out>/r04_kernel_stats.csv     per case and kernel: calls, average / min / max duration
-    <out>/r04_bench_pmc.json       "profile_binary_sha": sha256 (16 hex digits) of the libdsdtm_amd.so the passes ran with —
+    <out>/r05_kernel_stats.csv     per case and kernel: calls, average / min / max duration
+    <out>/r05_bench_pmc.json       "profile_binary_sha": sha256 (16 hex digits) of the libdsdtm_amd.so the passes ran with —
                                    bench.py reports these numbers only while it loads that same binary;
                                    per case and kernel: counters per dispatch + "hbm_traffic_per_launch" entries (what
                                    bench.py's roofline.traffic reads): FETCH_SIZE and WRITE_SIZE are KiB per dispatch;
@@ -18,13 +18,16 @@ ALG = {   # case -> (kernel substring, algorithmic bytes per launch, dispatches 
     "n1000": ("sparse_align", 1024 * 873292, 1),
     "n2000": ("sparse_align", 256 * 3378292, 1),
     "kernels": ("pyrdown_kernel", 2048 * 504000, 3),
+    # Optimizer::PoseOptimization, 4096 frames x 200 features per launch (tools/pose_opt_bench.py 4096 200 = bench.py's entry):
+    # per feature bearing 24 + map point 24 + level 4 + flag 1 in, residual norm 8 out; per frame the pose in and out + summary
+    "poseopt": ("pose_opt_kernel", 4096 * (200 * 61 + 2 * 96 + 64), 1),
 }
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with open(os.path.join(REPO, "dsdtm_amd", "csrc", "libdsdtm_amd.so"), "rb") as f:
     sha = hashlib.sha256(f.read()).hexdigest()[:16]
 sys.path.insert(0, REPO)
 from dsdtm_amd.csrc import build as hip_build
-stats_rows, pmc = [], {"round": 4, "profile_binary_sha": sha, "profile_source_sha": hip_build.source_sha(), "command": "tools/profile.sh (see the file for every command line)", "cases": {},
+stats_rows, pmc = [], {"round": 5, "profile_binary_sha": sha, "profile_source_sha": hip_build.source_sha(), "command": "tools/profile.sh (see the file for every command line)", "cases": {},
                        "hbm_traffic_per_launch": [], "fp64_per_launch": [], "overlap": {}}
 for case in sorted(os.listdir(src)):
     d = os.path.join(src, case)
@@ -113,7 +116,7 @@ for case in sorted(os.listdir(src)):
                     case=case, kernel=k, dispatches_per_launch=nd, algorithmic_bytes_per_launch=alg, fetch_bytes_raw=fetch,
                     fetch_bytes_gfx950_corrected=2.0 * fetch, write_bytes=write,
                     traffic_over_algorithmic=(2.0 * fetch + write) / alg))
-with open(os.path.join(src, "r04_kernel_stats.csv"), "w", newline="") as f:
+with open(os.path.join(src, "r05_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=["case", "kernel", "calls", "avg_ns", "min_ns", "max_ns", "total_ns", "percent"])
     w.writeheader()
     w.writerows(stats_rows)
@@ -140,7 +143,7 @@ for f in glob.glob(f"{src}/main/trace/**/*_kernel_trace.csv", recursive=True):
               union_span_ns=busy, union_span_per_launch_ns=busy / len(rows), launches_in_flight_avg=weighted / busy,
               first_start=st[0], last_end=max(en), wall_per_launch_ns=(max(en) - st[0]) / len(rows))
 pmc["overlap"] = ov
-json.dump(pmc, open(os.path.join(src, "r04_bench_pmc.json"), "w"), indent=1)
+json.dump(pmc, open(os.path.join(src, "r05_bench_pmc.json"), "w"), indent=1)
 print(json.dumps(ov, indent=1))
 print(json.dumps(pmc["hbm_traffic_per_launch"], indent=1))
 for r in stats_rows:
