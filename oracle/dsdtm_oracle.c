@@ -439,6 +439,7 @@ static double compute_residuals(const oracle_se3* T, const dsdtm_pyramid* cur, c
         (*tnPts)++;
     }
     if (MUT(MUT_Q9_SUM)) return chi2;                          /* "fixed": not normalised by the visible pixel count */
+    if (MUT(MUT_Q11_ZERO) && tResNum == 0) return 0.0;         /* "fixed": no 0/0 when nothing is visible */
     return chi2 / tResNum;                                     /* :298 (0/0 -> NaN) */
 }
 
@@ -626,6 +627,7 @@ int oracle_align2d(const uint8_t* img, int width, int height, int stride,
         }
     }
     mat3f_inverse(H, Hinv);                                    /* :345 */
+    if (MUT(MUT_A2_CHECK) && !(fabsf(Hinv[0]) < 1e30f)) return 0;   /* "fixed": a singular H is refused before px is touched */
     float mean_diff = 0.0f;
     float u = (float)px[0];
     float v = (float)px[1];

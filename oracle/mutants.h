@@ -26,12 +26,14 @@ enum oracle_mutant_id {
     MUT_Q9_EPS = 12,      /* :305,341 exit at max|x| <= 1e-6 instead of 1e-8                                 */
     MUT_Q10_COARSE = 13,  /* :59      returned count taken at the coarsest level instead of the finest       */
     MUT_Q10_MINFTS = 14,  /* :34      Min_fts compared with the initialised features only                    */
+    MUT_Q11_ZERO = 15,    /* :298     chi2 = 0 instead of 0/0 = NaN when no patch is visible                         */
     /* Align2D — src/Feature_alignment.cpp:318-417 */
     MUT_A1_DOUBLE = 20,   /* :330-398 double arithmetic instead of float                                     */
     MUT_A1_ROWSUMS = 21,  /* :386-392 Jres summed row by row and then over rows, not in one raster-order chain    */
     MUT_A3_STRICT = 22,   /* :367-368 u_r == cols-4 / v_r == rows-4 rejected                                 */
     MUT_A4_NOWRITE = 23,  /* :414     px not written back when the alignment fails                           */
     MUT_A4_NOMEAN = 24,   /* :386     no mean-offset term in the residual                                    */
+    MUT_A2_CHECK = 25,    /* :345     a conditioning check on H the reference does not have (NaN is what it returns) */
     /* warp prelude — src/Feature_alignment.cpp:160-275 */
     MUT_W1_FLOATDIV = 30, /* :231     1.0f/(1<<level) instead of the integer division                        */
     MUT_W2_ROUND = 31,    /* :254     rounding instead of truncation to u8                                   */

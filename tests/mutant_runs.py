@@ -28,6 +28,8 @@ TABLE = {
     "MUT_Q9_EPS":      ("sparse:main", "iters", "Q9", "src/Sprase_ImageAlign.cpp:305,341"),
     "MUT_Q10_COARSE":  ("sparse:main", "n_tracked", "Q10", "src/Sprase_ImageAlign.cpp:59"),
     "MUT_Q10_MINFTS":  ("sparse:minfts", "n_tracked", "Q10", "src/Sprase_ImageAlign.cpp:34"),
+    "MUT_Q11_ZERO":    ("sparse:away", "chi2", "Q11", "src/Sprase_ImageAlign.cpp:298"),
+    "MUT_A2_CHECK":    ("align2d", "px", "A2", "src/Feature_alignment.cpp:345,367-369"),
     "MUT_A1_DOUBLE":   ("align2d", "px", "A1", "src/Feature_alignment.cpp:330-398"),
     "MUT_A1_ROWSUMS":  ("align2d", "px", "A1", "src/Feature_alignment.cpp:386-392"),
     "MUT_A3_STRICT":   ("align2d", "converged", "A3", "src/Feature_alignment.cpp:367-368"),

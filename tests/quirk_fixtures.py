@@ -80,6 +80,9 @@ def sparse_cases():
     few.initial[:8] = 1
     few.p_world[few.p_world[:, 0] == 0.0] = base.p_world[0]
     cases["minfts"] = (few, ALIGN_PARAMS, 15, None)
+    # the current camera seeded looking away (1.2 rad about y): no patch projects into the image — chi2 = 0/0 = NaN, H = 0, the
+    # pseudo-inverse solve returns x = 0, the level ends on max|x| <= 1e-8 with the pose untouched (Q11)
+    cases["away"] = (base, ALIGN_PARAMS, 15, (synth.se3_exp([0, 0, 0, 0, 1.2, 0]) @ T4)[:3].copy())
     return cases
 
 
@@ -143,6 +146,12 @@ def align2d_cases():
         a = rng.uniform(0, 2 * np.pi)
         add(0, c, (c[0] + 7.5 * np.cos(a), c[1] + 7.5 * np.sin(a)))
     h, w = pyr[0].shape
+    # two constant reference patches: H singular, H.inverse() is all NaN / inf, the first update makes u NaN (A2: no check)
+    for i in range(2):
+        c = (40.0 + 20 * i, 40.0)
+        add(0, c, (c[0] + 0.4, c[1] - 0.3))
+        lv, pb, p_, st = rows[-1]
+        rows[-1] = (lv, np.full(100, 90 + 40 * i, np.uint8), np.full(64, 90 + 40 * i, np.uint8), st)
     for i in range(6):                                         # the admitted last column / row
         if i % 2:
             c = (w - 4 + 0.3 + 0.1 * i, rng.uniform(20, 70))

@@ -33,7 +33,7 @@ def test_committed_fixtures_are_the_generators_inputs(golden):
 
 
 def test_faithful_oracle_reproduces_the_committed_outputs(faithful, golden):
-    for name in ("main", "dark", "behind", "minfts"):
+    for name in ("main", "dark", "behind", "minfts", "away"):
         o = faithful["sparse:" + name]
         assert np.array_equal(o["T"], golden[f"{name}_out_T"], equal_nan=True) and o["n"] == int(golden[f"{name}_out_n"])
         for k in ("iters", "exit_code", "n_ref", "n_vis"):
@@ -57,8 +57,11 @@ def test_the_fixtures_reach_what_they_are_for(faithful):
     assert d["iters"][2] == 4 and d["exit_code"][2] == 0            # four iterations of identical chi2: `>` never reverts
     assert faithful["sparse:behind"]["n"] > 50
     assert faithful["sparse:minfts"]["n"] == 8
+    aw = faithful["sparse:away"]
+    assert aw["n"] == 0 and aw["n_vis"][:3] == [0, 0, 0] and aw["exit_code"][:3] == [2, 2, 2] and all(np.isnan(aw["chi2"][:3]))
     conv, px = faithful["align2d"]
-    assert 4 <= (~conv).sum() <= 10 and conv[28:].any()
+    assert 4 <= (~conv).sum() <= 10 and conv[30:].any()
+    assert not conv[28:30].any() and np.isnan(px[28:30]).all()       # singular H: NaN written back (A2, A4)
     assert set(faithful["warp"][1]) == {0, 1, 2}
     assert len(faithful["search:dense"][0]) == 200 and len(faithful["search:std"][0]) < 200
 
@@ -79,7 +82,7 @@ def test_mutation_build_with_no_switch_is_the_faithful_oracle(faithful):
 
 def test_every_quirk_of_the_survey_has_a_mutant():
     quirks = {row[2] for row in M.TABLE.values()}
-    assert {"Q1", "Q3", "Q4", "Q5", "Q6", "Q8", "Q9", "Q10", "A1", "A3", "A4", "W1", "W2", "W3", "S1"} <= quirks
+    assert {"Q1", "Q3", "Q4", "Q5", "Q6", "Q8", "Q9", "Q10", "Q11", "A1", "A2", "A3", "A4", "W1", "W2", "W3", "S1"} <= quirks
     assert {m for m in M.TABLE if m.startswith("MUT_")} == set(oracle_lib.MUTANTS) - {"MUT_NONE"}
     from tests import search_restatement as SR
     assert {m for m in M.TABLE if not m.startswith("MUT_")} == set(SR.SEARCH_MUTANTS)

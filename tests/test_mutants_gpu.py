@@ -57,7 +57,7 @@ def test_hip_path_agrees_with_the_faithful_oracle_on_every_quirk_fixture(hip, fa
 
 def test_hip_path_agrees_with_the_committed_outputs(hip):
     g = np.load(H.golden_path("quirks.npz"))
-    for name in ("main", "dark", "behind", "minfts"):
+    for name in ("main", "dark", "behind", "minfts", "away"):
         o = hip["sparse:" + name]
         want = dict(T=g[f"{name}_out_T"], n=int(g[f"{name}_out_n"]), chi2=list(g[f"{name}_out_chi2"]),
                     **{k: list(g[f"{name}_out_{k}"]) for k in ("iters", "exit_code", "n_ref", "n_vis")})
