@@ -186,6 +186,8 @@ def to_gray(img: np.ndarray) -> np.ndarray:
     img = np.asarray(img)
     if img.ndim == 2:
         return img.astype(np.uint8)
+    if img.shape[2] < 3:                                    # gray + alpha (colour type 4): the gray channel
+        return img[:, :, 0].astype(np.uint8)
     r, g, b = (img[:, :, k].astype(np.uint32) for k in range(3))
     return ((9798 * r + 19235 * g + 3735 * b + 16384) >> 15).astype(np.uint8)
 
@@ -204,6 +206,8 @@ def get_feature_depth(depth_m: np.ndarray, px) -> float:
     left / upper / right / lower neighbour, else -1."""
     x, y = cv_round(float(px[0])), cv_round(float(px[1]))
     h, w = depth_m.shape
+    if not (0 <= x < w and 0 <= y < h):                    # (the reference indexes the cv::Mat unchecked; a pixel outside has no depth)
+        return -1.0
     d = depth_m[y, x]
     if d != 0:
         return float(d)
