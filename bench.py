@@ -46,7 +46,7 @@ def algorithmic_bytes(width, height, levels, n_patches):
     return 2 * pyr + n_patches * 57 + 292
 
 
-PMC_SUMMARY = os.path.join("profiles", "r04_bench_pmc.json")
+PMC_SUMMARY = os.path.join("profiles", "r05_bench_pmc.json")
 
 
 def library_sha():
