@@ -165,6 +165,41 @@ def test_uninitial_zero_points_and_border_features(gpu_ctx, oracle):
     assert sg["iters"] == so["iters"]
 
 
+@pytest.mark.parametrize("seed,n,size,levels", [(31, 300, (640, 480), 4), (32, 200, (320, 240), 3), (33, 1000, (640, 480), 4)])
+def test_occluders_moving_objects_and_exposure_change(gpu_ctx, oracle, seed, n, size, levels):
+    """Inputs the synthetic plane does not have: the current frame with occluding blocks (a fifth of the patches land on them),
+    objects that moved on their own between the frames, saturated blobs and a global exposure change. The reference has no
+    robust weights (src/Sprase_ImageAlign.cpp:282-291: plain squared residuals), so these are simply large residuals that
+    drag the solution — the same solution, iteration for iteration, in the HIP path and the oracle."""
+    import copy
+    W, Hh = size
+    sc = copy.deepcopy(cached_scene(width=W, height=Hh, levels=levels, n_patches=n, seed=seed, margin=20))
+    rng = np.random.default_rng(seed)
+    cur = sc.cur_pyr[0].astype(np.int32)
+    ref = sc.ref_pyr[0]
+    for _ in range(12):                                        # occluders: flat and textured blocks
+        w, h = int(rng.integers(W // 20, W // 6)), int(rng.integers(Hh // 20, Hh // 6))
+        x, y = int(rng.integers(0, W - w)), int(rng.integers(0, Hh - h))
+        cur[y:y + h, x:x + w] = rng.integers(0, 256) if rng.random() < 0.5 else rng.integers(0, 256, (h, w))
+    for _ in range(6):                                         # moving objects: a piece of the reference pasted 5-15 px away
+        w, h = int(rng.integers(30, 80)), int(rng.integers(30, 80))
+        x, y = int(rng.integers(20, W - w - 20)), int(rng.integers(20, Hh - h - 20))
+        dx, dy = int(rng.integers(-15, 16)), int(rng.integers(-15, 16))
+        cur[y + dy:y + dy + h, x + dx:x + dx + w] = ref[y:y + h, x:x + w]
+    for _ in range(4):                                         # saturated blobs
+        x, y, r = int(rng.integers(40, W - 40)), int(rng.integers(40, Hh - 40)), int(rng.integers(8, 30))
+        yy, xx = np.mgrid[0:Hh, 0:W]
+        cur[(xx - x) ** 2 + (yy - y) ** 2 <= r * r] = 255
+    cur = np.clip(cur * 1.12 + 9, 0, 255).astype(np.uint8)    # exposure change
+    sc.cur_pyr = synth.build_pyramid(cur, levels)
+    To, no, so = oracle.sparse_align(sc, levels, 0, 10)
+    Tg, ng, sg = H.gpu_sparse_align(sc, levels, 0, 10, ctx=gpu_ctx)
+    H.assert_pose_close(Tg, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what="occluded scene")
+    assert ng == no and sg["iters"] == so["iters"] and sg["exit_code"] == so["exit_code"] and sg["n_vis"] == so["n_vis"]
+    ea, et = synth.pose_error(To, sc.T_cur_w_true)
+    assert ea > 1e-4 or et > 1e-4                              # the outliers do drag the estimate: this is not the clean scene again
+
+
 def test_identity_motion_converges_immediately(gpu_ctx, oracle):
     sc = cached_scene(width=320, height=240, levels=3, n_patches=150, seed=11, xi=(0, 0, 0, 0, 0, 0), margin=12)
     Tg, ng, sg = H.gpu_sparse_align(sc, 3, 0, 10, ctx=gpu_ctx)
