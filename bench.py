@@ -625,16 +625,17 @@ def tracked_frame_entries(torch, dev, ctx, stream):
             d_fr.data_ptr(), d_kfi.data_ptr(), d_rp.data_ptr(), d_rl.data_ptr(), d_rb.data_ptr(), d_pw.data_ptr(), Lm - 3, 10, Mm,
             d_scr.data_ptr(), d_px.data_ptr(), d_sl.data_ptr(), d_cv.data_ptr(), stream.cuda_stream))
     ms = timed(fmd)
-    b_cand = 4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1 + 2 * (100 + 64)   # candidate columns in, pixel in/out, level + flag out, patches through scratch
+    b_cand = 4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1                  # candidate columns in, pixel in/out, level + flag out (the warped patches stay in LDS)
     alg = Mm * b_cand + 2 * nfm * ws[0] * hs[0]                            # + level 0 of every keyframe and current frame once
     out.append({"key": "find_match_direct", "workload": f"Feature_Alignment::FindMatchDirect: {Mm} candidates of {nfm} current frames per call ({ncand} each, {Wm}x{Hm}): "
                             f"SolveAffineMatrix, GetBestSearchLevel, WarpAffine, GetPatchNoBoarder, Align2DGaussNewton (cap 10)",
                 "value": Mm / (ms * 1e-3), "unit": "candidates/s", "us_per_frame": ms * 1e3 / nfm,
                 "matched_fraction": float(d_cv.float().mean().item()),
-                "roofline": roofline_block("warp", alg, ms, None, Mm, b_cand, "candidate",
-                                           {"note": "two launches (warp prelude: lane = candidate for the FP64 chain in the reference's operation "
-                                                    "order, thread = sample for the 10x10 patches; Align2D: four candidates per wavefront); bound by "
-                                                    "dependent FP64 / float chains, the bytes are 433 per candidate + the level-0 images once"})})
+                "roofline": roofline_block("match_kernel", alg, ms, None, Mm, b_cand, "candidate",
+                                           {"note": "ONE launch (round 5; rounds 1-4: two, with 328 B of patches per candidate through HBM): lane = candidate "
+                                                    "for the FP64 chain in the reference's operation order, thread = sample for the 10x10 patches into LDS, "
+                                                    "four candidates per wavefront for Align2D; bound by dependent FP64 / float chains, the bytes are 105 "
+                                                    "per candidate + the level-0 images once"})})
     del d_cur, d_kf, d_rp, d_rb, d_pw, d_px0, d_px, d_scr
 
     # ---- detector image work: 256 frames of 640x480x5 levels per call

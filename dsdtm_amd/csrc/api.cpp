@@ -123,6 +123,7 @@ const OptionKey kOptionKeys[] = {
     {"ws_no_windows", "DSDTM_WS_NO_WINDOWS", &dsdtm::Options::ws_no_windows, true},
     {"ws_no_duo", "DSDTM_WS_NO_DUO", &dsdtm::Options::ws_no_duo, true},
     {"ws_no_sort", "DSDTM_WS_NO_SORT", &dsdtm::Options::ws_no_sort, true},
+    {"fmd_split", "DSDTM_FMD_SPLIT", &dsdtm::Options::fmd_split, true},
     {"pyr_fused", "DSDTM_PYR_FUSED", &dsdtm::Options::pyr_fused, false},
     {"pyr_band", "DSDTM_PYR_BAND", &dsdtm::Options::pyr_band, false},
     {"no_zero_copy", "DSDTM_NO_ZERO_COPY", &dsdtm::Options::no_zero_copy, true},
@@ -1606,14 +1607,19 @@ extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* 
     a.m = m; a.n_kf = n_kf; a.max_search_level = max_search_level; a.levels = p0.levels;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy;
     for (int l = 0; l < p0.levels; ++l) { a.lv[l].w = p0.w[l]; a.lv[l].h = p0.h[l]; a.lv[l].stride = p0.w[l]; a.lv[l].off = (uint32_t)p0.off[l]; }
-    HIP_TRY(ctx, warp_launch(a, ctx->stream));
     A2DKernelArgs b;
     memset(&b, 0, sizeof b);
     b.cur_pyr = cur->d; b.patch_border = d + o_pb; b.patch = d + o_pp; b.level = (const int32_t*)(io + o_sl);
     b.px_xy = (double*)(io + o_px); b.converged = io + o_cv; b.m = m; b.max_iters = max_iters; b.levels = p0.levels;
     b.px_level0 = 1;
     for (int l = 0; l < p0.levels; ++l) b.lv[l] = a.lv[l];
-    HIP_TRY(ctx, align2d_launch(b, ctx->stream));
+    if (options().fmd_split) {                 // rounds 1-4: two kernels, the warped patches through device memory
+        HIP_TRY(ctx, warp_launch(a, ctx->stream));
+        HIP_TRY(ctx, align2d_launch(b, ctx->stream));
+    } else {
+        a.affine = nullptr;                    // (nobody reads it here)
+        HIP_TRY(ctx, match_launch(a, b, ctx->stream));
+    }
     if (!zero_copy) HIP_TRY(ctx, hipMemcpyAsync(h + o_px, d + o_px, out_end - o_px, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(px_xy, h + o_px, M * 16);
@@ -1659,13 +1665,18 @@ extern "C" int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t
     a.m = m; a.n_kf = n_kf; a.max_search_level = max_search_level; a.levels = levels; a.n_frames = n_frames;
     a.fx = cam->fx; a.fy = cam->fy; a.cx = cam->cx; a.cy = cam->cy;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, warp_launch(a, (hipStream_t)hip_stream));
     A2DKernelArgs b;
     memset(&b, 0, sizeof b);
     b.cur_pyr = cur_pyr; b.patch_border = pb; b.patch = pp; b.level = search_level; b.px_xy = px_xy; b.converged = converged;
     b.m = m; b.max_iters = max_iters; b.levels = levels; b.px_level0 = 1; b.frame = cand_frame; b.n_frames = n_frames; b.pyr_pitch = pyr_pitch;
     for (int l = 0; l < levels; ++l) b.lv[l] = a.lv[l];
-    HIP_TRY(ctx, align2d_launch(b, (hipStream_t)hip_stream));
+    if (options().fmd_split) {                 // rounds 1-4: two kernels, the warped patches through `scratch`
+        HIP_TRY(ctx, warp_launch(a, (hipStream_t)hip_stream));
+        HIP_TRY(ctx, align2d_launch(b, (hipStream_t)hip_stream));
+    } else {                                   // one kernel, the patches stay in LDS (`scratch` is not touched)
+        a.affine = nullptr;
+        HIP_TRY(ctx, match_launch(a, b, (hipStream_t)hip_stream));
+    }
     return DSDTM_OK;
 }
 extern "C" size_t dsdtm_match_candidates_scratch_bytes(int m) {

@@ -16,9 +16,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.cpp", "sparse_align.hip", "align2d.hip", "pyrdown.hip", "warp.hip", "detect.hip", "pose_opt.hip",
+SOURCES = ["api.cpp", "sparse_align.hip", "align2d.hip", "pyrdown.hip", "warp.hip", "match.hip", "detect.hip", "pose_opt.hip",
            "selftest.hip"]
-HEADERS = ["kernels.h", "device_math.h", os.path.join("..", "..", "include", "dsdtm_amd.h")]
+HEADERS = ["kernels.h", "device_math.h", "warp_body.h", "align2d_body.h", os.path.join("..", "..", "include", "dsdtm_amd.h")]
 OUT = os.path.join(HERE, "libdsdtm_amd.so")
 TAG = OUT + ".tag"
 OBJ_DIR = os.path.join(HERE, "build")

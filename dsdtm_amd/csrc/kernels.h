@@ -50,6 +50,7 @@ struct Options {
     int team_spread_min = 33;  // DSDTM_TEAM_SPREAD_MIN: team size from which members are spread over all XCDs
     int ws_from = 704;         // DSDTM_WS_FROM: feature counts above this run the workspace kernel in batches
     int ws_no_windows = 0;     // DSDTM_WS_NO_WINDOWS
+    int fmd_split = 0;         // DSDTM_FMD_SPLIT: FindMatchDirect as two kernels with the patches through HBM (rounds 1-4; A/B)
     int ws_no_sort = 0;        // DSDTM_WS_NO_SORT: the workspace kernels walk a pair's features in list order (A/B, tests)
     int ws_no_duo = 0;         // DSDTM_WS_NO_DUO: 1025..2048 patches on one compute unit (HBM workspace) instead of two
     int pyr_fused = 1;         // DSDTM_PYR_FUSED: 0 never / 1 up to 32 images / 2 whenever the shape allows
@@ -149,6 +150,9 @@ struct WarpKernelArgs {
     LevelGeom lv[DSDTM_MAX_LEVELS];
 };
 hipError_t warp_launch(const WarpKernelArgs& args, hipStream_t stream);
+// FindMatchDirect in one launch (match.hip): the warp prelude and Align2D on patches that stay in LDS. `wa.patch_border`,
+// `wa.patch` and `aa.patch_border`, `aa.patch`, `aa.level` are not used (the search level goes out through wa.search_level).
+hipError_t match_launch(const WarpKernelArgs& wa, const A2DKernelArgs& aa, hipStream_t stream);
 
 // Pose-only refinement (Optimizer::PoseOptimization): one wavefront per frame.
 struct PoseOptArgs {

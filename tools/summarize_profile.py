@@ -97,8 +97,9 @@ for case in sorted(os.listdir(src)):
         pyr5 = 640 * 480 + 320 * 240 + 160 * 120 + 80 * 60 + 40 * 30
         # (round 4: Align2D runs 16 features per 256-thread group, the warp prelude 16 candidates per 128-thread group in batches)
         entry("align2d_rows_kernel", [("align2d_rows_kernel", M // 16 * 256)], M * 197 + 1280 * 960)
-        entry("warp_kernel+align2d_rows_kernel", [("warp_kernel", Mm // 16 * 128), ("align2d_rows_kernel", Mm // 16 * 256)],
-              Mm * (4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1 + 2 * (100 + 64)) + 2 * nfm * 640 * 480)
+        # (round 5: FindMatchDirect is ONE kernel, 16 candidates per 256-thread group, the warped patches stay in LDS)
+        entry("match_kernel", [("match_kernel", (Mm + 15) // 16 * 256)],
+              Mm * (4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1) + 2 * nfm * 640 * 480)
         strip_tasks = (640 // 4) * ((480 + 3) // 4)
         sel_tasks = (640 // 4) * 480
         entry("fast_score_strip_kernel+fast_select_rows_kernel+detect_decode_kernel",
