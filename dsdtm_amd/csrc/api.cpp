@@ -124,6 +124,7 @@ const OptionKey kOptionKeys[] = {
     {"ws_no_duo", "DSDTM_WS_NO_DUO", &dsdtm::Options::ws_no_duo, true},
     {"ws_no_sort", "DSDTM_WS_NO_SORT", &dsdtm::Options::ws_no_sort, true},
     {"fmd_split", "DSDTM_FMD_SPLIT", &dsdtm::Options::fmd_split, true},
+    {"match_group", "DSDTM_MATCH_GROUP", &dsdtm::Options::match_group, false},
     {"pyr_fused", "DSDTM_PYR_FUSED", &dsdtm::Options::pyr_fused, false},
     {"pyr_band", "DSDTM_PYR_BAND", &dsdtm::Options::pyr_band, false},
     {"no_zero_copy", "DSDTM_NO_ZERO_COPY", &dsdtm::Options::no_zero_copy, true},

@@ -50,6 +50,7 @@ struct Options {
     int team_spread_min = 33;  // DSDTM_TEAM_SPREAD_MIN: team size from which members are spread over all XCDs
     int ws_from = 704;         // DSDTM_WS_FROM: feature counts above this run the workspace kernel in batches
     int ws_no_windows = 0;     // DSDTM_WS_NO_WINDOWS
+    int match_group = 0;       // DSDTM_MATCH_GROUP: candidates per workgroup of the fused FindMatchDirect kernel (0 = 16; 32 and 64 measured slower)
     int fmd_split = 0;         // DSDTM_FMD_SPLIT: FindMatchDirect as two kernels with the patches through HBM (rounds 1-4; A/B)
     int ws_no_sort = 0;        // DSDTM_WS_NO_SORT: the workspace kernels walk a pair's features in list order (A/B, tests)
     int ws_no_duo = 0;         // DSDTM_WS_NO_DUO: 1025..2048 patches on one compute unit (HBM workspace) instead of two

@@ -4,7 +4,7 @@
 //
 // Rounds 1-4 ran two kernels — warp_kernel (warp.hip) wrote every candidate's 10x10 and 8x8 patches to HBM, align2d_rows_kernel
 // (align2d.hip) read them back: 2 x 164 B of the 433 B a candidate moves, 2.3x the algorithmic bytes of the call, and a kernel
-// boundary in the middle of a 20-us call. Here a 256-thread group carries 16 candidates through three phases:
+// boundary in the middle of a 20-us call. Here a 256-thread group carries its candidates through three phases:
 //   1. lane = candidate (16 lanes): the FP64 chain in the reference's operation order (warp_body.h: warp_candidate);
 //   2. thread = sample: the group's 1600 samples of the bordered patches into LDS (warp_body.h: warp_samples);
 //   3. four candidates per wavefront, one per 16-lane DPP row: Align2D on the LDS patches (align2d_body.h), the level of the
@@ -23,52 +23,71 @@
 
 namespace dsdtm {
 
-constexpr int MATCH_G = 16;         // candidates per 256-thread group (= features per group of align2d_rows_kernel<4>)
+constexpr int MATCH_G = 16;         // candidates per Align2D round of a 256-thread group (= features per group of align2d_rows_kernel<4>)
 
+// CH = candidates per workgroup (a multiple of MATCH_G, at most 64): phase 1 runs once for all of them — CH lanes of the first
+// wavefront, one FP64 chain each — then phases 2 and 3 go through them MATCH_G at a time. Measured (tools/fmd_bench.py,
+// 51 200 candidates / one frame's 816): CH = 16: 62.4 / 17.2 us; 32: 65.3 / 26.2 us; 64: 70.7 / 43.4 us (the two-kernel path:
+// 64.8 / 18.2 us) — the rounds, not the chain, are what a workgroup spends its time on, and amortising the chain only
+// serialises them. CH = 16 is the product shape; the others stay behind DSDTM_MATCH_GROUP for the record.
+template <int CH>
 __global__ __launch_bounds__(256) void match_kernel(const WarpKernelArgs a, const A2DKernelArgs b) {
-    __shared__ WarpCand s_c[MATCH_G];
-    __shared__ int s_sl[MATCH_G];                                       // search level of the group's candidates (-1: rejected)
+    static_assert(CH % MATCH_G == 0 && CH <= 64, "candidates per workgroup");
+    __shared__ WarpCand s_c[CH];
+    __shared__ int s_sl[CH];                                            // search level of the group's candidates (-1: rejected)
     __shared__ __attribute__((aligned(16))) uint8_t s_pb[MATCH_G * 100];
     __shared__ __attribute__((aligned(16))) uint8_t s_pp[MATCH_G * 64];
     __shared__ __attribute__((aligned(16))) float s_prod[MATCH_G][192];
-    const int c0 = (int)blockIdx.x * MATCH_G;
+    const int cb = (int)blockIdx.x * CH;
     const int tid = threadIdx.x;
-    const int ng = a.m - c0 < MATCH_G ? a.m - c0 : MATCH_G;
-    if (tid < ng) {
-        s_c[tid] = warp_candidate(a, c0 + tid);
-        s_sl[tid] = a.search_level[c0 + tid];                           // written by warp_candidate (this thread)
+    const int nb = a.m - cb < CH ? a.m - cb : CH;
+    if (tid < nb) {
+        s_c[tid] = warp_candidate(a, cb + tid);
+        s_sl[tid] = a.search_level[cb + tid];                           // written by warp_candidate (this thread)
     }
     __syncthreads();
-    warp_samples<256>(s_c, ng, tid, s_pb, s_pp);
-    __syncthreads();
-    // ---- Align2DGaussNewton (:318-417) on the patches in LDS; candidate = slot of the group ----
     constexpr int PPL = 4, LPF = 64 / PPL, FPW = 64 / LPF;
     const int lane = tid & 63;
     const int slot = (tid >> 6) * FPW + lane / LPF, l = lane % LPF;
-    const int f = c0 + slot;
-    const bool exists = slot < ng;
-    const int lvl = exists ? s_sl[slot] : -1;
-    const int fr = (exists && b.frame) ? b.frame[f] : 0;
-    const bool valid = exists && !(lvl < 0 || lvl >= b.levels || fr < 0 || (b.frame && fr >= b.n_frames));
-    if (exists && !valid && l == 0) b.converged[f] = 0;                 // rejected candidate: "not converged", pixel untouched
-    const LevelGeom lg = b.lv[valid ? lvl : 0];
-    const uint8_t* __restrict__ img = b.cur_pyr + (size_t)fr * b.pyr_pitch + lg.off;
-    const double lscale = (b.px_level0 && valid) ? (double)(1 << lvl) : 1.0;
-    float u, v;
-    bool converged;
-    align2d_rows_feature<PPL>(valid, img, lg, lg.stride * lg.h, (const uint8_t*)(s_pb + (exists ? slot : 0) * 100),
-                              (const uint8_t*)(s_pp + (exists ? slot : 0) * 64), s_prod[slot],
-                              valid ? b.px_xy[2 * (size_t)f] : 0.0, valid ? b.px_xy[2 * (size_t)f + 1] : 0.0, lscale, b.max_iters, lane, u, v, converged);
-    if (valid && l == 0) {
-        b.px_xy[2 * (size_t)f] = (double)u * lscale;                    // :414 always written back (:154-156 back to level 0)
-        b.px_xy[2 * (size_t)f + 1] = (double)v * lscale;
-        b.converged[f] = converged ? 1 : 0;
+    for (int sub = 0; sub < CH && sub < nb; sub += MATCH_G) {
+        const int c0 = cb + sub;
+        const int ng = nb - sub < MATCH_G ? nb - sub : MATCH_G;
+        warp_samples<256>(s_c + sub, ng, tid, s_pb, s_pp);
+        __syncthreads();
+        // ---- Align2DGaussNewton (:318-417) on the patches in LDS; candidate = slot of the round ----
+        const int f = c0 + slot;
+        const bool exists = slot < ng;
+        const int lvl = exists ? s_sl[sub + slot] : -1;
+        const int fr = (exists && b.frame) ? b.frame[f] : 0;
+        const bool valid = exists && !(lvl < 0 || lvl >= b.levels || fr < 0 || (b.frame && fr >= b.n_frames));
+        if (exists && !valid && l == 0) b.converged[f] = 0;             // rejected candidate: "not converged", pixel untouched
+        const LevelGeom lg = b.lv[valid ? lvl : 0];
+        const uint8_t* __restrict__ img = b.cur_pyr + (size_t)fr * b.pyr_pitch + lg.off;
+        const double lscale = (b.px_level0 && valid) ? (double)(1 << lvl) : 1.0;
+        float u, v;
+        bool converged;
+        align2d_rows_feature<PPL>(valid, img, lg, lg.stride * lg.h, (const uint8_t*)(s_pb + (exists ? slot : 0) * 100),
+                                  (const uint8_t*)(s_pp + (exists ? slot : 0) * 64), s_prod[slot],
+                                  valid ? b.px_xy[2 * (size_t)f] : 0.0, valid ? b.px_xy[2 * (size_t)f + 1] : 0.0, lscale, b.max_iters, lane, u, v, converged);
+        if (valid && l == 0) {
+            b.px_xy[2 * (size_t)f] = (double)u * lscale;                // :414 always written back (:154-156 back to level 0)
+            b.px_xy[2 * (size_t)f + 1] = (double)v * lscale;
+            b.converged[f] = converged ? 1 : 0;
+        }
+        if (CH > MATCH_G) __syncthreads();                              // the next round overwrites the patches
     }
 }
 
 hipError_t match_launch(const WarpKernelArgs& wa, const A2DKernelArgs& aa, hipStream_t stream) {
     if (wa.m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(match_kernel, dim3((unsigned)((wa.m + MATCH_G - 1) / MATCH_G)), dim3(256), 0, stream, wa, aa);
+    const int ch = options().match_group ? options().match_group : 16;
+    const dim3 grid((unsigned)((wa.m + ch - 1) / ch));
+    switch (ch) {
+        case 16: hipLaunchKernelGGL(match_kernel<16>, grid, dim3(256), 0, stream, wa, aa); break;
+        case 32: hipLaunchKernelGGL(match_kernel<32>, grid, dim3(256), 0, stream, wa, aa); break;
+        case 64: hipLaunchKernelGGL(match_kernel<64>, grid, dim3(256), 0, stream, wa, aa); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
