@@ -124,6 +124,7 @@ const OptionKey kOptionKeys[] = {
     {"ws_no_duo", "DSDTM_WS_NO_DUO", &dsdtm::Options::ws_no_duo, true},
     {"ws_no_sort", "DSDTM_WS_NO_SORT", &dsdtm::Options::ws_no_sort, true},
     {"fmd_split", "DSDTM_FMD_SPLIT", &dsdtm::Options::fmd_split, true},
+    {"fmd_no_xcd", "DSDTM_FMD_NO_XCD", &dsdtm::Options::fmd_no_xcd, true},
     {"match_group", "DSDTM_MATCH_GROUP", &dsdtm::Options::match_group, false},
     {"pyr_fused", "DSDTM_PYR_FUSED", &dsdtm::Options::pyr_fused, false},
     {"pyr_band", "DSDTM_PYR_BAND", &dsdtm::Options::pyr_band, false},
@@ -1618,7 +1619,7 @@ extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* 
         HIP_TRY(ctx, warp_launch(a, ctx->stream));
         HIP_TRY(ctx, align2d_launch(b, ctx->stream));
     } else {
-        a.affine = nullptr;                    // (nobody reads it here)
+        a.affine = nullptr; a.no_xcd = options().fmd_no_xcd;                    // (nobody reads it here)
         HIP_TRY(ctx, match_launch(a, b, ctx->stream));
     }
     if (!zero_copy) HIP_TRY(ctx, hipMemcpyAsync(h + o_px, d + o_px, out_end - o_px, hipMemcpyDeviceToHost, ctx->stream));
@@ -1675,7 +1676,7 @@ extern "C" int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t
         HIP_TRY(ctx, warp_launch(a, (hipStream_t)hip_stream));
         HIP_TRY(ctx, align2d_launch(b, (hipStream_t)hip_stream));
     } else {                                   // one kernel, the patches stay in LDS (`scratch` is not touched)
-        a.affine = nullptr;
+        a.affine = nullptr; a.no_xcd = options().fmd_no_xcd;
         HIP_TRY(ctx, match_launch(a, b, (hipStream_t)hip_stream));
     }
     return DSDTM_OK;

@@ -51,6 +51,7 @@ struct Options {
     int ws_from = 704;         // DSDTM_WS_FROM: feature counts above this run the workspace kernel in batches
     int ws_no_windows = 0;     // DSDTM_WS_NO_WINDOWS
     int match_group = 0;       // DSDTM_MATCH_GROUP: candidates per workgroup of the fused FindMatchDirect kernel (0 = 16; 32 and 64 measured slower)
+    int fmd_no_xcd = 0;        // DSDTM_FMD_NO_XCD: the fused FindMatchDirect kernel with plain block numbering (A/B)
     int fmd_split = 0;         // DSDTM_FMD_SPLIT: FindMatchDirect as two kernels with the patches through HBM (rounds 1-4; A/B)
     int ws_no_sort = 0;        // DSDTM_WS_NO_SORT: the workspace kernels walk a pair's features in list order (A/B, tests)
     int ws_no_duo = 0;         // DSDTM_WS_NO_DUO: 1025..2048 patches on one compute unit (HBM workspace) instead of two
@@ -147,6 +148,7 @@ struct WarpKernelArgs {
     const int32_t* cand_frame;    // optional, M: the candidate's current frame
     int n_frames;                 // with cand_frame: indices outside [0, n_frames) are rejected like an invalid cand_kf
     int m, n_kf, max_search_level, levels;
+    int no_xcd;                   // match_kernel: plain block numbering (A/B)
     float fx, fy, cx, cy;
     LevelGeom lv[DSDTM_MAX_LEVELS];
 };

@@ -38,7 +38,15 @@ __global__ __launch_bounds__(256) void match_kernel(const WarpKernelArgs a, cons
     __shared__ __attribute__((aligned(16))) uint8_t s_pb[MATCH_G * 100];
     __shared__ __attribute__((aligned(16))) uint8_t s_pp[MATCH_G * 64];
     __shared__ __attribute__((aligned(16))) float s_prod[MATCH_G][192];
-    const int cb = (int)blockIdx.x * CH;
+    // XCD-aware block numbering (workgroups go to the 8 XCDs round-robin, each XCD has its own L2): every XCD takes a contiguous
+    // range of candidate groups, i.e. of current frames / keyframes, instead of every eighth group of every frame — each
+    // frame's images are then fetched by one L2 instead of by all eight. The work per group is uniform, so the ranges balance.
+    unsigned lb = blockIdx.x;
+    {
+        const unsigned q = gridDim.x / 8u;
+        if (!a.no_xcd && lb < q * 8u) lb = (lb % 8u) * q + lb / 8u;
+    }
+    const int cb = (int)lb * CH;
     const int tid = threadIdx.x;
     const int nb = a.m - cb < CH ? a.m - cb : CH;
     if (tid < nb) {
