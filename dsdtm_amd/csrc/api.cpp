@@ -150,7 +150,7 @@ dsdtm::Options& dsdtm::options() {
 
 extern "C" {
 
-const char* dsdtm_version(void) { return "dsdtm_amd 0.4 (gfx950, HIP; FP64 reference grid)"; }
+const char* dsdtm_version(void) { return "dsdtm_amd 0.5 (gfx950, HIP; FP64 reference grid)"; }
 
 int dsdtm_device_count(void) {
     int n = 0;

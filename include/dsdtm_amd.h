@@ -229,8 +229,10 @@ int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* cur, const 
  * current frame of candidate i (T_cur_w: n_frames x 12), cand_kf[i] its reference keyframe; a candidate whose
  * cand_frame is outside [0, n_frames), cand_kf outside [0, n_kf) or ref_level outside the pyramid is rejected on the
  * device (search_level -1, converged 0, pixel untouched) — never dereferenced. scratch:
- * dsdtm_match_candidates_scratch_bytes(m) bytes, 16-byte aligned (affine matrices and warped patches; overwritten). px_xy in/out in
- * level-0 pixels, as above. Replaces FindMatchDirect (src/Feature_alignment.cpp:128-158) per candidate. */
+ * dsdtm_match_candidates_scratch_bytes(m) bytes, 16-byte aligned (kept in the signature: since library 0.5 the warp prelude and
+ * Align2D run as ONE kernel and the warped patches stay on chip; only the two-kernel diagnostic path writes them here). px_xy in/out in
+ * level-0 pixels, as above. Candidates of one current frame should be contiguous in the arrays (as a tracker produces them): the
+ * kernel gives each of the GPU's eight L2 caches a contiguous range of candidates, so that a frame's images are fetched once. Replaces FindMatchDirect (src/Feature_alignment.cpp:128-158) per candidate. */
 int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t* cur_pyr, int n_frames, const uint8_t* kf_pyr, int n_kf,
                                         size_t pyr_pitch, int levels, const int* width, const int* height, const int* stride,
                                         const size_t* level_offset, const dsdtm_camera* cam, const double* T_kf_w,
