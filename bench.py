@@ -1172,9 +1172,8 @@ def main():
         if rc == 0 and world == 1 and not args.no_secondary:
             try:
                 out["secondary"] = secondary_entries(torch, dev, ctx, cam_struct, stream, args)
-            except Exception as e:          # the headline was measured before this: it is printed whatever happens here
-                out["secondary_error"] = f"{type(e).__name__}: {e}"
-                rc = 3
+            except Exception as e:          # the headline was measured and checked before this: it is printed whatever happens
+                out["secondary_error"] = f"{type(e).__name__}: {e}"     # here, and the run stays a success (the error is in the line)
         # secondary entries: one short line each, BEFORE the headline; full objects (with their notes) -> bench_secondary.json;
         # the LAST stdout line is the compact headline, < 4 KB (bench_line.py asserts it)
         bench_line.emit(out, ROOT)
