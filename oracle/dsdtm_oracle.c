@@ -28,12 +28,9 @@
  * =================================================================================== */
 #include "mutants.h"
 #ifdef ORACLE_MUTANTS
-static int oracle_mutant = MUT_NONE;
-void oracle_set_mutant(int id) { oracle_mutant = id; }
-int oracle_get_mutant(void) { return oracle_mutant; }
-#define MUT(id) (oracle_mutant == (id))
-#else
-#define MUT(id) 0
+int oracle_mutant_id = MUT_NONE;
+void oracle_set_mutant(int id) { oracle_mutant_id = id; }
+int oracle_get_mutant(void) { return oracle_mutant_id; }
 #endif
 
 /* ===================================================================================

@@ -38,17 +38,28 @@ enum oracle_mutant_id {
     MUT_W1_FLOATDIV = 30, /* :231     1.0f/(1<<level) instead of the integer division                        */
     MUT_W2_ROUND = 31,    /* :254     rounding instead of truncation to u8                                   */
     MUT_W2_REFLEVEL = 32, /* :215-216 reference pixel not divided by its level's scale                       */
-    MUT_A13_DET = 33      /* :198     search level raised at det > 2 instead of det > 3                      */
+    MUT_A13_DET = 33,     /* :198     search level raised at det > 2 instead of det > 3                      */
+    /* pose-only refinement — src/Optimizer.cpp:20-101, include/Optimizer.h:129-250 (pose_opt_oracle.c) */
+    MUT_P1_JSCALE = 40,   /* h:162,176 the Jacobian divided by 1 << level like the residual (the reference does not)  */
+    MUT_P2_NOLOSS = 41,   /* cpp:33   no robust loss instead of CauchyLoss(1.0)                                      */
+    MUT_P3_PLUS = 42,     /* h:222-236 Plus as a vector sum instead of SE3(delta) * SE3(x)                            */
+    MUT_P4_ALLFEAT = 43,  /* cpp:47-65 residual blocks for every feature, not only Mpt && !IsBad && mbInitial         */
+    MUT_P5_PIXELS = 44,   /* h:160    observation taken as bearing.xy (not divided by bearing.z)                      */
+    MUT_P6_ITERS = 45     /* cpp:70   max_num_iterations 10 instead of 100                                           */
 };
 
 #ifdef ORACLE_MUTANTS
 #ifdef __cplusplus
 extern "C" {
 #endif
+extern int oracle_mutant_id;            /* defined in dsdtm_oracle.c */
 void oracle_set_mutant(int id);
 int oracle_get_mutant(void);
 #ifdef __cplusplus
 }
 #endif
+#define MUT(id) (oracle_mutant_id == (id))
+#else
+#define MUT(id) 0
 #endif
 #endif

@@ -50,6 +50,7 @@
 #include <string.h>
 
 #include "dsdtm_oracle.h"
+#include "mutants.h"     /* MUT(x): 0 in the faithful build (see dsdtm_oracle.c) */
 
 #define SMALL_EPS 1e-10
 
@@ -89,6 +90,7 @@ static void pose_of(const double x[6], oracle_se3* T) {
 
 /* PoseLocalParameterization::Plus (include/Optimizer.h:222-236) */
 void oracle_pose_plus(const double x[6], const double delta[6], double out[6]) {
+    if (MUT(MUT_P3_PLUS)) { for (int k = 0; k < 6; ++k) out[k] = x[k] + delta[k]; return; }   /* "fixed": plain vector sum */
     oracle_se3 To, Td, Tn;
     pose_of(x, &To);
     pose_of(delta, &Td);
@@ -133,6 +135,7 @@ static void block_eval(const blocks_t* b, int i, const oracle_se3* T, double r[2
         J[9] = 1.0 + y * J[8];
         J[10] = -x * J[8];
         J[11] = -x * z_inv;
+        if (MUT(MUT_P1_JSCALE)) for (int k = 0; k < 12; ++k) J[k] /= b->inv[i];   /* "fixed": scaled like the residual */
     }
 }
 
@@ -154,7 +157,8 @@ static int evaluate(const blocks_t* b, const double x[6], double* cost, double* 
         const double sum = 1.0 + s * 1.0;
         const double inv = 1.0 / sum;
         const double rho0 = 1.0 * log(sum);
-        const double rho1 = inv > DBL_MIN ? inv : DBL_MIN;
+        double rho1 = inv > DBL_MIN ? inv : DBL_MIN;
+        if (MUT(MUT_P2_NOLOSS)) { c += 0.5 * s - 0.5 * rho0; rho1 = 1.0; }   /* "fixed": TrivialLoss (rho = s) */
         c += 0.5 * rho0;
         if (jac) {
             const double sq = sqrt(rho1);            /* Corrector, alpha = 0 (rho'' < 0) */
@@ -258,7 +262,7 @@ int oracle_pose_optimization(const double* bearing, const double* p_world, const
 
     /* residual blocks in feature order (src/Optimizer.cpp:45-65) */
     int n = 0;
-    for (int i = 0; i < n_features; ++i) n += use[i] != 0;
+    for (int i = 0; i < n_features; ++i) n += (use[i] != 0 || MUT(MUT_P4_ALLFEAT));
     double* obs = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * 2);
     double* pw = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * 3);
     double* inv = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
@@ -268,9 +272,10 @@ int oracle_pose_optimization(const double* bearing, const double* p_world, const
     double* lhs = (double*)malloc(sizeof(double) * (size_t)m * 6);
     double* rhs = (double*)malloc(sizeof(double) * (size_t)m);
     for (int i = 0, k = 0; i < n_features; ++i) {
-        if (!use[i]) continue;
+        if (!use[i] && !MUT(MUT_P4_ALLFEAT)) continue;
         obs[2 * k] = bearing[3 * i] / bearing[3 * i + 2];       /* include/Optimizer.h:160 */
         obs[2 * k + 1] = bearing[3 * i + 1] / bearing[3 * i + 2];
+        if (MUT(MUT_P5_PIXELS)) { obs[2 * k] = bearing[3 * i]; obs[2 * k + 1] = bearing[3 * i + 1]; }
         pw[3 * k] = p_world[3 * i]; pw[3 * k + 1] = p_world[3 * i + 1]; pw[3 * k + 2] = p_world[3 * i + 2];
         inv[k] = (double)(1 << level[i]);
         ++k;
@@ -321,7 +326,7 @@ int oracle_pose_optimization(const double* bearing, const double* p_world, const
                 trace[4 * it] = x_cost; trace[4 * it + 1] = radius; trace[4 * it + 2] = gradient_max_norm;
                 trace[4 * it + 3] = (double)successful;
             }
-            if (it >= prm->max_iterations) { termination = DSDTM_PO_MAX_ITERATIONS; break; }
+            if (it >= (MUT(MUT_P6_ITERS) ? 10 : prm->max_iterations)) { termination = DSDTM_PO_MAX_ITERATIONS; break; }
             if (gradient_max_norm <= 1e-10) { termination = DSDTM_PO_GRADIENT_TOLERANCE; break; }
             if (radius <= 1e-32) { termination = DSDTM_PO_MIN_RADIUS; break; }
             ++it;

@@ -39,6 +39,12 @@ TABLE = {
     "MUT_W2_ROUND":    ("warp", "patch_border bytes", "W2", "src/Feature_alignment.cpp:254"),
     "MUT_W2_REFLEVEL": ("warp", "patch_border bytes", "W2", "src/Feature_alignment.cpp:215-216"),
     "MUT_A13_DET":     ("warp", "search_level", "a13", "src/Feature_alignment.cpp:198"),
+    "MUT_P1_JSCALE":   ("pose_opt", "iterations", "f3", "include/Optimizer.h:162,176-189"),
+    "MUT_P2_NOLOSS":   ("pose_opt", "pose", "f3", "src/Optimizer.cpp:33"),
+    "MUT_P3_PLUS":     ("pose_opt", "iterations", "f3", "include/Optimizer.h:222-236"),
+    "MUT_P4_ALLFEAT":  ("pose_opt", "n_residual_blocks", "f3", "src/Optimizer.cpp:47-65"),
+    "MUT_P5_PIXELS":   ("pose_opt", "pose", "f3", "include/Optimizer.h:160"),
+    "MUT_P6_ITERS":    ("pose_opt", "iterations", "f3", "src/Optimizer.cpp:70"),
     "S1_SHUFFLE":      ("search:std", "match count", "S1", "src/Feature_alignment.cpp:38-43,75"),
     "S1_NOCAP":        ("search:dense", "match count", "S1", "src/Feature_alignment.cpp:80"),
     "S1_NOSORT":       ("search:std", "match count", "S1", "src/Feature_alignment.cpp:88,123-126"),
@@ -61,7 +67,7 @@ _FIXTURES = {}
 
 def fixtures():
     if not _FIXTURES:
-        _FIXTURES.update(sparse=Q.sparse_cases(), align2d=Q.align2d_cases(), warp=Q.warp_cases())
+        _FIXTURES.update(sparse=Q.sparse_cases(), align2d=Q.align2d_cases(), warp=Q.warp_cases(), pose_opt=Q.pose_problems())
     return _FIXTURES
 
 
@@ -69,7 +75,7 @@ def domain(mutant):
     return TABLE[mutant][0].split(":")[0] if mutant else None
 
 
-def cpu_outputs(mutant=None, domains=("sparse", "align2d", "warp", "search"), search_worlds=None):
+def cpu_outputs(mutant=None, domains=("sparse", "align2d", "warp", "search", "pose_opt"), search_worlds=None):
     """{case: outputs} from the CPU restatement with `mutant` switched (None: the faithful one), for the given domains."""
     fx = fixtures()
     c_mut = mutant if (mutant and mutant.startswith("MUT_")) else None
@@ -84,6 +90,9 @@ def cpu_outputs(mutant=None, domains=("sparse", "align2d", "warp", "search"), se
             out["align2d"] = oracle_lib.align2d_batch(a["pyr"], a["patch_border"], a["patch"], a["level"], a["px0"], 10)
         if "warp" in domains:
             out["warp"] = Q.warp_outputs(oracle_lib.warp_patches, fx["warp"])
+        if "pose_opt" in domains:
+            out["pose_opt"] = [oracle_lib.pose_optimization(P.bearing, P.p_world, P.level, P.use, P.T_seed, linear_solver=0)
+                               for P in fx["pose_opt"]]
         if "search" in domains:
             for name in (search_worlds or Q.SEARCH_WORLDS):
                 out["search:" + name] = Q.search_restated(name, mutant=s_mut)
@@ -97,6 +106,8 @@ def first_difference(case, a, b):
         return Q.align2d_first_difference(a, b)
     if case == "warp":
         return Q.warp_first_difference(a, b)
+    if case == "pose_opt":
+        return Q.pose_first_difference(a, b)
     return Q.search_first_difference(a, b)
 
 

@@ -282,3 +282,33 @@ def search_first_difference(a, b):
     if not np.array_equal(ma, mb):
         return "mask"
     return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pose-only refinement problems (Optimizer::PoseOptimization): observations on levels 0..3 (the residual is divided by
+# 1 << level, the Jacobian is not), outliers (the Cauchy loss), unused features (Mpt / IsBad / mbInitial), a seed far enough
+# from the optimum for tens of iterations
+# ---------------------------------------------------------------------------------------------------------------
+POSE_PROBLEMS = [dict(seed=101, n=200, max_level=3, outlier_frac=0.15, unused_frac=0.2),
+                 dict(seed=102, n=120, max_level=3, seed_t=0.12, seed_w=0.1, unused_frac=0.1),
+                 dict(seed=103, n=300, max_level=2, outlier_frac=0.3, noise_px=1.0, unused_frac=0.25)]
+
+
+def pose_problems():
+    return [synth.make_pose_problem(**kw) for kw in POSE_PROBLEMS]
+
+
+def pose_first_difference(a, b, tol=1e-10):
+    """a, b = lists of (T, residual norms, summary): the assertions of tests/test_pose_opt_gpu.py::assert_same."""
+    for (Ta, ra, sa), (Tb, rb, sb) in zip(a, b):
+        for k in ("n_residual_blocks", "iterations", "successful_steps", "termination"):
+            if sa[k] != sb[k]:
+                return k
+        ang, dt = synth.pose_error(Ta, Tb)
+        if not (ang <= tol and dt <= tol):
+            return "pose"
+        if len(ra) != len(rb) or not np.allclose(ra, rb, rtol=0, atol=tol):
+            return "residual norms"
+        if not np.allclose([sa["initial_cost"], sa["final_cost"]], [sb["initial_cost"], sb["final_cost"]], rtol=1e-10, atol=1e-300):
+            return "cost"
+    return None

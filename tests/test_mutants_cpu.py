@@ -70,10 +70,14 @@ def test_mutation_build_with_no_switch_is_the_faithful_oracle(faithful):
     """-DORACLE_MUTANTS alone changes nothing: every output bit for bit (so a difference below is the switch, not the build)."""
     with oracle_lib.mutant("MUT_NONE") as lib:
         assert lib.oracle_get_mutant() == 0
-        o = M.cpu_outputs(domains=("sparse", "align2d", "warp"))
+        o = M.cpu_outputs(domains=("sparse", "align2d", "warp", "pose_opt"))
     for case, a in o.items():
         b = faithful[case]
-        if case.startswith("sparse:"):
+        if case == "pose_opt":
+            for (Ta, ra, sa), (Tb, rb, sb) in zip(a, b):
+                assert np.array_equal(Ta, Tb) and np.array_equal(ra, rb)
+                assert all(np.array_equal(sa[k], sb[k]) for k in sa)
+        elif case.startswith("sparse:"):
             assert np.array_equal(a["T"], b["T"], equal_nan=True) and {k: a[k] for k in a if k != "T" and k != "chi2"} == {k: b[k] for k in b if k != "T" and k != "chi2"}
             assert np.array_equal(a["chi2"], b["chi2"], equal_nan=True)
         else:
@@ -84,6 +88,7 @@ def test_every_quirk_of_the_survey_has_a_mutant():
     quirks = {row[2] for row in M.TABLE.values()}
     assert {"Q1", "Q3", "Q4", "Q5", "Q6", "Q8", "Q9", "Q10", "Q11", "A1", "A2", "A3", "A4", "W1", "W2", "W3", "S1"} <= quirks
     assert {m for m in M.TABLE if m.startswith("MUT_")} == set(oracle_lib.MUTANTS) - {"MUT_NONE"}
+    assert sum(1 for m in M.TABLE if M.domain(m) == "pose_opt") >= 6          # Optimizer::PoseOptimization too
     from tests import search_restatement as SR
     assert {m for m in M.TABLE if not m.startswith("MUT_")} == set(SR.SEARCH_MUTANTS)
 

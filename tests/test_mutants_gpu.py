@@ -11,6 +11,7 @@ import pytest
 
 from dsdtm_amd import feature_alignment as FA
 from dsdtm_amd import search
+from dsdtm_amd.optimizer import pose_optimization
 from tests import helpers as H
 from tests import mutant_runs as M
 from tests import quirk_fixtures as Q
@@ -42,6 +43,11 @@ def hip(gpu_ctx):
     out["warp"] = Q.warp_outputs(lambda *args: FA.warp_patches(*args, ctx=gpu_ctx), fx["warp"])
     for name in Q.SEARCH_WORLDS:
         out["search:" + name] = gpu_search(gpu_ctx, name)
+    out["pose_opt"] = []
+    for P in fx["pose_opt"]:
+        T = np.ascontiguousarray(P.T_seed, np.float64).reshape(12).copy()
+        rn, sm = pose_optimization(gpu_ctx, P.bearing, P.p_world, P.level, P.use, T)
+        out["pose_opt"].append((T.reshape(3, 4), rn, sm))
     return out
 
 
