@@ -1233,6 +1233,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
 
     // ---------------------------------- patch waves ----------------------------------
     unsigned seen = 0;                                                 // states consumed so far
+    unsigned pairs_done = 0;                                           // pairs this slot has finished (issue priority alternates, below)
     const int row = lane >> 4;
     const bool row_writer = (lane & 15) == 15;
     WavePartial& my_part = s_part[wave * 4 + row];
@@ -1258,6 +1259,16 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
             F = make_feature(fraw, Cref);
         }
         for (int level = a.max_level - 1; level >= a.min_level; --level) {
+            // ISSUE PRIORITY BETWEEN THE TWO SLOTS. The second slot's waves are the younger half of the workgroup and lose the issue
+            // arbitration to the first slot's: measured (tools/stamps.py) its pairs took 97.0 us against 85.3 us, so the first
+            // slot sat idle for the last 23 us of a launch on the average CU. A static priority would only swap the roles
+            // (measured); alternating it PER PAIR — second slot favoured on its first pair, first slot on its second, ... —
+            // evens them out: 91.2 / 92.0 us per pair, both slots end within 2.3 us of each other, one launch 204.7 -> 196 us.
+            // (Per level instead of per pair: half the gain; with three or four slots per workgroup — 190 / 120 patches — the same
+            // rule measured flat or slightly negative, so only the two-slot shapes use it; profiles/r05_tail.txt §5.)
+            if (PPW == 2) {
+                if ((pairs_done + slot) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
             const LevelGeom lg = a.lv[level];
             const double scale = (double)(1.0f / (float)(1 << level));
             const double fs = (double)a.f * scale;
@@ -1342,6 +1353,7 @@ __global__ __launch_bounds__(PPW * (NPW + 1) * 64) void sparse_align_reg_kernel(
                 if (s.ctrl) break;
             }
         }
+        ++pairs_done;
         pair_signal_arrive(&s.ack, lane);                              // done with this pair's shared state
         if (STAMPS && lane == 0 && a.workspace) {                      // every patch wave: pass and barrier cycles
             unsigned long long* o = (unsigned long long*)a.workspace + (size_t)a.n_pairs * 20 + (size_t)pair * 16;

@@ -111,3 +111,10 @@ print("  pair duration: first of a slot %.1f us, later pairs %.1f us (mean); p95
 cu = slots // 2
 alone = np.array([abs(last_end[cu == c][0] - last_end[cu == c][-1]) for c in np.unique(cu)]) / 100.0
 print("  per CU, time one slot runs alone at the end: mean %.1f us, p95 %.1f us" % (alone.mean(), np.percentile(alone, 95)))
+# arbitration by age: is the workgroup's second slot (its waves are the younger half) systematically slower than the first?
+s0, s1 = dur_rt[slot % 2 == 0], dur_rt[slot % 2 == 1]
+print("  pair duration by slot of the workgroup: slot 0 %.1f us (p95 %.1f), slot 1 %.1f us (p95 %.1f)" % (s0.mean(), np.percentile(s0, 95), s1.mean(), np.percentile(s1, 95)))
+le0 = np.array([last_end[np.searchsorted(slots, k)] for k in slots if k % 2 == 0]); le1 = np.array([last_end[np.searchsorted(slots, k)] for k in slots if k % 2 == 1])
+print("  a slot's last end after the launch's first begin: slot 0 %.1f us, slot 1 %.1f us (mean)" % ((le0 - T0).mean() / 100.0, (le1 - T0).mean() / 100.0))
+pwv = pw[:, :5] / np.maximum(n_it, 1)[:, None]
+print("  pass cycles per iteration by patch wave, slot 0: " + " ".join("%.0f" % v for v in pwv[slot % 2 == 0].mean(0)) + " | slot 1: " + " ".join("%.0f" % v for v in pwv[slot % 2 == 1].mean(0)))
