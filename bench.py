@@ -374,13 +374,16 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
     from tests import oracle_lib
     out = []
     lib = oracle_lib.load()
-    for name, width, height, n_pairs, n_patches, launches in (
-            ("config 3 shape: 640x480, 4 levels, 1000 patches, cap 10", 640, 480, 1024, 1000, 10),
-            ("config 5 shape: 1280x960, 4 levels, 2000 patches, cap 10", 1280, 960, 256, 2000, 10)):
+    for name, width, height, n_pairs, n_patches, launches, levels, iters in (
+            ("config 3 shape: 640x480, 4 levels, 1000 patches, cap 10", 640, 480, 1024, 1000, 10, args.levels, args.iters),
+            ("config 5 shape: 1280x960, 4 levels, 2000 patches, cap 10", 1280, 960, 256, 2000, 10, args.levels, args.iters),
+            # what DSDTM's Tracking really constructs (src/Tracking.cpp:20-24,37; Config/default.yaml:64-65,93): 5 levels, 8 iterations,
+            # Camera.Max_tkfts = 200 features per frame
+            ("Tracking's own arguments: 640x480, 5 levels, 190 patches, cap 8", 640, 480, 1024, 190, 10, 5, 8)):
         cam = synth.Camera.tum(width, height)
         cs = capi.camera_struct(cam)
-        prm = capi.AlignParams(args.levels, 0, args.iters, 15)
-        d = build_batch(torch, dev, ctx, cam, n_pairs, width, height, args.levels, n_patches, seed=0xC0DE + n_patches, stream=stream)
+        prm = capi.AlignParams(levels, 0, iters, 15)
+        d = build_batch(torch, dev, ctx, cam, n_pairs, width, height, levels, n_patches, seed=0xC0DE + n_patches, stream=stream)
         desc = d["desc"]
 
         def launch(s, d=d, desc=desc, cs=cs, prm=prm):
@@ -406,7 +409,7 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
         ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, stream.cuda_stream))
         t = [a.elapsed_time(b) for a, b in ev]
         ms_avg, ms_min = float(np.mean(t)), float(np.min(t))
-        b_alg = algorithmic_bytes(width, height, args.levels, n_patches)
+        b_alg = algorithmic_bytes(width, height, levels, n_patches)
         # the same launches issued on four streams in turn, as the main line issues its steps (each launch in flight has
         # its own pose / count buffers; the statistics buffer is shared and not read here)
         ns, nl = 4, 24
@@ -439,7 +442,7 @@ def secondary_entries(torch, dev, ctx, cam_struct_640, stream, args):
         dl = np.array([synth.pose_error(Tg[i], hb.T[i]) for i in range(sample)])
         stats = np.frombuffer(d["stats"][:sample].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
         out.append({
-            "key": f"align_{n_pairs}x{n_patches}_{width}x{height}",
+            "key": f"align_{n_pairs}x{n_patches}_{width}x{height}" + ("" if (levels, iters) == (args.levels, args.iters) else f"_L{levels}_cap{iters}"),
             "workload": f"{n_pairs} independent pairs per launch, {name}",
             "value": n_pairs / (ms_avg * 1e-3), "unit": "alignments/s",
             "value_note": "one launch at a time (HIP events around every launch)",

@@ -102,9 +102,9 @@ def test_bench_last_line_is_compact_with_every_secondary_entry():
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     assert out["pose_delta_vs_cpu"]["max_rad"] <= 1e-4 and out["pose_delta_vs_cpu"]["max_m"] <= 1e-4 and out["pose_delta_vs_cpu"]["pairs_checked"] == 8
     sec = [json.loads(l) for l in lines[:-1] if l.startswith('{"secondary"')]
-    assert len(sec) == out["secondary"]["entries"] >= 12 and all(len(l) < 1024 for l in lines[:-1] if l.startswith("{"))
+    assert len(sec) == out["secondary"]["entries"] >= 13 and all(len(l) < 1024 for l in lines[:-1] if l.startswith("{"))
     keys = {e["secondary"] for e in sec}
-    for k in ("align_1024x1000_640x480", "align_256x2000_1280x960", "pyramid", "align2d", "pose_opt", "find_match_direct", "detector",
+    for k in ("align_1024x1000_640x480", "align_256x2000_1280x960", "align_1024x190_640x480_L5_cap8", "pyramid", "align2d", "pose_opt", "find_match_direct", "detector",
               "run_one_pair_config2", "run_one_pair_config3", "run_one_pair_config5", "tracked_frame", "streamed_host_fed"):
         assert k in keys, (k, keys)
     with open(os.path.join(ROOT, "bench_secondary.json")) as f:
