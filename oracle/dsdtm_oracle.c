@@ -754,8 +754,8 @@ int oracle_align2d_batch(const dsdtm_pyramid* cur, const uint8_t* patch_border, 
 static int reflect101(int p, int len) {
     if (len == 1) return 0;
     while (p < 0 || p >= len) {
-        if (p < 0) p = -p;
-        else p = 2 * len - 2 - p;
+        if (p < 0) p = MUT(MUT_PD_BORDER) ? -p - 1 : -p;
+        else p = MUT(MUT_PD_BORDER) ? 2 * len - 1 - p : 2 * len - 2 - p;
     }
     return p;
 }
@@ -776,7 +776,7 @@ void oracle_pyrdown(const uint8_t* src, int w, int h, int sstride, uint8_t* dst,
         }
         for (int x = 0; x < dw; ++x) {
             int v = rowbuf[2 * dw + x] * 6 + (rowbuf[dw + x] + rowbuf[3 * dw + x]) * 4 + rowbuf[x] + rowbuf[4 * dw + x];
-            dst[(size_t)y * dstride + x] = (uint8_t)((v + 128) >> 8);
+            dst[(size_t)y * dstride + x] = (uint8_t)((v + (MUT(MUT_PD_ROUND) ? 127 : 128)) >> 8);
         }
     }
     free(rowbuf);
@@ -950,7 +950,7 @@ void oracle_fast10(const uint8_t* img, int w, int h, int stride, int barrier, ui
     for (int y = 3; y < h - 3; ++y)
         for (int x = 3; x < w - 3; ++x) {
             const int m = fast10_margin(img + (size_t)y * stride + x, stride);
-            if (m > barrier) score[(size_t)y * w + x] = (uint8_t)(m - 1);     /* fast_10_score.cpp:22-3140 */
+            if (m > barrier) score[(size_t)y * w + x] = (uint8_t)(MUT(MUT_D_SCORE) ? m : m - 1);     /* fast_10_score.cpp:22-3140 */
         }
     /* nonmax_3x3.cpp:47-106: every comparison is `neighbour score >= own score` */
     for (int y = 3; y < h - 3; ++y)
@@ -962,7 +962,7 @@ void oracle_fast10(const uint8_t* img, int w, int h, int stride, int barrier, ui
                 for (int dx = -1; dx <= 1; ++dx) {
                     if (!dx && !dy) continue;
                     const int n = score[(size_t)(y + dy) * w + (x + dx)];
-                    if (n && n >= s) { sup = 1; break; }
+                    if (n && (MUT(MUT_D_NMS_TIE) ? n > s : n >= s)) { sup = 1; break; }
                 }
             keep[(size_t)y * w + x] = (uint8_t)!sup;
         }
@@ -993,10 +993,10 @@ int oracle_fast10_list(const uint8_t* img, int w, int h, int stride, int barrier
  * cannot be built here — OpenCV). */
 float oracle_shi_tomasi(const uint8_t* img, int w, int h, int stride, int u, int v) {
     float dXX = 0.0f, dYY = 0.0f, dXY = 0.0f;
-    const int halfbox_size = 4, box_size = 8, box_area = 64;
+    const int halfbox_size = 4, box_size = MUT(MUT_D_BOX) ? 9 : 8, box_area = 64;
     const int x_min = u - halfbox_size, x_max = u + halfbox_size, y_min = v - halfbox_size, y_max = v + halfbox_size;
     if (x_min < 1 || x_max >= w - 1 || y_min < 1 || y_max >= h - 1) return 0.0f;      /* :173 */
-    for (int y = y_min; y < y_max; ++y) {
+    for (int y = y_min; y < (MUT(MUT_D_BOX) ? y_max + 1 : y_max); ++y) {
         const uint8_t* l = img + (size_t)stride * y + x_min - 1;
         const uint8_t* r = img + (size_t)stride * y + x_min + 1;
         const uint8_t* t = img + (size_t)stride * (y - 1) + x_min;
@@ -1033,7 +1033,7 @@ void oracle_detect_cells(const dsdtm_pyramid* pyr, int levels, int cell_size, in
                 if (k < 0 || k >= G) continue;
                 if (grid_occupied && grid_occupied[k]) continue;                    /* :100 */
                 const float sc = oracle_shi_tomasi(img, w, h, st, x, y);            /* :103 */
-                if (sc > cell_score[k]) {                                           /* :104-107 */
+                if (MUT(MUT_D_CELLMAX) ? sc >= cell_score[k] : sc > cell_score[k]) {    /* :104-107 */
                     cell_score[k] = sc; cell_x[k] = x * scale; cell_y[k] = y * scale; cell_level[k] = L;
                 }
             }

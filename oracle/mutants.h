@@ -45,7 +45,14 @@ enum oracle_mutant_id {
     MUT_P3_PLUS = 42,     /* h:222-236 Plus as a vector sum instead of SE3(delta) * SE3(x)                            */
     MUT_P4_ALLFEAT = 43,  /* cpp:47-65 residual blocks for every feature, not only Mpt && !IsBad && mbInitial         */
     MUT_P5_PIXELS = 44,   /* h:160    observation taken as bearing.xy (not divided by bearing.z)                      */
-    MUT_P6_ITERS = 45     /* cpp:70   max_num_iterations 10 instead of 100                                           */
+    MUT_P6_ITERS = 45,    /* cpp:70   max_num_iterations 10 instead of 100                                           */
+    /* cv::pyrDown (src/Frame.cpp:74-81) and Feature_detector::detect (src/Feature_detection.cpp:69-198, Thirdparty/fast) */
+    MUT_PD_ROUND = 50,    /* pyr      (s + 127) >> 8 instead of (s + 128) >> 8                                       */
+    MUT_PD_BORDER = 51,   /* pyr      BORDER_REFLECT (edge pixel repeated) instead of BORDER_REFLECT_101             */
+    MUT_D_NMS_TIE = 52,   /* nonmax_3x3.cpp:47-106 a corner suppressed only by a STRICTLY greater neighbour           */
+    MUT_D_SCORE = 53,     /* fast_10_score.cpp the score is the margin itself, not margin - 1                          */
+    MUT_D_CELLMAX = 54,   /* Feature_detection.cpp:104 >= instead of > (the LAST of equal scores wins the cell)        */
+    MUT_D_BOX = 55        /* Feature_detection.cpp:173-185 Shi-Tomasi box -4..+4 (9x9) instead of -4..+3 (8x8)         */
 };
 
 #ifdef ORACLE_MUTANTS

@@ -45,6 +45,12 @@ TABLE = {
     "MUT_P4_ALLFEAT":  ("pose_opt", "n_residual_blocks", "f3", "src/Optimizer.cpp:47-65"),
     "MUT_P5_PIXELS":   ("pose_opt", "pose", "f3", "include/Optimizer.h:160"),
     "MUT_P6_ITERS":    ("pose_opt", "iterations", "f3", "src/Optimizer.cpp:70"),
+    "MUT_PD_ROUND":    ("detector", "pyramid bytes", "a9", "src/Frame.cpp:79 (cv::pyrDown)"),
+    "MUT_PD_BORDER":   ("detector", "pyramid bytes", "a9", "src/Frame.cpp:79 (cv::pyrDown)"),
+    "MUT_D_NMS_TIE":   ("detector", "fast score map / survivors", "f4", "Thirdparty/fast/src/nonmax_3x3.cpp:47-106"),
+    "MUT_D_SCORE":     ("detector", "fast score map / survivors", "f4", "Thirdparty/fast/src/fast_10_score.cpp"),
+    "MUT_D_CELLMAX":   ("detector", "cell x", "f4", "src/Feature_detection.cpp:104"),
+    "MUT_D_BOX":       ("detector", "cell score", "f4", "src/Feature_detection.cpp:173-185"),
     "S1_SHUFFLE":      ("search:std", "match count", "S1", "src/Feature_alignment.cpp:38-43,75"),
     "S1_NOCAP":        ("search:dense", "match count", "S1", "src/Feature_alignment.cpp:80"),
     "S1_NOSORT":       ("search:std", "match count", "S1", "src/Feature_alignment.cpp:88,123-126"),
@@ -75,7 +81,7 @@ def domain(mutant):
     return TABLE[mutant][0].split(":")[0] if mutant else None
 
 
-def cpu_outputs(mutant=None, domains=("sparse", "align2d", "warp", "search", "pose_opt"), search_worlds=None):
+def cpu_outputs(mutant=None, domains=("sparse", "align2d", "warp", "search", "pose_opt", "detector"), search_worlds=None):
     """{case: outputs} from the CPU restatement with `mutant` switched (None: the faithful one), for the given domains."""
     fx = fixtures()
     c_mut = mutant if (mutant and mutant.startswith("MUT_")) else None
@@ -90,6 +96,8 @@ def cpu_outputs(mutant=None, domains=("sparse", "align2d", "warp", "search", "po
             out["align2d"] = oracle_lib.align2d_batch(a["pyr"], a["patch_border"], a["patch"], a["level"], a["px0"], 10)
         if "warp" in domains:
             out["warp"] = Q.warp_outputs(oracle_lib.warp_patches, fx["warp"])
+        if "detector" in domains:
+            out["detector"] = Q.detector_outputs(oracle_lib.pyrdown, oracle_lib.fast10_list, oracle_lib.detect_cells)
         if "pose_opt" in domains:
             out["pose_opt"] = [oracle_lib.pose_optimization(P.bearing, P.p_world, P.level, P.use, P.T_seed, linear_solver=0)
                                for P in fx["pose_opt"]]
@@ -108,6 +116,8 @@ def first_difference(case, a, b):
         return Q.warp_first_difference(a, b)
     if case == "pose_opt":
         return Q.pose_first_difference(a, b)
+    if case == "detector":
+        return Q.detector_first_difference(a, b)
     return Q.search_first_difference(a, b)
 
 

@@ -312,3 +312,35 @@ def pose_first_difference(a, b, tol=1e-10):
         if not np.allclose([sa["initial_cost"], sa["final_cost"]], [sb["initial_cost"], sb["final_cost"]], rtol=1e-10, atol=1e-300):
             return "cost"
     return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pyramid + detector: a textured 160x120 frame whose right half repeats a 12x12 tile (identical corners with identical
+# Shi-Tomasi scores inside one 25-px cell: the strict `>` of Feature_detection.cpp:104 keeps the FIRST of them)
+# ---------------------------------------------------------------------------------------------------------------
+def detector_image():
+    img = np.clip(np.rint(synth.make_texture(120, 160, 77)), 0, 255).astype(np.uint8)
+    tile = img[20:32, 30:42].copy()
+    img[:, 88:] = np.tile(tile, (10, 6))
+    return img
+
+
+def detector_outputs(pyrdown, fast10_list, detect_cells):
+    """pyrdown(img) -> next level; fast10_list(img, barrier) -> (x, y, score, is_nonmax) rows; detect_cells(pyr, levels, cell, cols,
+    rows, occupied, threshold) -> (score, x, y, level) per cell. CPU oracle wrappers or their GPU twins."""
+    img = detector_image()
+    l1 = pyrdown(img)
+    l2 = pyrdown(l1)
+    pyr = [img, l1, l2]
+    return dict(pyr1=l1, pyr2=l2, fast=fast10_list(img, 20), cells=detect_cells(pyr, 3, 25, 7, 5, None, 5.0))
+
+
+def detector_first_difference(a, b):
+    if not (np.array_equal(a["pyr1"], b["pyr1"]) and np.array_equal(a["pyr2"], b["pyr2"])):
+        return "pyramid bytes"
+    if not np.array_equal(a["fast"], b["fast"]):
+        return "fast score map / survivors"
+    for x, y, name in zip(a["cells"], b["cells"], ("cell score", "cell x", "cell y", "cell level")):
+        if not np.array_equal(x, y):
+            return name
+    return None

@@ -70,10 +70,12 @@ def test_mutation_build_with_no_switch_is_the_faithful_oracle(faithful):
     """-DORACLE_MUTANTS alone changes nothing: every output bit for bit (so a difference below is the switch, not the build)."""
     with oracle_lib.mutant("MUT_NONE") as lib:
         assert lib.oracle_get_mutant() == 0
-        o = M.cpu_outputs(domains=("sparse", "align2d", "warp", "pose_opt"))
+        o = M.cpu_outputs(domains=("sparse", "align2d", "warp", "pose_opt", "detector"))
     for case, a in o.items():
         b = faithful[case]
-        if case == "pose_opt":
+        if case == "detector":
+            assert M.first_difference(case, a, b) is None
+        elif case == "pose_opt":
             for (Ta, ra, sa), (Tb, rb, sb) in zip(a, b):
                 assert np.array_equal(Ta, Tb) and np.array_equal(ra, rb)
                 assert all(np.array_equal(sa[k], sb[k]) for k in sa)

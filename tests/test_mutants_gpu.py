@@ -19,6 +19,37 @@ from tests import quirk_fixtures as Q
 pytestmark = pytest.mark.gpu
 
 
+def gpu_pyrdown(ctx, img):
+    """One level of Frame::ComputeImagePyramid through the C ABI (dsdtm_pyrdown)."""
+    import ctypes as C
+    from dsdtm_amd import capi
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    outs = (C.c_void_p * 2)(None, out.ctypes.data)
+    strides = (C.c_int * 2)(w, out.strides[0])
+    ctx.check(ctx.lib.dsdtm_pyrdown(ctx.handle, img.ctypes.data_as(capi.u8p), w, h, img.strides[0], 2, outs, strides))
+    return out
+
+
+def gpu_detect_cells(ctx, pyr, levels, cell, cols, rows, occupied, thr):
+    """The per-cell part of Feature_detector::detect through the reference-shaped class."""
+    from dsdtm_amd import synth
+    from dsdtm_amd.feature_detection import Feature_detector
+    from dsdtm_amd.frame import Config, Frame
+    h, w = pyr[0].shape
+    old, oldc = Config.Get("Camera.MaxPyraLevels"), Config.Get("Camera.CellSize")
+    Config.Set("Camera.MaxPyraLevels", levels)
+    Config.Set("Camera.CellSize", cell)
+    try:
+        det = Feature_detector(w, h, ctx=ctx)
+        assert (det.mGrid_cols, det.mGrid_rows) == (cols, rows)
+        return det.detect_cells(Frame(synth.Camera.tum(w, h), pyr), thr)
+    finally:
+        Config.Set("Camera.MaxPyraLevels", old)
+        Config.Set("Camera.CellSize", oldc)
+
+
 def gpu_search(ctx, name):
     cam, kfs, cur, mps, cell = Q.search_world(name)
     s = search.LocalPointSearch(cam, ctx=ctx)
@@ -43,6 +74,9 @@ def hip(gpu_ctx):
     out["warp"] = Q.warp_outputs(lambda *args: FA.warp_patches(*args, ctx=gpu_ctx), fx["warp"])
     for name in Q.SEARCH_WORLDS:
         out["search:" + name] = gpu_search(gpu_ctx, name)
+    from tests.test_detector_gpu import gpu_fast10
+    out["detector"] = Q.detector_outputs(lambda im: gpu_pyrdown(gpu_ctx, im), lambda im, b: gpu_fast10(gpu_ctx, im, b),
+                                         lambda *a: gpu_detect_cells(gpu_ctx, *a))
     out["pose_opt"] = []
     for P in fx["pose_opt"]:
         T = np.ascontiguousarray(P.T_seed, np.float64).reshape(12).copy()
