@@ -331,6 +331,38 @@ def cpu_baselines(d, cam_struct, prm, sample):
     return out, T1, nt1, st1
 
 
+def rank_parity(d, cam_struct, prm, n_pairs, threads):
+    """This rank's own parity leg (every rank of an N-GPU run, after the timed region): the first `n_pairs` pairs of ITS batch
+    through the CPU oracle — the checker, never timed into `value` — against the poses / counts / iterations its last step
+    left on the device. Returns [max_rad, max_m, n_tracked_equal, iterations_equal, pairs_checked] as floats (gathered over
+    the ranks by the caller). The reference's result IS the pose (src/Sprase_ImageAlign.cpp:57-59)."""
+    from dsdtm_amd import capi, synth
+    from tests import oracle_lib
+    hb = HostBatch(d, n_pairs)
+    hb.run(oracle_lib.load(), cam_struct, prm, max(1, threads))
+    Tg = d["T_cur_w"][:n_pairs].cpu().numpy()
+    ntg = d["n_tracked"][:n_pairs].cpu().numpy()
+    stg = np.frombuffer(d["stats"][:n_pairs].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
+    dl = np.array([synth.pose_error(Tg[i], hb.T[i]) for i in range(n_pairs)])
+    bad = not np.isfinite(dl).all()
+    return [float("inf") if bad else float(dl[:, 0].max()), float("inf") if bad else float(dl[:, 1].max()),
+            float(np.array_equal(ntg, hb.nt)), float(np.array_equal(stg["iters"], hb.st["iters"])), float(n_pairs)]
+
+
+def aggregate_rank_checks(rank_checks):
+    """The gathered rank_parity rows (one per rank) -> (pose_delta_vs_cpu object, passed). A rank that checked nothing, a
+    non-finite delta, any delta over north_star's 1e-4 rad / 1e-4 m or a differing n_tracked fails the whole job."""
+    mr, mm = max(r[0] for r in rank_checks), max(r[1] for r in rank_checks)
+    pd = {"max_rad": mr, "max_m": mm, "pairs_checked": int(sum(r[4] for r in rank_checks)),
+          "n_tracked_equal": bool(all(r[2] == 1.0 for r in rank_checks)),
+          "iterations_equal": bool(all(r[3] == 1.0 for r in rank_checks)),
+          "ranks_checked": sum(1 for r in rank_checks if r[4] > 0),
+          "per_rank_max_rad": [r[0] for r in rank_checks], "per_rank_max_m": [r[1] for r in rank_checks],
+          "tolerance": "1e-4 rad / 1e-4 m (north_star)"}
+    ok = bool(mr <= 1e-4 and mm <= 1e-4 and pd["n_tracked_equal"] and pd["ranks_checked"] == len(rank_checks))
+    return pd, ok
+
+
 def hip_event_ms(torch, stream, fn, launches):
     """Average duration of `launches` calls of fn(stream), HIP events on `stream` around each call."""
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
@@ -890,6 +922,9 @@ def main():
                          "comes out of idle over ~40 ms of load (tools/warmup_sweep.sh: the same 20 timed steps run 7 %% faster "
                          "behind 200 launches than behind 5); 0 = none")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="pairs timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--rank-check-pairs", type=int, default=32,
+                    help="N > 1: pairs of its OWN last step every rank checks against the CPU oracle after the timed region "
+                         "(gathered into pose_delta_vs_cpu.ranks_checked; a rank over 1e-4 rad / m nulls value, exit 1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary roofline entries (other shapes, pyrDown)")
     ap.add_argument("--stub", action="store_true",
@@ -943,10 +978,12 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         per_rank = [[local, float(hi - lo)]]
+        checks = [[0.0, 0.0, 1.0, 1.0, 0.0]]              # the shape of a rank_parity row; the stub checks no pair (pairs_checked 0)
         if use_dist:
             elapsed = shard.max_over_ranks(elapsed, dist, torch.device("cpu"))
             total = shard.sum_over_ranks(hi - lo, dist, torch.device("cpu"))
             per_rank = shard.gather_over_ranks([local, float(hi - lo)], dist, torch.device("cpu"))
+            checks = shard.gather_over_ranks(checks[0], dist, torch.device("cpu"))
         else:
             total = hi - lo
         if rank == 0:
@@ -956,6 +993,7 @@ def main():
                 "data": "stub (no GPU work)", "pairs_per_step_all_ranks": total, "elapsed_max_s": elapsed,
                 "per_rank_ms_per_step": [r[0] / max(1, args.steps) * 1e3 for r in per_rank],
                 "per_rank_value": [None for _ in per_rank], "ranks_seen": len(per_rank),
+                "pose_delta_vs_cpu": aggregate_rank_checks(checks)[0],
                 **({"barrier_backend": dist.get_backend()} if use_dist else {})}), flush=True)
         if use_dist:
             dist.destroy_process_group()
@@ -1117,6 +1155,15 @@ def main():
         k_span = k_avg
         k_avg = k_solo
 
+    # N > 1: EVERY rank holds its own last step against the CPU oracle (the checker runs after the timed region, on that rank's
+    # share of the host threads), and the verdicts are gathered: an N-GPU rate is only a result if ranks 1..N-1 aligned their
+    # pairs too. (N = 1: rank 0 checks all its pairs below, in the cpu_baseline leg.)
+    rank_checks = None
+    if world > 1 and args.rank_check_pairs > 0:
+        n_chk = max(1, min(args.rank_check_pairs, args.pairs))
+        mine = rank_parity(d, cam_struct, prm, n_chk, max(1, usable_cpus() // world))
+        rank_checks = shard.gather_over_ranks(mine, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
+
     rc = 0
     if rank == 0:
         n_total = args.pairs * world * args.steps
@@ -1165,10 +1212,17 @@ def main():
             pd = {"max_rad": float(dl[:, 0].max()), "max_m": float(dl[:, 1].max()), "pairs_checked": int(sample),
                   "n_tracked_equal": bool(np.array_equal(ntg[:sample], nto)),
                   "iterations_equal": bool(np.array_equal(stats["iters"][:sample], sto["iters"])),
-                  "tolerance": "1e-4 rad / 1e-4 m (north_star)"}
+                  "ranks_checked": 1, "tolerance": "1e-4 rad / 1e-4 m (north_star)"}
             out["pose_delta_vs_cpu"] = pd
             if not (pd["max_rad"] <= 1e-4 and pd["max_m"] <= 1e-4 and pd["n_tracked_equal"]):
                 # a fast kernel with different results is not a result: no headline number, non-zero exit
+                out["value"] = None
+                out["parity_failed"] = True
+                rc = 1
+        if rank_checks is not None:
+            pd, ok = aggregate_rank_checks(rank_checks)
+            out["pose_delta_vs_cpu"] = pd
+            if not ok:
                 out["value"] = None
                 out["parity_failed"] = True
                 rc = 1
@@ -1176,7 +1230,8 @@ def main():
             try:
                 out["secondary"] = secondary_entries(torch, dev, ctx, cam_struct, stream, args)
             except Exception as e:          # the headline was measured and checked before this: it is printed whatever happens
-                out["secondary_error"] = f"{type(e).__name__}: {e}"     # here, and the run stays a success (the error is in the line)
+                out["secondary_error"] = f"{type(e).__name__}: {e}"     # here — but a crashed secondary kernel is not a success:
+                rc = 3                                                  # distinct non-zero exit (1 = parity of the headline failed)
         # secondary entries: one short line each, BEFORE the headline; full objects (with their notes) -> bench_secondary.json;
         # the LAST stdout line is the compact headline, < 4 KB (bench_line.py asserts it)
         bench_line.emit(out, ROOT)

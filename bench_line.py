@@ -90,7 +90,7 @@ def compact(full):
             keys = CPU_KEYS if k == "cpu_baseline" else ("value", "unit", "cores", "kind")
             out[k] = _pick(strip_notes(full[k], 120), keys)
     if isinstance(full.get("pose_delta_vs_cpu"), dict):
-        out["pose_delta_vs_cpu"] = _pick(full["pose_delta_vs_cpu"], ("max_rad", "max_m", "pairs_checked", "n_tracked_equal", "iterations_equal"))
+        out["pose_delta_vs_cpu"] = _pick(full["pose_delta_vs_cpu"], ("max_rad", "max_m", "pairs_checked", "n_tracked_equal", "iterations_equal", "ranks_checked"))
     if isinstance(full.get("fp64"), dict):
         out["fp64"] = _pick(full["fp64"], ("bound", "achieved", "peak", "unit", "frac"))
     for k in ("parity_failed", "value_from_idle", "executed_iterations_total_mean", "n_tracked_mean", "library", "library_sha",

@@ -375,6 +375,18 @@ static int recover_settle(dsdtm_ctx* ctx, int slot, hipStream_t rerun_stream) {
         set_err(ctx, "sparse-align kernel: a wait for a partner workgroup timed out (re-run disabled: no_recover)");
         return DSDTM_ERR_HIP;
     }
+    // The re-run is queued BEHIND whatever the caller issued on that stream since. A later unsettled launch of this stream that
+    // names the same pose buffer (a loop into one buffer with no check in between) would have its results overwritten by this
+    // older launch's: that cannot be repaired here, so it is reported instead of papered over (dsdtm_amd.h: unchecked launches
+    // of one stream name distinct output buffers).
+    for (int i = 0; i < dsdtm_ctx::RECOVER_SLOTS; ++i) {
+        const dsdtm_ctx::Recover& y = ctx->rec[i];
+        if (i != slot && y.used && y.stream == r.stream && y.order > r.order && y.b.T_cur_w == r.b.T_cur_w) {
+            set_err(ctx, "sparse-align kernel: a wait for a partner workgroup timed out in a launch whose pose buffer a later unchecked "
+                         "launch of the same stream reuses: it cannot be re-run (check the stream between launches into one buffer)");
+            return DSDTM_ERR_HIP;
+        }
+    }
     HIP_TRY(ctx, hipMemcpyAsync(r.b.T_cur_w, r.d_seed, (size_t)r.b.n_pairs * 96, hipMemcpyDeviceToDevice, rerun_stream));
     LaunchMode m;
     m.one_cu = true;

@@ -1574,7 +1574,7 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
             uint32_t* const tmp = ws_win + 2 * BINS;                   // [npad] keys in bin order, arbitrary inside a bin
             uint32_t* const wtot = ws_win + 2 * BINS + 2048;           // [NPW] bin counts per wave of the scan
             const float ysc = a.lv[0].h <= BINS ? 1.0f : (float)BINS / (float)a.lv[0].h;
-            const float xsc = a.lv[0].w <= 2047 ? 1.0f : 2047.0f / (float)a.lv[0].w;
+            const float xsc = a.lv[0].w <= 2047 ? 1.0f : 2046.0f / (float)a.lv[0].w;   // (column keys 0..2046: see below)
             for (int i = tid; i < BINS; i += PT) start[i] = 0u;
             uint32_t key[KPT];
 #pragma unroll
@@ -1585,7 +1585,9 @@ void sparse_align_ws_kernel(const SAKernelArgs a) {
                     const size_t fi = (size_t)pair * a.max_features + i;
                     const float x = a.px_xy[2 * fi], y = a.px_xy[2 * fi + 1];
                     const int yk = (int)fminf(fmaxf(y == y ? y * ysc : 0.0f, 0.0f), (float)(BINS - 1));
-                    const int xk = (int)fminf(fmaxf(x == x ? x * xsc : 0.0f, 0.0f), 2047.0f);
+                    // column key at most 2046: feature 2047 of a 2048-feature pair whose pixel clamps to the last row bin must not
+                    // produce the all-ones key, which means "no feature" below (round-5 advice)
+                    const int xk = (int)fminf(fmaxf(x == x ? x * xsc : 0.0f, 0.0f), 2046.0f);
                     key[k] = ((uint32_t)yk << 22) | ((uint32_t)xk << 11) | (uint32_t)i;
                 }
             }

@@ -385,7 +385,10 @@ int dsdtm_sparse_align_batch_streamed(dsdtm_ctx* const* ctx, int n_ctx, const ds
  * counters and re-run records are per context (host-mapped words read without a copy): a check never synchronises
  * the device or touches another context's state. At most 64 multi-compute-unit launches of a context are kept
  * unsettled; the 65th first waits for the oldest and settles it on the stream it was launched on — so the device
- * buffers a launch names (T_cur_w, n_tracked, stats) and its stream must stay alive until that stream's check. On devices that are not one 8-XCD / 256-CU partition, and inside
+ * buffers a launch names (T_cur_w, n_tracked, stats) and its stream must stay alive until that stream's check, and
+ * launches of one stream that have not been checked yet must name DISTINCT output buffers (a re-run is queued behind the
+ * stream's later work: were a later launch to reuse the pose buffer, the re-run would overwrite its results — such a case
+ * is reported as DSDTM_ERR_HIP by the check instead of being re-run). On devices that are not one 8-XCD / 256-CU partition, and inside
  * a stream capture, those shapes run the one-compute-unit kernels from the start. The reference has no counterpart
  * (its path is one CPU thread); the single-pair host entry points above settle their launch themselves. */
 int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream);

@@ -86,7 +86,7 @@ def load(native: bool = False):
         return _LIBS[key]
     name = f"liboracle_native_{_cpu_tag()}.so" if native else "liboracle.so"
     path = os.path.join(_ORACLE_DIR, "_build", name)
-    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("dsdtm_oracle.c", "pose_opt_oracle.c", "dsdtm_oracle.h")]
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("dsdtm_oracle.c", "pose_opt_oracle.c", "dsdtm_oracle.h", "mutants.h")]
     override = os.environ.get("DSDTM_ORACLE_LIB")       # the sanitizer job (tests/test_sanitizers_cpu.py) runs the oracle's own
     if override and not native:                          # CPU tests against an ASan/UBSan build of the same sources
         path = override

@@ -298,3 +298,99 @@ def test_config1_rgbd_sequence_through_the_cpp_driver(gpu_ctx, oracle, tmp_path)
         H.assert_pose_close(T, To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"rgbd frame {k}")
         assert tracked == no and iters == so["iters"][:4]
         assert te < 2e-3 and ang < 5e-4, (k, te, ang)                  # the error against ground truth the test prints
+
+
+def test_config4_whole_8192_pairs_over_eight_contexts(gpu_ctx, oracle):
+    """BASELINE config 4 WHOLE, on one GPU: 8192 independent 640x480 pairs — the eight 1024-pair blocks bench.py's ranks
+    0..7 build (seeds shard.batch_seed(0xD5D7, r)), 4 levels, 300 patches, cap 10 — as ONE host batch through
+    dsdtm_sparse_align_batch_sharded with EIGHT contexts on device 0 (one host thread + stream per context: the one-process
+    form of the 8-GPU split, src/Sprase_ImageAlign.cpp:29-60 per pair) and, level 0 only, through
+    dsdtm_sparse_align_batch_streamed. Every pose / n_tracked / iteration count / exit code against the CPU oracle on the
+    same bytes (all host threads), both entries bit-equal to each other and to eight single-context device launches."""
+    import torch
+    import bench
+    from dsdtm_amd import shard
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    W, Hh, L, N, PB, G = 640, 480, 4, 300, 1024, 8
+    P = PB * G
+    cam = synth.Camera.tum(W, Hh)
+    cs = capi.camera_struct(cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    lib = gpu_ctx.lib
+    ws, hs, st_, offs, nbytes = capi.pyramid_layout(W, Hh, L)
+    pitch = (nbytes + 255) // 256 * 256
+    host = dict(ref=np.empty((P, pitch), np.uint8), cur=np.empty((P, pitch), np.uint8), px=np.empty((P, N, 2), np.float32),
+                bear=np.empty((P, N, 3)), pw=np.empty((P, N, 3)), ini=np.empty((P, N), np.uint8), Tr=np.empty((P, 12)),
+                seed=np.empty((P, 12)))
+    single = dict(T=np.empty((P, 12)), nt=np.empty(P, np.int32), st=np.empty(P, capi.STATS_DTYPE))
+    for r in range(G):
+        d = bench.build_batch(torch, dev, gpu_ctx, cam, PB, W, Hh, L, N, seed=shard.batch_seed(0xD5D7, r), stream=stream)
+        assert d["pitch"] == pitch
+        lo, hi = shard.pair_range(P, r, G)
+        assert (lo, hi) == (r * PB, (r + 1) * PB)
+        for k, src in (("ref", "ref_pyr"), ("cur", "cur_pyr"), ("px", "px"), ("bear", "bearing"), ("pw", "p_world"), ("ini", "initial"),
+                       ("Tr", "T_ref_w"), ("seed", "T_seed")):
+            host[k][lo:hi] = d[src].cpu().numpy()
+        # the block as ONE single-context device launch (what rank r of an 8-GPU run does)
+        d["T_cur_w"].copy_(d["T_seed"])
+        torch.cuda.synchronize()
+        gpu_ctx.check(lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(d["desc"]), C.byref(cs), C.byref(prm), stream.cuda_stream))
+        gpu_ctx.check(lib.dsdtm_sparse_align_check(gpu_ctx.handle, stream.cuda_stream))
+        single["T"][lo:hi] = d["T_cur_w"].cpu().numpy()
+        single["nt"][lo:hi] = d["n_tracked"].cpu().numpy()
+        single["st"][lo:hi] = np.frombuffer(d["stats"].cpu().numpy().tobytes(), dtype=capi.STATS_DTYPE)
+        del d
+        torch.cuda.empty_cache()
+
+    def desc_for(T, nt, st):
+        b = capi.BatchDesc()
+        b.n_pairs, b.max_features, b.levels = P, N, L
+        for l in range(L):
+            b.width[l], b.height[l], b.stride[l], b.level_offset[l] = ws[l], hs[l], st_[l], offs[l]
+        b.pyr_pitch = pitch
+        b.ref_pyr, b.cur_pyr, b.px_xy, b.bearing, b.p_world = (host[k].ctypes.data for k in ("ref", "cur", "px", "bear", "pw"))
+        b.initial, b.n_features, b.T_ref_w, b.T_cur_w = host["ini"].ctypes.data, None, host["Tr"].ctypes.data, T.ctypes.data
+        b.n_tracked, b.stats = nt.ctypes.data, st.ctypes.data
+        return b
+
+    # the CPU oracle on the same bytes, every host thread (8192 alignments: ~0.5 s on 16 threads)
+    To, nto, sto = host["seed"].copy(), np.zeros(P, np.int32), np.zeros(P, capi.STATS_DTYPE)
+    bo = desc_for(To, nto, sto)
+    oracle.load().oracle_sparse_align_batch_timed(C.byref(bo), C.byref(cs), C.byref(prm), bench.usable_cpus())
+
+    ctxs = [capi.Context(0) for _ in range(G)]
+    arr = (C.c_void_p * G)(*[c.handle for c in ctxs])
+    # 1. whole pyramids from host memory, eight shards
+    Ts, nts, sts = host["seed"].copy(), np.full(P, -1, np.int32), np.zeros(P, capi.STATS_DTYPE)
+    bs = desc_for(Ts, nts, sts)
+    rc = lib.dsdtm_sparse_align_batch_sharded(arr, G, C.byref(bs), C.byref(cs), C.byref(prm))
+    assert rc == 0, [c.lib.dsdtm_last_error(c.handle) for c in ctxs]
+    # 2. level 0 only (the pyramids' first W*H bytes: image_pitch = the pyramid pitch), pyramids on the device, chunks of 128
+    Tt, ntt, stt = host["seed"].copy(), np.full(P, -1, np.int32), np.zeros(P, capi.STATS_DTYPE)
+    s = capi.StreamDesc()
+    s.n_pairs, s.max_features, s.levels, s.width, s.height, s.row_stride, s.image_pitch = P, N, L, W, Hh, W, pitch
+    s.ref_image, s.cur_image = host["ref"].ctypes.data, host["cur"].ctypes.data
+    s.px_xy, s.bearing, s.p_world, s.initial = (host[k].ctypes.data for k in ("px", "bear", "pw", "ini"))
+    s.n_features, s.T_ref_w, s.T_cur_w, s.n_tracked, s.stats = None, host["Tr"].ctypes.data, Tt.ctypes.data, ntt.ctypes.data, stt.ctypes.data
+    rc = lib.dsdtm_sparse_align_batch_streamed(arr, G, C.byref(s), 128, C.byref(cs), C.byref(prm))
+    assert rc == 0, [c.lib.dsdtm_last_error(c.handle) for c in ctxs]
+    for c in ctxs:
+        c.close()
+
+    # both host-fed entries and the eight single-context launches: the same bits
+    for what, (T, nt, st) in (("sharded", (Ts, nts, sts)), ("streamed", (Tt, ntt, stt))):
+        assert np.array_equal(T, single["T"]), what
+        assert np.array_equal(nt, single["nt"]), what
+        for k in ("iters", "n_ref", "n_vis", "exit_code", "chi2"):
+            assert np.array_equal(st[k], single["st"][k], equal_nan=(k == "chi2")), (what, k)
+    # and the oracle's results, pair by pair
+    dl = np.array([synth.pose_error(Ts[i].reshape(3, 4), To[i].reshape(3, 4)) for i in range(P)])
+    assert np.isfinite(dl).all() and dl[:, 0].max() <= H.TIGHT_RAD and dl[:, 1].max() <= H.TIGHT_M, dl.max(axis=0)
+    assert np.array_equal(nts, nto)
+    for k in ("iters", "n_ref", "n_vis", "exit_code"):
+        assert np.array_equal(sts[k], sto[k]), k
+    assert np.allclose(sts["chi2"], sto["chi2"], rtol=1e-9, atol=0, equal_nan=True)
+    assert (nts > 250).mean() > 0.99                      # alignments, not no-ops
+    # the eight blocks differ (a rank that re-ran block 0 would not go unnoticed)
+    assert len({host["Tr"][r * PB].tobytes() for r in range(G)}) == G

@@ -139,3 +139,23 @@ def test_compact_line_sheds_extras_but_never_the_required_objects():
         assert "limit 4096" in str(e)
     else:
         raise AssertionError("an oversized line must not be printed")
+
+
+def test_rank_checks_aggregate_to_one_verdict():
+    """N > 1: every rank's own parity row [max_rad, max_m, n_tracked_equal, iterations_equal, pairs_checked] is gathered and
+    folded by bench.aggregate_rank_checks: the job passes only when EVERY rank checked pairs and stayed inside north_star's
+    1e-4 rad / 1e-4 m with equal n_tracked."""
+    import bench
+    good = [[2e-15, 1e-15, 1.0, 1.0, 32.0], [7e-16, 3e-15, 1.0, 1.0, 32.0]]
+    pd, ok = bench.aggregate_rank_checks(good)
+    assert ok and pd["ranks_checked"] == 2 and pd["pairs_checked"] == 64 and pd["max_rad"] == 2e-15 and pd["max_m"] == 3e-15
+    assert pd["n_tracked_equal"] and pd["iterations_equal"] and len(pd["per_rank_max_rad"]) == 2
+    for bad in ([[2e-15, 1e-15, 1.0, 1.0, 32.0], [3e-4, 1e-15, 1.0, 1.0, 32.0]],           # rank 1 over the tolerance
+                [[2e-15, 1e-15, 1.0, 1.0, 32.0], [1e-15, 1e-15, 0.0, 1.0, 32.0]],           # rank 1: another n_tracked
+                [[2e-15, 1e-15, 1.0, 1.0, 32.0], [float("inf"), 0.0, 1.0, 1.0, 32.0]],      # rank 1: NaN poses
+                [[2e-15, 1e-15, 1.0, 1.0, 32.0], [0.0, 0.0, 1.0, 1.0, 0.0]]):               # rank 1 checked nothing
+        assert not bench.aggregate_rank_checks(bad)[1]
+    # the compact line keeps the verdict and the count of ranks behind it
+    import bench_line
+    line = bench_line.compact({"metric": "m", "value": 1.0, "pose_delta_vs_cpu": pd})
+    assert line["pose_delta_vs_cpu"]["ranks_checked"] == 2 and line["pose_delta_vs_cpu"]["pairs_checked"] == 64

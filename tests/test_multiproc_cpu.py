@@ -77,6 +77,8 @@ def test_bench_gpus_flag_spawns_one_worker_per_rank():
     # one entry per rank, gathered after the timed region (all_gather over the process group)
     assert out["ranks_seen"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and out["barrier_backend"] == "gloo"
     assert len(lines[0]) < 4096
+    # the per-rank parity rows travel the same way (all_gather, folded by rank 0); the stub checks no pair and says so
+    assert out["pose_delta_vs_cpu"]["ranks_checked"] == 0 and out["pose_delta_vs_cpu"]["pairs_checked"] == 0
 
 
 def test_bench_refuses_a_world_that_contradicts_the_flag():

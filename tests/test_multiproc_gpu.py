@@ -40,6 +40,11 @@ def test_bench_two_ranks_share_one_gpu():
     assert all(0 < t <= out["ms_per_step"] * (1 + 1e-6) for t in out["per_rank_ms_per_step"])     # own time <= max-over-ranks time
     assert all(abs(v - 64 * 3 / (t * 3e-3)) <= 1e-4 * v for v, t in zip(out["per_rank_value"], out["per_rank_ms_per_step"]))
     assert len(lines[0]) < 4096
+    # EVERY rank held pairs of its own last step against the CPU oracle after the timed region (the reference's result is
+    # the pose, src/Sprase_ImageAlign.cpp:57-59): both verdicts are in the line
+    pd = out["pose_delta_vs_cpu"]
+    assert pd["ranks_checked"] == 2 and pd["pairs_checked"] == 64 and pd["max_rad"] <= 1e-4 and pd["max_m"] <= 1e-4
+    assert pd["n_tracked_equal"] and pd["iterations_equal"]
 
 
 @pytest.mark.gpu
@@ -76,6 +81,7 @@ def test_bench_two_ranks_under_the_drivers_launcher():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["pairs_per_gpu"] == 64 and out["value"] > 0
     assert abs(out["value"] - 2 * 64 * 3 / (out["ms_per_step"] * 3e-3)) <= 2e-5 * out["value"]
+    assert out["pose_delta_vs_cpu"]["ranks_checked"] == 2 and out["pose_delta_vs_cpu"]["max_rad"] <= 1e-4
 
 
 @pytest.mark.gpu

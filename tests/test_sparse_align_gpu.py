@@ -880,7 +880,7 @@ def test_team_exchange_survives_the_wrap_of_its_tag_epoch(oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("N,P,size", [(1000, 9, (320, 240)), (2000, 10, (640, 480)), (1500, 3, (320, 240))])
+@pytest.mark.parametrize("N,P,size", [(1000, 9, (320, 240)), (2000, 10, (640, 480)), (1500, 3, (320, 240)), (2048, 4, (640, 480))])
 def test_workspace_kernels_walk_features_in_row_order_with_the_same_results(gpu_ctx, oracle, N, P, size):
     """Batches of large pairs order a pair's features by image row on the device (one LDS sort per pair) before the lanes take
     them: the reference sums in list order (src/Sprase_ImageAlign.cpp:84-103), so only the rounding of the sums may differ —
@@ -900,6 +900,8 @@ def test_workspace_kernels_walk_features_in_row_order_with_the_same_results(gpu_
         sc.initial[7::13] = 0
         sc.px[3] = (np.nan, 40.0); sc.px[4] = (-1e9, 1e9); sc.px[5] = (W + 500.0, -3.0); sc.px[6] = (np.inf, np.nan)
         sc.initial[3:7] = 0                                      # (the reference never reads the pixel of an uninitialised feature, :86)
+        if N == 2048:                                            # the LAST index of a full list with a pixel that clamps to the last row
+            sc.px[N - 1] = (1e9, 1e9); sc.initial[N - 1] = 0     # and column bin: its sort key must not collide with "no feature"
         base.append(sc)
     scenes = [base[i % 3] for i in range(P)]
     nf = np.array([N - (37 * i) % 300 for i in range(P)], np.int32)
