@@ -168,12 +168,14 @@ class PoseOptSummary(C.Structure):
 PO_FUNCTION_TOLERANCE, PO_PARAMETER_TOLERANCE, PO_GRADIENT_TOLERANCE, PO_MAX_ITERATIONS = 0, 1, 2, 3
 PO_MIN_RADIUS, PO_INVALID_STEPS, PO_NO_RESIDUALS, PO_EVALUATION_FAILED = 4, 5, 6, 7
 
-_LIB = None
-LIB_NAME = "libdsdtm_amd.so"
+_LIBS = {}
+LIB_NAME = "libdsdtm_amd.so"             # the release library: the product (exactly the header's symbols, no switches)
+DIAG_LIB_NAME = "libdsdtm_amd_diag.so"   # the diagnostic build (build.py --diag): + dsdtm_debug_*, environment switches
 
 
-def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
+def lib_path(diag: bool | None = False) -> str:
+    diag = _DIAG_DEFAULT if diag is None else bool(diag)
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", DIAG_LIB_NAME if diag else LIB_NAME)
 
 
 class DsdtmError(RuntimeError):
@@ -182,12 +184,37 @@ class DsdtmError(RuntimeError):
         self.status = status
 
 
-def load():
-    """Load libdsdtm_amd.so (no fallback: raises if it has not been built)."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = lib_path()
+# Which library a Context is created from when the caller does not say: the release one. tools/ (A/B scripts that set
+# DSDTM_* switches in the environment — only the diagnostic library reads them) export DSDTM_PY_DIAG=1; tests use
+# `with capi.diag_default():`. This is the PYTHON binding's choice of file; the release library itself reads no environment.
+_DIAG_DEFAULT = os.environ.get("DSDTM_PY_DIAG") == "1"
+
+
+class diag_default:
+    """`with capi.diag_default(): ...` — contexts created inside the block without an explicit `diag=` come from the
+    diagnostic library (for code that builds its own Context, e.g. tools/ modules driven by a `diag` test)."""
+
+    def __init__(self, flag: bool = True):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        global _DIAG_DEFAULT
+        self.old, _DIAG_DEFAULT = _DIAG_DEFAULT, self.flag
+        return self
+
+    def __exit__(self, *exc):
+        global _DIAG_DEFAULT
+        _DIAG_DEFAULT = self.old
+        return False
+
+
+def load(diag: bool | None = None):
+    """Load libdsdtm_amd.so — or, diag=True, the diagnostic build beside it (tools/ and the tests marked `diag`: fault
+    injection and A/B switches the release library does not have). No fallback: raises if it has not been built."""
+    diag = _DIAG_DEFAULT if diag is None else bool(diag)
+    if diag in _LIBS:
+        return _LIBS[diag]
+    path = lib_path(diag)
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: the HIP extension is not built. Run "
@@ -260,24 +287,26 @@ def load():
                                                       C.POINTER(AlignParams)]
     lib.dsdtm_shard_range.restype = None
     lib.dsdtm_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    lib.dsdtm_debug_set_option.restype = C.c_int
-    lib.dsdtm_debug_set_option.argtypes = [C.c_char_p, C.c_int]
-    lib.dsdtm_debug_get_option.restype = C.c_int
-    lib.dsdtm_debug_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
-    _LIB = lib
+    if diag:
+        lib.dsdtm_debug_set_option.restype = C.c_int
+        lib.dsdtm_debug_set_option.argtypes = [C.c_char_p, C.c_int]
+        lib.dsdtm_debug_get_option.restype = C.c_int
+        lib.dsdtm_debug_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    _LIBS[diag] = lib
     return lib
 
 
 class debug_options:
-    """`with capi.debug_options(no_team=1): ...` — diagnostic switches of the library (kernels.h: Options) for the
-    duration of a block. The library reads the environment once, when the first context is created; tests and A/B
+    """`with capi.debug_options(no_team=1): ...` — diagnostic switches of the DIAGNOSTIC library (kernels.h: Options) for
+    the duration of a block; they act on contexts of that library only (Context(device, diag=True)). The release library
+    has no switches. The diagnostic library reads the environment once, when its first context is created; tests and A/B
     tools change a switch afterwards through this."""
 
     def __init__(self, **kv):
         self.kv, self.old = kv, {}
 
     def __enter__(self):
-        lib = load()
+        lib = load(diag=True)
         for k, v in self.kv.items():
             cur = C.c_int()
             if lib.dsdtm_debug_get_option(k.encode(), C.byref(cur)) != OK:
@@ -287,7 +316,7 @@ class debug_options:
         return self
 
     def __exit__(self, *exc):
-        lib = load()
+        lib = load(diag=True)
         for k, v in self.old.items():
             lib.dsdtm_debug_set_option(k.encode(), v)
         return False
@@ -340,8 +369,10 @@ class DeviceFrame:
 class Context:
     """Owns one dsdtm_ctx (one per calling thread, as the reference classes are single-threaded)."""
 
-    def __init__(self, device: int = 0):
-        self.lib = load()
+    def __init__(self, device: int = 0, diag: bool | None = None):
+        diag = _DIAG_DEFAULT if diag is None else bool(diag)
+        self.lib = load(diag)
+        self.diag = diag
         h = C.c_void_p()
         st = self.lib.dsdtm_create(device, C.byref(h))
         if st != OK:
@@ -370,8 +401,9 @@ class Context:
 _DEFAULT_CTX = {}
 
 
-def default_context(device: int = 0) -> Context:
-    ctx = _DEFAULT_CTX.get(device)
+def default_context(device: int = 0, diag: bool | None = None) -> Context:
+    diag = _DIAG_DEFAULT if diag is None else bool(diag)
+    ctx = _DEFAULT_CTX.get((device, diag))
     if ctx is None:
-        ctx = _DEFAULT_CTX[device] = Context(device)
+        ctx = _DEFAULT_CTX[(device, diag)] = Context(device, diag)
     return ctx

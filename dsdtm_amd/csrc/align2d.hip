@@ -205,10 +205,12 @@ __global__ __launch_bounds__(256) void align2d_rows_kernel(const A2DKernelArgs a
 
 hipError_t align2d_launch(const A2DKernelArgs& args, hipStream_t stream) {
     if (args.m <= 0) return hipSuccess;
-    // DSDTM_A2D_TREE=1 (diagnostic, cost comparison only): DPP tree sums instead of the reference's order
-    if (options().a2d_tree) hipLaunchKernelGGL(align2d_kernel<true>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args);
-    else if (options().a2d_group == 8) hipLaunchKernelGGL(align2d_rows_kernel<8>, dim3((unsigned)((args.m + 31) / 32)), dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL(align2d_rows_kernel<4>, dim3((unsigned)((args.m + 15) / 16)), dim3(256), 0, stream, args);
+#ifdef DSDTM_DIAG
+    // a2d_tree (diagnostic build, cost comparison only): DPP tree sums instead of the reference's order; a2d_group 8: 114 VGPRs
+    if (options().a2d_tree) { hipLaunchKernelGGL(align2d_kernel<true>, dim3((unsigned)((args.m + 3) / 4)), dim3(256), 0, stream, args); return hipGetLastError(); }
+    if (options().a2d_group == 8) { hipLaunchKernelGGL(align2d_rows_kernel<8>, dim3((unsigned)((args.m + 31) / 32)), dim3(256), 0, stream, args); return hipGetLastError(); }
+#endif
+    hipLaunchKernelGGL(align2d_rows_kernel<4>, dim3((unsigned)((args.m + 15) / 16)), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -112,7 +112,10 @@ static void set_err(dsdtm_ctx* ctx, const char* fmt, ...) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// ---- diagnostic switches (kernels.h: Options) --------------------------------------------------
+// ---- diagnostic switches (kernels.h: Options) — diagnostic build only ----------------------------
+// The release library has no switches: options() is a compile-time constant there, nothing reads the environment,
+// and no dsdtm_debug_* symbol exists (tests/test_capi_cpu.py checks `nm -D` and `strings`).
+#ifdef DSDTM_DIAG
 namespace {
 struct OptionKey { const char* key; const char* env; int dsdtm::Options::*field; bool flag; };
 const OptionKey kOptionKeys[] = {
@@ -147,10 +150,15 @@ dsdtm::Options& dsdtm::options() {
     static Options o;
     return o;
 }
+#endif  // DSDTM_DIAG
 
 extern "C" {
 
-const char* dsdtm_version(void) { return "dsdtm_amd 0.5 (gfx950, HIP; FP64 reference grid)"; }
+#ifdef DSDTM_DIAG
+const char* dsdtm_version(void) { return "dsdtm_amd 0.6 (gfx950, HIP; FP64 reference grid; DIAGNOSTIC build)"; }
+#else
+const char* dsdtm_version(void) { return "dsdtm_amd 0.6 (gfx950, HIP; FP64 reference grid)"; }
+#endif
 
 int dsdtm_device_count(void) {
     int n = 0;
@@ -164,7 +172,9 @@ const char* dsdtm_last_error(const dsdtm_ctx* ctx) { return ctx ? ctx->err : g_c
 int dsdtm_create(int device, dsdtm_ctx** out) {
     if (!out) return DSDTM_ERR_INVALID;
     *out = nullptr;
-    std::call_once(g_options_once, options_from_env);     // the only place the library reads the environment
+#ifdef DSDTM_DIAG
+    std::call_once(g_options_once, options_from_env);     // diagnostic build: the only place the library reads the environment
+#endif
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -228,6 +238,7 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
     return DSDTM_OK;
 }
 
+#ifdef DSDTM_DIAG
 // Diagnostic switches by name (tests, A/B tools): the keys of kOptionKeys, process-wide. Returns DSDTM_ERR_INVALID
 // for an unknown key. Not for production use: no entry point synchronises against a concurrent change.
 int dsdtm_debug_set_option(const char* key, int value) {
@@ -242,6 +253,7 @@ int dsdtm_debug_get_option(const char* key, int* value) {
         if (key && value && strcmp(key, k.key) == 0) { *value = dsdtm::options().*(k.field); return DSDTM_OK; }
     return DSDTM_ERR_INVALID;
 }
+#endif  // DSDTM_DIAG
 
 void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (!ctx) return;
@@ -320,8 +332,13 @@ static int ring_mark_launch(dsdtm_ctx* ctx, int ring, hipStream_t stream) {
     return DSDTM_OK;
 }
 
+#ifdef DSDTM_DIAG
 static thread_local void* g_stamp_out = nullptr;   // device buffer, set only by the stamps debug entry
 static thread_local int g_team_drop_members = 0;         // set only by dsdtm_debug_sparse_align_short_team
+#else
+static constexpr void* g_stamp_out = nullptr;      // (release build: neither diagnostic exists)
+static constexpr int g_team_drop_members = 0;
+#endif
 
 // How a launch is accounted for (see dsdtm_ctx::h_flags / Recover)
 struct LaunchMode {
@@ -482,12 +499,14 @@ static int launch_batch(dsdtm_ctx* ctx, const dsdtm_batch_desc* b, const dsdtm_c
         a.timeout_flag = ctx->d_flags + ri;
     }
     if (mode.single) a.timeout_flag = ctx->d_flags + dsdtm_ctx::FLAG_SINGLE;
+#ifdef DSDTM_DIAG
     if (g_stamp_out) {   // diagnostic path of dsdtm_debug_sparse_align_stamps
         if (b->max_features > 320) { set_err(ctx, "stamps: <=320 features only"); return DSDTM_ERR_INVALID; }
         a.workspace = (double*)g_stamp_out;
         HIP_TRY(ctx, sparse_align_launch_stamps(a, ctx->num_cus, stream));
         return DSDTM_OK;
     }
+#endif
     // Few pairs of more than 448 features: one pair over K compute units. The members of a team spin on each
     // other, so all of a launch's workgroups must be resident together: sparse_align_team_size admits a launch
     // only when it fills at most half the CUs, and the team launches of a context are totally ordered — one on
@@ -632,6 +651,7 @@ extern "C" int dsdtm_sparse_align_check(dsdtm_ctx* ctx, void* hip_stream) {
     return DSDTM_OK;
 }
 
+#ifdef DSDTM_DIAG
 extern "C" long long dsdtm_debug_recovered_launches(dsdtm_ctx* ctx) { return ctx ? (long long)ctx->recovered : -1; }
 // Tests: the context's team-launch counter (its low 20 bits are the epoch of the exchange tags, its low 3 bits the ring slot),
 // so that the epoch wrap — 2^20 team launches away in real use — can be crossed by a handful of launches. Returns the number
@@ -641,6 +661,7 @@ extern "C" long long dsdtm_debug_team_seq(dsdtm_ctx* ctx, long long set_to) {
     if (set_to >= 0) ctx->team_seq = (unsigned)set_to;
     return (long long)ctx->team_wraps;
 }
+#endif  // DSDTM_DIAG
 
 // ---- the batch from host memory over several contexts / devices ------------------------------
 extern "C" void dsdtm_shard_range(int n_pairs, int n_shards, int shard, int* lo, int* hi) {
@@ -1311,6 +1332,7 @@ extern "C" int dsdtm_detect_cells_batch_device(dsdtm_ctx* ctx, const uint8_t* py
     return DSDTM_OK;
 }
 
+#ifdef DSDTM_DIAG
 // Diagnostic (tests): the FAST-10 score map and the non-max survivors of ONE 8-bit image, as the detector's
 // two passes produce them on the device. score/keep: width*height bytes each.
 extern "C" int dsdtm_debug_fast10(dsdtm_ctx* ctx, const uint8_t* img, int width, int height, int stride, int barrier,
@@ -1337,6 +1359,7 @@ extern "C" int dsdtm_debug_fast10(dsdtm_ctx* ctx, const uint8_t* img, int width,
     memcpy(keep, h + pitch, n);
     return DSDTM_OK;
 }
+#endif  // DSDTM_DIAG
 
 // ---- Align2D ------------------------------------------------------------------------------
 extern "C" int dsdtm_align2d_batch_device(dsdtm_ctx* ctx, const dsdtm_image_desc* cur, const uint8_t* patch_border,
@@ -1627,10 +1650,13 @@ extern "C" int dsdtm_match_candidates_frames(dsdtm_ctx* ctx, const dsdtm_frame* 
     b.px_xy = (double*)(io + o_px); b.converged = io + o_cv; b.m = m; b.max_iters = max_iters; b.levels = p0.levels;
     b.px_level0 = 1;
     for (int l = 0; l < p0.levels; ++l) b.lv[l] = a.lv[l];
-    if (options().fmd_split) {                 // rounds 1-4: two kernels, the warped patches through device memory
+#ifdef DSDTM_DIAG
+    if (options().fmd_split) {                 // rounds 1-4 (diagnostic build): two kernels, the warped patches through device memory
         HIP_TRY(ctx, warp_launch(a, ctx->stream));
         HIP_TRY(ctx, align2d_launch(b, ctx->stream));
-    } else {
+    } else
+#endif
+    {
         a.affine = nullptr; a.no_xcd = options().fmd_no_xcd;                    // (nobody reads it here)
         HIP_TRY(ctx, match_launch(a, b, ctx->stream));
     }
@@ -1684,10 +1710,13 @@ extern "C" int dsdtm_match_candidates_batch_device(dsdtm_ctx* ctx, const uint8_t
     b.cur_pyr = cur_pyr; b.patch_border = pb; b.patch = pp; b.level = search_level; b.px_xy = px_xy; b.converged = converged;
     b.m = m; b.max_iters = max_iters; b.levels = levels; b.px_level0 = 1; b.frame = cand_frame; b.n_frames = n_frames; b.pyr_pitch = pyr_pitch;
     for (int l = 0; l < levels; ++l) b.lv[l] = a.lv[l];
-    if (options().fmd_split) {                 // rounds 1-4: two kernels, the warped patches through `scratch`
+#ifdef DSDTM_DIAG
+    if (options().fmd_split) {                 // rounds 1-4 (diagnostic build): two kernels, the warped patches through `scratch`
         HIP_TRY(ctx, warp_launch(a, (hipStream_t)hip_stream));
         HIP_TRY(ctx, align2d_launch(b, (hipStream_t)hip_stream));
-    } else {                                   // one kernel, the patches stay in LDS (`scratch` is not touched)
+    } else
+#endif
+    {                                          // one kernel, the patches stay in LDS (`scratch` is not touched)
         a.affine = nullptr; a.no_xcd = options().fmd_no_xcd;
         HIP_TRY(ctx, match_launch(a, b, (hipStream_t)hip_stream));
     }
@@ -1781,6 +1810,7 @@ extern "C" int dsdtm_pose_optimization(dsdtm_ctx* ctx, const double* bearing, co
     return DSDTM_OK;
 }
 
+#ifdef DSDTM_DIAG
 // ---- debug: device self-test of the FP64 building blocks (not in the public header) ------------
 extern "C" int dsdtm_debug_selftest(dsdtm_ctx* ctx, const double* in, double* out, int n_cases) {
     if (!ctx || !in || !out || n_cases < 0) return DSDTM_ERR_INVALID;
@@ -1831,3 +1861,4 @@ extern "C" int dsdtm_debug_occupancy(dsdtm_ctx* ctx, int variant) {
     (void)hipSetDevice(ctx->device);
     return sparse_align_occupancy(variant);
 }
+#endif  // DSDTM_DIAG

@@ -41,9 +41,11 @@ struct SAKernelArgs {
     LevelGeom lv[DSDTM_MAX_LEVELS];
 };
 
-// Diagnostic switches (A/B runs, tests). Process-wide, read from the environment ONCE — by the first dsdtm_create —
-// and changed afterwards only through dsdtm_debug_set_option; no entry point of the library reads the environment
-// on its call path.
+// Diagnostic switches (A/B runs, tests). They exist as VARIABLES only in the diagnostic build (build.py --diag,
+// -DDSDTM_DIAG: libdsdtm_amd_diag.so), where they are process-wide, read from the environment once — by the first
+// dsdtm_create — and changed afterwards through dsdtm_debug_set_option. In the RELEASE build (libdsdtm_amd.so, the
+// library bench.py, smoke() and the parity tests load) they are the compile-time constants below: nothing reads the
+// environment, nothing can change them, and the kernels only they select are not compiled in.
 struct Options {
     int no_team = 0;           // DSDTM_NO_TEAM: large single pairs take the one-CU kernels instead of a team
     int team_min = 449;        // DSDTM_TEAM_MIN: feature count from which few large pairs run as teams
@@ -65,7 +67,12 @@ struct Options {
     int team_no_wrap_clear = 0;  // DSDTM_TEAM_NO_WRAP_CLEAR: the team ring is NOT re-zeroed when the tag epoch wraps (A/B of that hazard only)
     int no_recover = 0;        // DSDTM_NO_RECOVER: a multi-CU launch that timed out is reported, not re-run (tests)
 };
+#ifdef DSDTM_DIAG
 Options& options();
+#else
+inline constexpr Options kReleaseOptions{};
+inline constexpr const Options& options() { return kReleaseOptions; }
+#endif
 
 constexpr int SA_PPW = 2;      // pair slots per workgroup of the <= 320-feature register kernel (see sparse_align.hip)
 enum SAVariant { SA_REG320 = 0, SA_REG448 = 1, SA_WS = 2, SA_REG128 = 3, SA_REG192 = 4, SA_REG256 = 5, SA_REG704 = 6 };
@@ -80,8 +87,10 @@ int sparse_align_team_size(int n_pairs, int max_features, int num_cus);
 size_t sparse_align_team_bytes(int n_pairs);
 // drop_members > 0 (tests only): the last members of every team are not launched, so the others' waits run out
 hipError_t sparse_align_launch_team(const SAKernelArgs& args, int k, hipStream_t stream, int drop_members = 0);
+#ifdef DSDTM_DIAG
 int sparse_align_occupancy(int variant);   // occupancy API answer (workgroups per CU)
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream);
+#endif
 
 // Feature detector (per-cell part): FAST-10 score map, then non-max + Shi-Tomasi + best corner per cell — for
 // n_frames packed pyramids at once (frame f: pyr + f * pyr_pitch, score + f * pyr_pitch, cell_key / occupied / the
@@ -171,7 +180,9 @@ struct PoseOptArgs {
 };
 hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream);
 
-// device self-test of the FP64 building blocks (wave reduction, LDLT, SE3); see selftest.hip
+#ifdef DSDTM_DIAG
+// device self-test of the FP64 building blocks (wave reduction, LDLT, SE3); see selftest.hip (diagnostic build only)
 hipError_t selftest_launch(const double* in, double* out, int n_cases, hipStream_t stream);
+#endif
 
 }  // namespace dsdtm

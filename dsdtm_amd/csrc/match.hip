@@ -92,8 +92,10 @@ hipError_t match_launch(const WarpKernelArgs& wa, const A2DKernelArgs& aa, hipSt
     const dim3 grid((unsigned)((wa.m + ch - 1) / ch));
     switch (ch) {
         case 16: hipLaunchKernelGGL(match_kernel<16>, grid, dim3(256), 0, stream, wa, aa); break;
+#ifdef DSDTM_DIAG                                     // 32 and 64 candidates per group: measured slower, kept for A/B only
         case 32: hipLaunchKernelGGL(match_kernel<32>, grid, dim3(256), 0, stream, wa, aa); break;
         case 64: hipLaunchKernelGGL(match_kernel<64>, grid, dim3(256), 0, stream, wa, aa); break;
+#endif
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -2142,6 +2142,7 @@ size_t sparse_align_workspace_bytes(int n_pairs, int max_features) {
     return (size_t)n_pairs * ws_doubles_per_pair(max_features) * sizeof(double);
 }
 
+#ifdef DSDTM_DIAG
 int sparse_align_occupancy(int variant) {
     int nb = -1;
     if (variant == SA_REG320) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_reg_kernel<5, SA_PPW, false>, SA_PPW * 6 * 64, 0);
@@ -2149,6 +2150,7 @@ int sparse_align_occupancy(int variant) {
     else if (variant == SA_WS) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_align_ws_kernel<WS_NPW, 0>, WS_THREADS, 0);
     return nb;
 }
+#endif
 
 // persistent grid: one workgroup per CU (fewer when the batch is small); slots pull pairs dynamically
 static unsigned persistent_grid(int n_pairs, int ppw, int num_cus) {
@@ -2164,10 +2166,12 @@ static hipError_t launch_reg(const SAKernelArgs& args, int num_cus, hipStream_t 
     return hipGetLastError();
 }
 
+#ifdef DSDTM_DIAG
 hipError_t sparse_align_launch_stamps(const SAKernelArgs& args, int num_cus, hipStream_t stream) {
     if (args.n_pairs <= 0) return hipSuccess;
     return launch_reg<5, SA_PPW, true>(args, num_cus, stream);
 }
+#endif
 
 // More than 64 KB of dynamic LDS is an opt-in per kernel AND per device (the sharded entry launches from one
 // process on up to eight devices): set once for every (instantiation, device) pair, on the calling thread's device.

@@ -72,10 +72,12 @@ hipError_t warp_launch(const WarpKernelArgs& args, hipStream_t stream) {
     const dim3 grid((unsigned)((args.m + g - 1) / g));
     switch (g) {
         case 2: hipLaunchKernelGGL(warp_kernel<2>, grid, dim3(128), 0, stream, args); break;
-        case 8: hipLaunchKernelGGL(warp_kernel<8>, grid, dim3(128), 0, stream, args); break;
         case 16: hipLaunchKernelGGL(warp_kernel<16>, grid, dim3(128), 0, stream, args); break;
+#ifdef DSDTM_DIAG                                     // group sizes that were measured and not kept (A/B)
+        case 8: hipLaunchKernelGGL(warp_kernel<8>, grid, dim3(128), 0, stream, args); break;
         case 32: hipLaunchKernelGGL(warp_kernel<32>, grid, dim3(128), 0, stream, args); break;
         case 64: hipLaunchKernelGGL(warp_kernel<64>, grid, dim3(128), 0, stream, args); break;
+#endif
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -28,16 +28,23 @@ def gpu_fast10(ctx, img, barrier):
     return np.stack([xs, ys, score[ys, xs], keep[ys, xs]], 1).astype(np.int32)
 
 
-def test_fast_maps_equal_the_reference_vectors(gpu_ctx):
-    """Score map + non-max survivors of the device passes, corner by corner, against the vectors the
+@pytest.mark.diag
+def test_fast_maps_equal_the_reference_vectors(gpu_ctx_diag):
+    """(The score map and the survivor map are intermediate results: only the diagnostic library has an entry that returns them,
+    dsdtm_debug_fast10 — the same detect.hip, which DSDTM_DIAG does not touch. The release library's detector is held against the
+    reference-pinned oracle through its public entries below.)
+    Score map + non-max survivors of the device passes, corner by corner, against the vectors the
     reference's own FAST sources produced (tests/golden/fast_reference.npz)."""
+    gpu_ctx = gpu_ctx_diag
     fx = np.load(H.golden_path("fast_reference.npz"))
     assert np.array_equal(gpu_fast10(gpu_ctx, fx["test1"], 75), fx["test1_b75"]) and len(fx["test1_b75"]) == 167
     for name in ("test1", "noise", "lowc", "tex", "narrow"):
         assert np.array_equal(gpu_fast10(gpu_ctx, fx[name], 20), fx[name + "_b20"]), name
 
 
-def test_fast_maps_equal_the_oracle_on_odd_shapes(gpu_ctx, oracle):
+@pytest.mark.diag
+def test_fast_maps_equal_the_oracle_on_odd_shapes(gpu_ctx_diag, oracle):
+    gpu_ctx = gpu_ctx_diag
     rng = np.random.default_rng(8)
     for shape in [(7, 22), (6, 40), (33, 257), (61, 300), (480, 640)]:
         img = rng.integers(0, 256, shape, dtype=np.uint8)

@@ -75,7 +75,9 @@ def hip(gpu_ctx):
     for name in Q.SEARCH_WORLDS:
         out["search:" + name] = gpu_search(gpu_ctx, name)
     from tests.test_detector_gpu import gpu_fast10
-    out["detector"] = Q.detector_outputs(lambda im: gpu_pyrdown(gpu_ctx, im), lambda im, b: gpu_fast10(gpu_ctx, im, b),
+    from dsdtm_amd import capi
+    diag_ctx = capi.default_context(0, diag=True)      # the FAST score / survivor maps are intermediate results: only the
+    out["detector"] = Q.detector_outputs(lambda im: gpu_pyrdown(gpu_ctx, im), lambda im, b: gpu_fast10(diag_ctx, im, b),   # diagnostic library returns them (same detect.hip)
                                          lambda *a: gpu_detect_cells(gpu_ctx, *a))
     out["pose_opt"] = []
     for P in fx["pose_opt"]:

@@ -224,6 +224,7 @@ def test_match_candidates_batch_device_equals_the_oracle_across_group_boundaries
 
 
 @pytest.mark.gpu
+@pytest.mark.diag
 def test_find_match_direct_in_one_kernel_equals_the_two_kernel_path_and_the_oracle():
     """Round 5: FindMatchDirect is one launch (match.hip: the warped patches never leave LDS). The two-kernel path of rounds 1-4
     (warp_kernel -> HBM -> align2d_rows_kernel; debug option fmd_split) runs the same device functions: search level, flag and
@@ -234,6 +235,6 @@ def test_find_match_direct_in_one_kernel_equals_the_two_kernel_path_and_the_orac
     spec = importlib.util.spec_from_file_location("soak_fmd", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_fmd.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.main((1, 15, 16, 17, 127, 4099)) == 0
-    with capi.debug_options(fmd_split=1):
+    assert mod.main((1, 15, 16, 17, 127, 4099)) == 0                 # the release library: one kernel
+    with capi.diag_default(), capi.debug_options(fmd_split=1):       # the diagnostic library: the two-kernel path of rounds 1-4
         assert mod.main((1, 15, 16, 17, 127, 4099)) == 0

@@ -364,6 +364,7 @@ def test_sharded_large_pairs_take_the_big_lds_kernels_on_every_context(gpu_ctx, 
 
 
 @pytest.mark.gpu
+@pytest.mark.diag
 @pytest.mark.parametrize("N,P", [(600, 2), (1900, 18)])
 def test_sharded_entry_fetches_the_results_again_after_a_transparent_rerun(oracle, N, P):
     """dsdtm_sparse_align_batch_sharded queues its downloads before it checks the launch. When that check re-seeds and re-runs a
@@ -374,7 +375,7 @@ def test_sharded_entry_fetches_the_results_again_after_a_transparent_rerun(oracl
     base = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=1300 + N + i, margin=12) for i in range(min(P, 3))]
     scenes = [base[i % len(base)] for i in range(P)]
     want = [oracle.sparse_align(sc, L, 0, 10) for sc in base]
-    ctx = capi.Context(0)
+    ctx = capi.Context(0, diag=True)                                   # the diagnostic library: a member of every pair stays away
     lib = ctx.lib
     drop = lib.dsdtm_debug_drop_team_members
     drop.restype, drop.argtypes = None, [C.c_int]

@@ -9,8 +9,10 @@ from tests.conftest import cached_scene
 pytestmark = pytest.mark.gpu
 
 
-def test_device_building_blocks(gpu_ctx, oracle):
+@pytest.mark.diag
+def test_device_building_blocks(gpu_ctx_diag, oracle):
     """DPP wave reduction, pivoted LDLT, SE(3) exp/mul on the device vs the oracle's."""
+    gpu_ctx = gpu_ctx_diag            # the diagnostic library: this test needs its dsdtm_debug_* entries
     import ctypes as C
     rng = np.random.default_rng(7)
     lib = oracle.load()
@@ -641,11 +643,12 @@ def test_batch_launch_is_graph_capturable(gpu_ctx, oracle, N, P):
             assert ntg[i] == no
 
 
-def test_team_kernel_over_several_compute_units(gpu_ctx, oracle):
+def test_team_kernel_over_several_compute_units(gpu_ctx_each, oracle):
     """More features than one workgroup's registers hold (N > 704) and few pairs: every pair runs on a TEAM
     of K workgroups that exchange their partial sums and the pose through HBM each iteration. Same results
     as the oracle and — to rounding — as the single-workgroup workspace kernel (option no_team), bit-identical
     from launch to launch, ragged feature counts included; with many pairs the launcher falls back."""
+    gpu_ctx = gpu_ctx_each            # the release library, then the diagnostic one (its switches only there)
     import ctypes as C
     import os
     import torch
@@ -672,9 +675,10 @@ def test_team_kernel_over_several_compute_units(gpu_ctx, oracle):
     for _ in range(3):                                        # no dependence on timing
         T2, n2 = run(t, b, scenes)
         assert np.array_equal(T1, T2) and np.array_equal(n1, n2)
-    with capi.debug_options(no_team=1):
-        Tw, nw = run(t, b, scenes)
-    assert np.array_equal(n1, nw) and np.abs(T1 - Tw).max() < 1e-12
+    if gpu_ctx.diag:
+        with capi.debug_options(no_team=1):
+            Tw, nw = run(t, b, scenes)
+        assert np.array_equal(n1, nw) and np.abs(T1 - Tw).max() < 1e-12
     # ragged feature counts: members without a live patch still take part in every exchange
     nf = np.array([1000, 720, 300], np.int32)
     t["nf"] = torch.from_numpy(nf).to(dev)
@@ -739,13 +743,15 @@ def _short_team(ctx):
     return f, g
 
 
+@pytest.mark.diag
 @pytest.mark.parametrize("N,P", [(600, 2), (1900, 18)])
-def test_a_wait_that_runs_out_is_recovered_transparently(gpu_ctx, oracle, N, P):
+def test_a_wait_that_runs_out_is_recovered_transparently(gpu_ctx_diag, oracle, N, P):
     """The multi-CU kernels' waits on partner workgroups are bounded. A debug entry launches teams (2 pairs of 600
     features) / two-member pairs (18 pairs of 1900 features: too many for teams) with a member missing, so the members that run can never complete an exchange:
     they must give up, stop the pair and let the kernel end — and dsdtm_sparse_align_check must re-seed the poses and
     re-run the batch on the one-CU kernels in the same call: DSDTM_OK, the oracle's results, like the reference's Run
     (src/Sprase_ImageAlign.cpp:29-60), which cannot fail for scheduling reasons."""
+    gpu_ctx = gpu_ctx_diag            # the diagnostic library: this test needs its dsdtm_debug_* entries
     import ctypes as C
     import torch
     from dsdtm_amd import capi
@@ -777,16 +783,18 @@ def test_a_wait_that_runs_out_is_recovered_transparently(gpu_ctx, oracle, N, P):
     assert np.array_equal(t["Tc"].cpu().numpy(), Tg) or np.allclose(t["Tc"].cpu().numpy(), Tg, atol=1e-12, rtol=0)
 
 
-def test_the_timeout_word_is_per_context(gpu_ctx, oracle):
+@pytest.mark.diag
+def test_the_timeout_word_is_per_context(gpu_ctx_diag, oracle):
     """Two contexts on device 0; a timeout is provoked in one of them with the re-run switched off, so that it surfaces
     as DSDTM_ERR_HIP there — once. The other context's launch, in flight on its own stream meanwhile, and its check are
     unaffected (round 3 had one device-global flag: the first check of EITHER context reported and cleared it)."""
+    gpu_ctx = gpu_ctx_diag            # the diagnostic library: this test needs its dsdtm_debug_* entries
     import ctypes as C
     import torch
     from dsdtm_amd import capi
     dev = torch.device("cuda", 0)
     W, Hh, L, N = 320, 240, 3, 600
-    other = capi.Context(0)
+    other = capi.Context(0, diag=True)
     scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=1900 + i, margin=12) for i in range(2)]
     ta, ba = _device_batch(torch, dev, scenes, L, W, Hh)
     tb, bb = _device_batch(torch, dev, scenes, L, W, Hh)
@@ -813,10 +821,12 @@ def test_the_timeout_word_is_per_context(gpu_ctx, oracle):
         assert ntg[i] == no
 
 
-def test_single_pair_run_recovers_from_a_team_timeout(gpu_ctx, oracle):
+@pytest.mark.diag
+def test_single_pair_run_recovers_from_a_team_timeout(gpu_ctx_diag, oracle):
     """Sprase_ImgAlign::Run through the resident-frame entry with 600 features runs as a team of three compute units. With
     the debug switch that keeps the last member away the first attempt times out; the entry re-seeds the pose from its
     pinned block and re-runs on one compute unit: the caller sees the oracle's result and no error."""
+    gpu_ctx = gpu_ctx_diag            # the diagnostic library: this test needs its dsdtm_debug_* entries
     import ctypes as C
     sc = cached_scene(width=320, height=240, levels=3, n_patches=600, seed=1777, margin=12)
     To, no, so = oracle.sparse_align(sc, 3, 0, 10)
@@ -835,6 +845,7 @@ def test_single_pair_run_recovers_from_a_team_timeout(gpu_ctx, oracle):
     assert ng == no and sg["iters"] == so["iters"]
 
 
+@pytest.mark.diag
 def test_team_exchange_survives_the_wrap_of_its_tag_epoch(oracle):
     """The team kernel's exchange words are tagged with 20 bits of launch epoch and never cleared between launches: ring slot
     and epoch repeat together every 2^20 team launches, and a word member m of pair p wrote exactly then would be accepted
@@ -845,7 +856,7 @@ def test_team_exchange_survives_the_wrap_of_its_tag_epoch(oracle):
     import ctypes as C
     import torch
     from dsdtm_amd import capi
-    ctx = capi.Context(0)                                    # a context of its own: the counter is per context
+    ctx = capi.Context(0, diag=True)                         # a context of its own: the counter is per context
     dev = torch.device("cuda", 0)
     W, Hh, L = 320, 240, 3
     seq = ctx.lib.dsdtm_debug_team_seq
@@ -881,12 +892,13 @@ def test_team_exchange_survives_the_wrap_of_its_tag_epoch(oracle):
 
 
 @pytest.mark.parametrize("N,P,size", [(1000, 9, (320, 240)), (2000, 10, (640, 480)), (1500, 3, (320, 240)), (2048, 4, (640, 480))])
-def test_workspace_kernels_walk_features_in_row_order_with_the_same_results(gpu_ctx, oracle, N, P, size):
+def test_workspace_kernels_walk_features_in_row_order_with_the_same_results(gpu_ctx_each, oracle, N, P, size):
     """Batches of large pairs order a pair's features by image row on the device (one LDS sort per pair) before the lanes take
     them: the reference sums in list order (src/Sprase_ImageAlign.cpp:84-103), so only the rounding of the sums may differ —
     the oracle's poses to 1e-8, identical n_tracked / iterations / exit codes / n_ref / n_vis, with the ordering on and off
     (debug option ws_no_sort), for ragged feature counts, uninitialised features, and feature pixels that are NaN, negative or
     far outside the image (the sort key is a hint: it must never become an index)."""
+    gpu_ctx = gpu_ctx_each            # the release library, then the diagnostic one (its switches only there)
     import ctypes as C
     import copy
     import torch
@@ -915,8 +927,9 @@ def test_workspace_kernels_walk_features_in_row_order_with_the_same_results(gpu_
     prm = capi.AlignParams(L, 0, 10, 15)
     seeds = torch.from_numpy(np.stack([s_.T_cur_w_seed.reshape(12) for s_ in scenes])).to(dev)
     outs = []
-    for no_sort in (0, 1):
-        with capi.debug_options(ws_no_sort=no_sort):
+    import contextlib
+    for no_sort in ((0, 1) if gpu_ctx.diag else (0,)):
+        with (capi.debug_options(ws_no_sort=no_sort) if gpu_ctx.diag else contextlib.nullcontext()):
             t["Tc"].copy_(seeds)
             torch.cuda.synchronize()
             gpu_ctx.check(gpu_ctx.lib.dsdtm_sparse_align_batch_device(gpu_ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), None))
@@ -933,7 +946,8 @@ def test_workspace_kernels_walk_features_in_row_order_with_the_same_results(gpu_
             H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"{what}, pair {i}")
             assert ng[i] == no and list(sg["iters"][i][:L]) == list(so["iters"][:L]) and list(sg["exit_code"][i][:L]) == list(so["exit_code"][:L])
             assert list(sg["n_ref"][i][:L]) == list(so["n_ref"][:L]) and list(sg["n_vis"][i][:L]) == list(so["n_vis"][:L])
-    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-9             # the two orders differ by rounding only
+    if gpu_ctx.diag:
+        assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-9         # the two orders differ by rounding only
     # and the ordered launch is deterministic: the same bits again
     t["Tc"].copy_(seeds)
     torch.cuda.synchronize()
@@ -1034,11 +1048,12 @@ def test_more_streams_than_a_context_tracks(gpu_ctx, oracle):
                 assert ntg[i] == no
 
 
-def test_two_member_pairs_ragged_counts_determinism_and_the_one_unit_path(gpu_ctx, oracle):
+def test_two_member_pairs_ragged_counts_determinism_and_the_one_unit_path(gpu_ctx_each, oracle):
     """1025..2048 patches in batches: one pair on TWO compute units (halves wholly in LDS, partials exchanged through
     tagged words). A pair count that is not a multiple of 8, ragged live counts — a member whose half holds no live
     patch, a pair below Min_fts — statistics from member 0, bit-identical results from launch to launch, and the same
     results (to rounding: other summation order) on one compute unit with the HBM workspace (option ws_no_duo)."""
+    gpu_ctx = gpu_ctx_each            # the release library, then the diagnostic one (its switches only there)
     import ctypes as C
     import copy
     import torch
@@ -1080,9 +1095,10 @@ def test_two_member_pairs_ragged_counts_determinism_and_the_one_unit_path(gpu_ct
     for _ in range(3):
         T2, n2, s2 = run()
         assert np.array_equal(T1, T2) and np.array_equal(n1, n2) and np.array_equal(s1["chi2"], s2["chi2"])
-    with capi.debug_options(ws_no_duo=1):
-        T3, n3, s3 = run()
-    assert np.array_equal(n1, n3) and np.array_equal(s1["iters"], s3["iters"]) and np.abs(T1 - T3).max() < 1e-12
+    if gpu_ctx.diag:
+        with capi.debug_options(ws_no_duo=1):
+            T3, n3, s3 = run()
+        assert np.array_equal(n1, n3) and np.array_equal(s1["iters"], s3["iters"]) and np.abs(T1 - T3).max() < 1e-12
 
 
 def _roll_scene(theta, radius, n, seed, width=640, height=480, levels=4):
@@ -1194,11 +1210,13 @@ def test_workspace_launches_are_graph_capturable_after_reserve(gpu_ctx, oracle, 
     ctx.close()
 
 
-def test_more_unsettled_multi_cu_launches_than_recovery_slots(gpu_ctx, oracle):
+@pytest.mark.diag
+def test_more_unsettled_multi_cu_launches_than_recovery_slots(gpu_ctx_diag, oracle):
     """A context keeps what a re-run needs for 64 unsettled multi-CU launches. The first of 70 team launches on one stream
     loses a member (its waits run out); nobody calls dsdtm_sparse_align_check in between, so the 65th launch has to settle
     the oldest one itself — waits for its event, finds the timeout word set, re-seeds and re-runs it on the one-CU kernels —
     before it reuses the slot. Every launch ends with the oracle's results and the final check has nothing left to repair."""
+    gpu_ctx = gpu_ctx_diag            # the diagnostic library: this test needs its dsdtm_debug_* entries
     import ctypes as C
     import torch
     from dsdtm_amd import capi
@@ -1208,7 +1226,7 @@ def test_more_unsettled_multi_cu_launches_than_recovery_slots(gpu_ctx, oracle):
     want = [oracle.sparse_align(sc, L, 0, 10) for sc in scenes]
     cam = capi.camera_struct(scenes[0].cam)
     prm = capi.AlignParams(L, 0, 10, 15)
-    ctx = capi.Context(0)                                  # its own context: all 64 slots free
+    ctx = capi.Context(0, diag=True)                       # its own context: all 64 slots free
     f, recovered = _short_team(ctx)
     st = torch.cuda.Stream(device=dev)
     packed = [_device_batch(torch, dev, scenes, L, W, Hh) for _ in range(70)]
@@ -1226,10 +1244,12 @@ def test_more_unsettled_multi_cu_launches_than_recovery_slots(gpu_ctx, oracle):
     ctx.close()
 
 
-def test_captured_large_pairs_run_the_one_cu_kernels(gpu_ctx, oracle):
+@pytest.mark.diag
+def test_captured_large_pairs_run_the_one_cu_kernels(gpu_ctx_diag, oracle):
     """Inside a stream capture no multi-CU kernel is used (a graph replay could be neither ordered against live team
     launches nor re-run after a timeout): 18 pairs of 1900 features captured into a hipGraph run the one-CU workspace kernel
     (scratch reserved up front), replay twice with the oracle's results, and leave nothing to settle."""
+    gpu_ctx = gpu_ctx_diag            # the diagnostic library: this test needs its dsdtm_debug_* entries
     import ctypes as C
     import torch
     from dsdtm_amd import capi
@@ -1241,7 +1261,7 @@ def test_captured_large_pairs_run_the_one_cu_kernels(gpu_ctx, oracle):
     t, b = _device_batch(torch, dev, scenes, L, W, Hh)
     cam = capi.camera_struct(scenes[0].cam)
     prm = capi.AlignParams(L, 0, 10, 15)
-    ctx = capi.Context(0)
+    ctx = capi.Context(0, diag=True)
     _, recovered = _short_team(ctx)
     ctx.check(ctx.lib.dsdtm_reserve(ctx.handle, ctx.lib.dsdtm_sparse_align_workspace_bytes(C.byref(b))))
     seed = t["Tc"].clone()
@@ -1261,4 +1281,41 @@ def test_captured_large_pairs_run_the_one_cu_kernels(gpu_ctx, oracle):
             assert ntg[i] == no
     ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, st.cuda_stream))
     assert recovered(ctx.handle) == 0
+    ctx.close()
+
+
+@pytest.mark.diag
+def test_a_timed_out_launch_whose_pose_buffer_a_later_launch_reuses_is_reported(oracle):
+    """A re-run after a timeout is queued BEHIND the stream's later work. Two unchecked multi-CU launches of one stream into the
+    SAME pose buffer, the first of which times out (a member stays away): re-running it would overwrite the second launch's
+    results with the first's, so the check reports DSDTM_ERR_HIP instead of returning OK with the wrong poses (round-5 advice;
+    dsdtm_amd.h: unchecked launches of one stream name distinct output buffers). The context stays usable."""
+    import ctypes as C
+    import torch
+    from dsdtm_amd import capi
+    dev = torch.device("cuda", 0)
+    W, Hh, L, N = 320, 240, 3, 600
+    scenes = [cached_scene(width=W, height=Hh, levels=L, n_patches=N, seed=1300 + N + i, margin=12) for i in range(2)]
+    want = [oracle.sparse_align(sc, L, 0, 10) for sc in scenes]
+    cam = capi.camera_struct(scenes[0].cam)
+    prm = capi.AlignParams(L, 0, 10, 15)
+    ctx = capi.Context(0, diag=True)
+    f, recovered = _short_team(ctx)
+    st = torch.cuda.Stream(device=dev)
+    t, b = _device_batch(torch, dev, scenes, L, W, Hh)
+    ctx.check(f(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))                                   # times out
+    ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))   # same buffers, no check between
+    rc = ctx.lib.dsdtm_sparse_align_check(ctx.handle, st.cuda_stream)
+    assert rc == capi.ERR_HIP and b"reuses" in ctx.lib.dsdtm_last_error(ctx.handle)
+    assert recovered(ctx.handle) == 0                                           # nothing was re-run over the later launch's results
+    assert ctx.lib.dsdtm_sparse_align_check(ctx.handle, st.cuda_stream) == capi.OK      # reported once; the second record settles clean
+    # the context is usable: a fresh launch from the seeds gives the oracle's results
+    t["Tc"].copy_(torch.from_numpy(np.stack([s.T_cur_w_seed.reshape(12) for s in scenes])).to(dev))
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.dsdtm_sparse_align_batch_device(ctx.handle, C.byref(b), C.byref(cam), C.byref(prm), st.cuda_stream))
+    ctx.check(ctx.lib.dsdtm_sparse_align_check(ctx.handle, st.cuda_stream))
+    Tg, ntg = t["Tc"].cpu().numpy(), t["nt"].cpu().numpy()
+    for i, (To, no, _) in enumerate(want):
+        H.assert_pose_close(Tg[i], To, H.TIGHT_RAD * 10, H.TIGHT_M * 10, what=f"after the refused re-run, pair {i}")
+        assert ntg[i] == no
     ctx.close()

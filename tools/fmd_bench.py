@@ -18,7 +18,7 @@ from dsdtm_amd import capi, synth  # noqa: E402
 def main():
     groups = [int(v) for v in sys.argv[1:]] or [0, 2, 8, 16, 32, 64]
     dev = torch.device("cuda", 0)
-    ctx = capi.Context(0)
+    ctx = capi.Context(0, diag=True)   # the diagnostic library (dsdtm_debug_* / switches)
     stream = torch.cuda.Stream(device=dev)
     tdev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     for nfm, ncand in ((64, 800), (1, 816)):

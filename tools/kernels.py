@@ -52,6 +52,7 @@ def a2d():
     ctx.check(ctx.lib.dsdtm_align2d_batch_device(ctx.handle, C.byref(img), pbd.data_ptr(), pd.data_ptr(), lv.data_ptr(), pxd.data_ptr(), cv.data_ptr(), 10, M, st.cuda_stream))
 t = timed(a2d)
 print(f"Align2D (sums in the reference's order, the product path): {M} features (10 it cap) in {t*1e3:.3f} ms -> {M/t/1e6:.1f} M features/s, converged {cv.float().mean().item():.3f}")
-with capi.debug_options(a2d_tree=1):     # diagnostic: DPP tree sums (flags can differ from the reference on the 0.03 px threshold)
+if ctx.diag:                             # (DSDTM_PY_DIAG=1: the diagnostic library) DPP tree sums — flags can differ from the reference on the 0.03 px threshold
+  with capi.debug_options(a2d_tree=1):
     t = timed(a2d)
-print(f"Align2D (DPP tree sums, diagnostic):                        {M} features (10 it cap) in {t*1e3:.3f} ms -> {M/t/1e6:.1f} M features/s, converged {cv.float().mean().item():.3f}")
+  print(f"Align2D (DPP tree sums, diagnostic):                        {M} features (10 it cap) in {t*1e3:.3f} ms -> {M/t/1e6:.1f} M features/s, converged {cv.float().mean().item():.3f}")

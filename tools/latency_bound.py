@@ -26,7 +26,7 @@ from dsdtm_amd import capi, synth  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    ctx = capi.Context(0)
+    ctx = capi.Context(0, diag=True)   # the diagnostic library (dsdtm_debug_* / switches)
     stream = torch.cuda.Stream(device=dev)
     setopt = ctx.lib.dsdtm_debug_set_option
     z = torch.zeros(1, dtype=torch.int32, device=dev)

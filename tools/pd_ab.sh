@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B of library variants on the per-level pyramid kernel (2048 640x480 pyramids): tools/pd_ab.sh variants/lib_a.so ...
+export DSDTM_PY_DIAG=1   # the DSDTM_* switches below exist in the diagnostic library only (build.py --diag)
 cd "$(dirname "$0")/.."
 # the product library is put back when the script ends (the variants only ever replace it for the duration of a run)
 LIB=dsdtm_amd/csrc/libdsdtm_amd.so

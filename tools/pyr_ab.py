@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dsdtm_amd import capi
 
-dev = torch.device("cuda", 0); ctx = capi.Context(0); st = torch.cuda.Stream(device=dev)
+dev = torch.device("cuda", 0); ctx = capi.Context(0, diag=True)   # the diagnostic library (dsdtm_debug_* / switches); st = torch.cuda.Stream(device=dev)
 
 def timed(fn, reps, warm=3):
     for _ in range(warm): fn()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 5: why are the LATER iterations of the large-pair kernel slower when a pair's features are walked in image-row order?
 # SQ / LDS / cache counters of the 1024 x 1000-patch launch with the device-side order on and off (separate --pmc passes).
+export DSDTM_PY_DIAG=1   # the DSDTM_* switches below exist in the diagnostic library only (build.py --diag)
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/${1:-sortpmc}"
 mkdir -p "$OUT"

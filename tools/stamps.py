@@ -8,7 +8,7 @@ import bench
 from dsdtm_amd import capi, synth
 
 ap = argparse.ArgumentParser(); ap.add_argument("--pairs", type=int, default=1024); a = ap.parse_args()
-dev = torch.device("cuda", 0); ctx = capi.Context(0)
+dev = torch.device("cuda", 0); ctx = capi.Context(0, diag=True)   # the diagnostic library (dsdtm_debug_* / switches)
 cam = synth.Camera.tum(640, 480); cs = capi.camera_struct(cam); prm = capi.AlignParams(4, 0, 10, 15)
 st = torch.cuda.Stream(device=dev)
 d = bench.build_batch(torch, dev, ctx, cam, a.pairs, 640, 480, 4, 300, seed=0xD5D7, stream=st)

@@ -41,7 +41,7 @@ def time_launches(ctx, d, desc, cs, prm, stream, n=12):
 
 def main():
     dev = torch.device("cuda", 0)
-    ctx = capi.Context(0)
+    ctx = capi.Context(0, diag=True)   # the diagnostic library (dsdtm_debug_* / switches)
     stream = torch.cuda.Stream(device=dev)
     setopt = ctx.lib.dsdtm_debug_set_option
     for name, W, H, n_full, N in (("config 3 shape", 640, 480, 1024, 1000), ("config 5 shape", 1280, 960, 256, 2000)):

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from dsdtm_amd import capi, synth
 from dsdtm_amd.frame import Config, frames_from_scene
 from dsdtm_amd.sparse_align import Sprase_ImgAlign
-ctx = capi.default_context(0)
+ctx = capi.default_context(0, diag=True)   # the diagnostic library (switches)
 Config.Set("Camera.Min_fts", 15)
 for n in (1000, 2000, 3000, 4096, 5120, 6144, 7168, 8192):
     sc = synth.make_scene(n_patches=n, seed=5)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # workspace kernel, 1025..2048 patches: one pair on one compute unit with its grid inputs in an HBM workspace
 # (DSDTM_WS_NO_DUO=1) against one pair on two compute units, each half wholly in LDS; time and FETCH/WRITE traffic.
+export DSDTM_PY_DIAG=1   # the DSDTM_* switches below exist in the diagnostic library only (build.py --diag)
 REPO="$(cd "$(dirname "$0")/.." && pwd)"; cd "$REPO"
 O=gpurun_out/${1:-wsduo}; mkdir -p $O
 run() { timeout -k 10 120 python bench.py "$@" --steps 20 --warmup 3 --streams 1 --no-cpu --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%s: kernel %.4f ms  %.0f /s' % ('$LABEL', d['roofline']['kernel_ms_avg'], d['value']))"; }

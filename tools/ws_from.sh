@@ -1,5 +1,6 @@
 #!/bin/bash
 # batches of 1024 pairs: register kernels (one slot per CU from 321 features) against the workspace kernel (2 x 4 waves)
+export DSDTM_PY_DIAG=1   # the DSDTM_* switches below exist in the diagnostic library only (build.py --diag)
 cd "$(dirname "$0")/.."
 for n in 330 448 600 704; do for from in 704 320; do
   export DSDTM_WS_FROM=$from
