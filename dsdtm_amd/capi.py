@@ -140,7 +140,7 @@ EXPORTED_SYMBOLS = [
     "dsdtm_detect_cells", "dsdtm_detect_cells_frame", "dsdtm_match_candidates_frames",
     "dsdtm_pose_optimization", "dsdtm_pose_optimization_batch_device",
     "dsdtm_sparse_align_batch_sharded", "dsdtm_sparse_align_batch_streamed", "dsdtm_shard_range", "dsdtm_detect_cells_batch_device",
-    "dsdtm_match_candidates_batch_device", "dsdtm_match_candidates_scratch_bytes",
+    "dsdtm_match_candidates_batch_device", "dsdtm_match_candidates_scratch_bytes", "dsdtm_track_frame",
 ]
 
 
@@ -162,6 +162,34 @@ class PoseOptSummary(C.Structure):
         return dict(iterations=self.iterations, successful_steps=self.successful_steps, termination=self.termination,
                     n_residual_blocks=self.n_residual_blocks, initial_cost=self.initial_cost,
                     final_cost=self.final_cost, x=np.array(list(self.x)))
+
+
+class TrackDesc(C.Structure):
+    """dsdtm_track_desc: one tracked frame (new image, Run against the last frame, the local map) for dsdtm_track_frame."""
+    _fields_ = [("image", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32), ("levels", C.c_int32),
+                ("ref", C.c_void_p), ("ref_px_xy", C.c_void_p), ("ref_bearing", C.c_void_p), ("ref_p_world", C.c_void_p),
+                ("ref_initial", C.c_void_p), ("n_ref_features", C.c_int32), ("T_ref_w", C.c_void_p), ("T_seed", C.c_void_p),
+                ("align", AlignParams), ("min_tracked", C.c_int32),
+                ("kf", C.c_void_p), ("n_kf", C.c_int32), ("T_kf_w", C.c_void_p), ("n_points", C.c_int32),
+                ("mp_world", C.c_void_p), ("mp_found", C.c_void_p), ("mp_bad", C.c_void_p), ("obs_offset", C.c_void_p),
+                ("obs_kf", C.c_void_p), ("obs_px", C.c_void_p), ("obs_level", C.c_void_p), ("obs_bearing", C.c_void_p),
+                ("mask", C.c_void_p), ("mask_stride", C.c_int32), ("cell_size", C.c_int32), ("max_pyr_levels", C.c_int32),
+                ("max_matches", C.c_int32), ("align2d_iters", C.c_int32), ("pose_opt", PoseOptParams)]
+
+
+class TrackMatch(C.Structure):
+    _fields_ = [("cell", C.c_int32), ("point", C.c_int32), ("px", C.c_float * 2), ("level", C.c_int32)]
+
+
+TRACK_MATCH_DTYPE = np.dtype([("cell", "<i4"), ("point", "<i4"), ("px", "<f4", 2), ("level", "<i4")])
+assert TRACK_MATCH_DTYPE.itemsize == C.sizeof(TrackMatch)
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("frame", C.c_void_p), ("T_run", C.c_double * 12), ("n_tracked", C.c_int32), ("lost", C.c_int32),
+                ("stats", AlignStats), ("n_in_grid", C.c_int32), ("n_matches", C.c_int32), ("replay_full_scan", C.c_int32), ("reserved", C.c_int32),
+                ("T_opt", C.c_double * 12),
+                ("summary", PoseOptSummary)]
 
 
 # dsdtm_pose_opt_termination
@@ -285,6 +313,8 @@ def load(diag: bool | None = None):
     lib.dsdtm_sparse_align_batch_streamed.restype = C.c_int
     lib.dsdtm_sparse_align_batch_streamed.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamDesc), C.c_int, C.POINTER(Camera),
                                                       C.POINTER(AlignParams)]
+    lib.dsdtm_track_frame.restype = C.c_int
+    lib.dsdtm_track_frame.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(TrackDesc), C.POINTER(TrackResult), C.c_void_p, C.c_void_p]
     lib.dsdtm_shard_range.restype = None
     lib.dsdtm_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if diag:

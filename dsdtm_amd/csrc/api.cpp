@@ -89,7 +89,21 @@ struct dsdtm_ctx {
     std::vector<hipEvent_t> copy_events;
     hipEvent_t copy_fence = nullptr;
     int num_cus = 256;
+    // Pyramid buffers of destroyed frames, kept for the next frame of the same size: a live tracker creates and destroys one
+    // frame per image, and hipMalloc / hipFree (which waits for the whole device) cost more than the pyramid kernel.
+    struct PooledFrame { size_t pitch; uint8_t* d; };
+    static constexpr size_t FRAME_POOL = 8;
+    std::vector<PooledFrame> frame_pool;
 };
+
+// Contexts that are alive (dsdtm_frame_destroy may be handed a context that is already gone: it must not be dereferenced)
+static std::mutex g_live_mutex;
+static std::vector<dsdtm_ctx*> g_live_ctx;
+static bool ctx_is_live(dsdtm_ctx* ctx) {
+    std::lock_guard<std::mutex> g(g_live_mutex);
+    for (dsdtm_ctx* c : g_live_ctx) if (c == ctx) return true;
+    return false;
+}
 
 static thread_local char g_create_err[512] = "";
 
@@ -234,6 +248,10 @@ int dsdtm_create(int device, dsdtm_ctx** out) {
         delete ctx;
         return DSDTM_ERR_NOMEM;
     }
+    try {
+        std::lock_guard<std::mutex> g(g_live_mutex);
+        g_live_ctx.push_back(ctx);
+    } catch (...) { dsdtm_destroy(ctx); return DSDTM_ERR_NOMEM; }
     *out = ctx;
     return DSDTM_OK;
 }
@@ -257,6 +275,11 @@ int dsdtm_debug_get_option(const char* key, int* value) {
 
 void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> g(g_live_mutex);
+        for (size_t i = 0; i < g_live_ctx.size(); ++i)
+            if (g_live_ctx[i] == ctx) { g_live_ctx.erase(g_live_ctx.begin() + (long)i); break; }
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -271,6 +294,7 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     for (auto& e : ctx->copy_events) (void)hipEventDestroy(e);
     if (ctx->copy_fence) (void)hipEventDestroy(ctx->copy_fence);
     if (ctx->h_flags) (void)hipHostFree((void*)ctx->h_flags);
+    for (auto& pf : ctx->frame_pool) (void)hipFree(pf.d);
     delete ctx;
 }
 
@@ -1135,6 +1159,13 @@ static int frame_alloc(dsdtm_ctx* ctx, const PackedPyr& pl, dsdtm_frame** out) {
     dsdtm_frame* f = new (std::nothrow) dsdtm_frame();
     if (!f) return DSDTM_ERR_NOMEM;
     f->owner = ctx; f->device = ctx->device; f->pl = pl; f->pitch = align_up(pl.bytes, 256); f->d = nullptr;
+    for (size_t i = 0; i < ctx->frame_pool.size(); ++i)
+        if (ctx->frame_pool[i].pitch == f->pitch) {             // a destroyed frame's buffer of this size (its users have drained:
+            f->d = ctx->frame_pool[i].d;                        // every entry that takes a dsdtm_frame waits for its stream)
+            ctx->frame_pool.erase(ctx->frame_pool.begin() + (long)i);
+            *out = f;
+            return DSDTM_OK;
+        }
     if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&f->d, f->pitch) != hipSuccess) {
         set_err(ctx, "hipMalloc of a %zu-byte frame failed", f->pitch);
         delete f;
@@ -1197,7 +1228,11 @@ extern "C" int dsdtm_frame_create_from_image(dsdtm_ctx* ctx, const uint8_t* leve
 
 extern "C" void dsdtm_frame_destroy(dsdtm_ctx* ctx, dsdtm_frame* f) {
     if (!f) return;
-    (void)ctx;
+    // its own, LIVE context: the buffer goes to that context's pool (no hipFree, which would wait for the whole device)
+    if (ctx && f->d && ctx_is_live(ctx) && f->owner == ctx && ctx->frame_pool.size() < dsdtm_ctx::FRAME_POOL) {
+        try { ctx->frame_pool.push_back(dsdtm_ctx::PooledFrame{f->pitch, f->d}); f->d = nullptr; } catch (...) {}
+        if (!f->d) { delete f; return; }
+    }
     (void)hipSetDevice(f->device);
     if (f->d) (void)hipFree(f->d);       // hipFree waits for the device's pending work
     delete f;
@@ -1807,6 +1842,245 @@ extern "C" int dsdtm_pose_optimization(dsdtm_ctx* ctx, const double* bearing, co
     memcpy(T_cur_w, h + o_T, 96);
     memcpy(summary, h + o_sm, sizeof(*summary));
     if (summary->n_residual_blocks > 0) memcpy(residual_norm, h + o_rn, (size_t)summary->n_residual_blocks * 8);
+    return DSDTM_OK;
+}
+
+// ---- one tracked frame in ONE submission (src/Tracking.cpp:199-256) ------------------------------
+// new frame -> Run -> ReprojectPoint + Get_ClosetObs for every local map point -> FindMatchDirect for all of them -> the cell
+// walk of SearchLocalPoints replayed on the device -> PoseOptimization, enqueued back to back on the context's stream; the host
+// waits once. Inputs are packed into the context's pinned block while the GPU already works on the earlier stages (the image
+// goes first); the kernels read them from there (host-mapped, each byte once) and write their few results there.
+extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const dsdtm_track_desc* d, dsdtm_track_result* res,
+                                 dsdtm_track_match* matches, double* residual_norm) {
+    if (!ctx) return DSDTM_ERR_INVALID;
+    if (!cam || !d || !res || !matches || !residual_norm) { set_err(ctx, "NULL argument"); return DSDTM_ERR_INVALID; }
+    memset(res, 0, sizeof *res);
+    if (!d->image || d->width <= 0 || d->height <= 0 || d->stride < d->width || d->levels <= 0 || d->levels > DSDTM_MAX_LEVELS ||
+        d->width > 16384 || d->height > 16384) { set_err(ctx, "track: bad image geometry"); return DSDTM_ERR_INVALID; }
+    if (!d->ref || !d->T_ref_w || !d->T_seed || d->n_ref_features < 0 ||
+        (d->n_ref_features > 0 && (!d->ref_px_xy || !d->ref_bearing || !d->ref_p_world || !d->ref_initial))) {
+        set_err(ctx, "track: NULL reference-frame argument"); return DSDTM_ERR_INVALID;
+    }
+    if (d->n_kf < 0 || d->n_kf > 4096 || d->n_points < 0 || d->n_points > 4096 || (d->n_kf > 0 && (!d->kf || !d->T_kf_w)) ||
+        (d->n_points > 0 && (!d->mp_world || !d->mp_found || !d->mp_bad || !d->obs_offset))) {
+        set_err(ctx, "track: bad local map (at most 4096 keyframes and 4096 map points per call)"); return DSDTM_ERR_INVALID;
+    }
+    if (d->cell_size <= 0 || d->cell_size > 1024 || d->max_matches <= 0 || d->max_matches > 256 || d->align2d_iters < 0 ||
+        d->pose_opt.max_iterations < 0 || (d->mask && d->mask_stride < d->width)) {
+        set_err(ctx, "track: bad search parameters (cell_size 1..1024, max_matches 1..256)"); return DSDTM_ERR_INVALID;
+    }
+    const int max_search_level = d->max_pyr_levels - 3;                                      // src/Feature_alignment.cpp:144
+    if (max_search_level < 0 || max_search_level >= d->levels) { set_err(ctx, "track: max_pyr_levels - 3 outside the pyramid"); return DSDTM_ERR_INVALID; }
+    // the new frame's geometry (Frame::ComputeImagePyramid) must be the reference frame's and the keyframes'
+    PackedPyr pl;
+    int st[DSDTM_MAX_LEVELS];
+    pl.levels = d->levels;
+    {
+        size_t o = 0;
+        for (int l = 0; l < d->levels; ++l) {
+            pl.w[l] = l ? (pl.w[l - 1] + 1) / 2 : d->width; pl.h[l] = l ? (pl.h[l - 1] + 1) / 2 : d->height; st[l] = pl.w[l];
+            pl.off[l] = o; o += align_up((size_t)pl.w[l] * pl.h[l], 64);
+        }
+        pl.bytes = o;
+    }
+    auto same_geometry = [&](const dsdtm_frame* f) {
+        return f && f->owner == ctx && f->pl.levels == pl.levels && !memcmp(f->pl.w, pl.w, sizeof(int) * pl.levels) &&
+               !memcmp(f->pl.h, pl.h, sizeof(int) * pl.levels);
+    };
+    if (!same_geometry(d->ref)) { set_err(ctx, "track: the reference frame is NULL, foreign or of another geometry"); return DSDTM_ERR_INVALID; }
+    for (int k = 0; k < d->n_kf; ++k)
+        if (!same_geometry(d->kf[k])) { set_err(ctx, "track: keyframe %d is NULL, foreign or of another geometry", k); return DSDTM_ERR_INVALID; }
+    if (int rc = validate_params(ctx, &d->align, pl.levels)) return rc;
+    const int M = d->n_points;
+    const int nnz = M > 0 ? d->obs_offset[M] : 0;
+    if (M > 0) {
+        if (d->obs_offset[0] != 0 || nnz < 0 || (nnz > 0 && (!d->obs_kf || !d->obs_px || !d->obs_level || !d->obs_bearing))) {
+            set_err(ctx, "track: bad observation arrays"); return DSDTM_ERR_INVALID;
+        }
+        for (int i = 0; i < M; ++i)
+            if (d->obs_offset[i + 1] < d->obs_offset[i]) { set_err(ctx, "track: obs_offset is not monotone at point %d", i); return DSDTM_ERR_INVALID; }
+        for (int j = 0; j < nnz; ++j)
+            if (d->obs_kf[j] < 0 || d->obs_kf[j] >= d->n_kf || d->obs_level[j] < 0 || d->obs_level[j] >= pl.levels) {
+                set_err(ctx, "track: observation %d names keyframe %d / level %d out of range", j, d->obs_kf[j], d->obs_level[j]);
+                return DSDTM_ERR_INVALID;
+            }
+    }
+    const int grid_rows = (d->height + d->cell_size - 1) / d->cell_size, grid_cols = (d->width + d->cell_size - 1) / d->cell_size;   // :29-30
+    if ((long long)grid_rows * grid_cols > 4096) { set_err(ctx, "track: more than 4096 grid cells"); return DSDTM_ERR_INVALID; }
+    const size_t lds = track_replay_lds_bytes(M, grid_rows * grid_cols, d->cell_size);
+    if (lds > 160 * 1024 - 256) { set_err(ctx, "track: %d map points over %d cells do not fit one workgroup's LDS", M, grid_rows * grid_cols); return DSDTM_ERR_INVALID; }
+
+    const size_t img = (size_t)d->width * d->height, nf = (size_t)d->n_ref_features, Mz = (size_t)M, NZ = (size_t)nnz,
+                 MM = (size_t)d->max_matches, NK = (size_t)d->n_kf;
+    // ---- the pinned block (host-mapped): inputs, then results ----
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t h_img = take(img), h_mask = take(d->mask ? img : 0);
+    const size_t h_bear = take(nf * 24), h_pw = take(nf * 24), h_tr = take(96), h_px = take(nf * 8), h_ini = take(nf);
+    const size_t h_T = take(96), h_nt = take(4), h_st = take(sizeof(dsdtm_align_stats));
+    const size_t h_mpw = take(Mz * 24), h_found = take(Mz * 4), h_bad = take(Mz), h_off = take((Mz + 1) * 4), h_okf = take(NZ * 4),
+                 h_opx = take(NZ * 8), h_olv = take(NZ * 4), h_ob = take(NZ * 24), h_Tkf = take(NK * 96), h_kfp = take(NK * sizeof(void*));
+    const size_t h_cnt = take(16), h_match = take(MM * sizeof(dsdtm_track_match)), h_Topt = take(96),
+                 h_sm = take(sizeof(dsdtm_pose_opt_summary)), h_rn = take(MM * 8);
+    const size_t h_total = o;
+    // ---- device scratch ----
+    o = 0;
+    const size_t g_T = take(96), g_Tkf = take(NK * 96), g_kfp = take(NK * sizeof(void*)), g_pw = take(Mz * 24), g_cell = take(Mz * 4),
+                 g_px0 = take(Mz * 16), g_px = take(Mz * 16), g_ck = take(Mz * 4), g_cf = take(Mz * 4), g_rp = take(Mz * 8),
+                 g_rl = take(Mz * 4), g_rb = take(Mz * 24), g_ib = take(Mz), g_sl = take(Mz * 4), g_cv = take(Mz),
+                 g_pob = take(MM * 24), g_pow = take(MM * 24), g_pol = take(MM * 4), g_pou = take(MM), g_pon = take(4);
+    const size_t g_total = o;
+    if (int rc = ensure_stage(ctx, h_total > g_total ? h_total : g_total)) return rc;
+    uint8_t* h = (uint8_t*)ctx->h_pinned;
+    uint8_t* g = (uint8_t*)ctx->d_stage;
+    void* hd_ = nullptr;
+    HIP_TRY(ctx, hipHostGetDevicePointer(&hd_, ctx->h_pinned, 0));
+    uint8_t* hd = (uint8_t*)hd_;                       // the pinned block as the device sees it
+    hipStream_t stream = ctx->stream;
+
+    dsdtm_frame* f = nullptr;
+    if (int rc = frame_alloc(ctx, pl, &f)) return rc;
+    auto fail = [&](int rc) { (void)hipStreamSynchronize(stream); dsdtm_frame_destroy(ctx, f); return rc; };
+#define TRACK_TRY(call)                                                                                        \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) { set_err(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return fail(DSDTM_ERR_HIP); } \
+    } while (0)
+
+    // 1. the new frame: level 0 crosses the link, the pyramid is built on the device (src/Frame.cpp:35-41, :74-81)
+    if (d->stride == d->width) memcpy(h + h_img, d->image, img);
+    else for (int y = 0; y < d->height; ++y) memcpy(h + h_img + (size_t)y * d->width, d->image + (size_t)y * d->stride, (size_t)d->width);
+    TRACK_TRY(hipMemcpyAsync(f->d, h + h_img, img, hipMemcpyHostToDevice, stream));
+    if (int rc = dsdtm_pyrdown_batch_device(ctx, f->d, f->pitch, 1, pl.levels, pl.w, pl.h, st, pl.off, stream)) return fail(rc);
+
+    // 2. Run(cur, ref) — while the GPU copies and builds the pyramid, the host packs what Run reads
+    memcpy(h + h_bear, d->ref_bearing, nf * 24);
+    memcpy(h + h_pw, d->ref_p_world, nf * 24);
+    memcpy(h + h_tr, d->T_ref_w, 96);
+    memcpy(h + h_px, d->ref_px_xy, nf * 8);
+    memcpy(h + h_ini, d->ref_initial, nf);
+    // Run() (:34-38): too few features -> 0, the pose untouched. Decided on the host: no launch.
+    const bool run = d->n_ref_features >= d->align.min_fts && d->align.max_level - 1 >= d->align.min_level && d->n_ref_features > 0;
+    dsdtm_batch_desc b;
+    memset(&b, 0, sizeof b);
+    b.n_pairs = 1; b.max_features = d->n_ref_features; b.levels = pl.levels;
+    for (int l = 0; l < pl.levels; ++l) { b.width[l] = pl.w[l]; b.height[l] = pl.h[l]; b.stride[l] = pl.w[l]; b.level_offset[l] = pl.off[l]; }
+    b.pyr_pitch = d->ref->pitch;
+    b.ref_pyr = d->ref->d; b.cur_pyr = f->d;
+    b.px_xy = (const float*)(hd + h_px); b.bearing = (const double*)(hd + h_bear); b.p_world = (const double*)(hd + h_pw);
+    b.initial = hd + h_ini; b.T_ref_w = (const double*)(hd + h_tr); b.T_cur_w = (double*)(hd + h_T);
+    b.n_tracked = (int32_t*)(hd + h_nt); b.stats = (dsdtm_align_stats*)(hd + h_st);
+    if (d->ref->pitch != f->pitch) { set_err(ctx, "track: pyramid pitches differ"); return fail(DSDTM_ERR_INVALID); }
+
+    // 3. the local map, packed once (the retry below re-uses it)
+    bool packed_map = false;
+    auto pack_map = [&]() {
+        if (packed_map) return;
+        packed_map = true;
+        if (d->mask) for (int y = 0; y < d->height; ++y) memcpy(h + h_mask + (size_t)y * d->width, d->mask + (size_t)y * d->mask_stride, (size_t)d->width);
+        if (M > 0) {
+            memcpy(h + h_mpw, d->mp_world, Mz * 24); memcpy(h + h_found, d->mp_found, Mz * 4); memcpy(h + h_bad, d->mp_bad, Mz);
+            memcpy(h + h_off, d->obs_offset, (Mz + 1) * 4);
+        } else memset(h + h_off, 0, 4);
+        if (nnz > 0) {
+            memcpy(h + h_okf, d->obs_kf, NZ * 4); memcpy(h + h_opx, d->obs_px, NZ * 8); memcpy(h + h_olv, d->obs_level, NZ * 4);
+            memcpy(h + h_ob, d->obs_bearing, NZ * 24);
+        }
+        if (d->n_kf > 0) memcpy(h + h_Tkf, d->T_kf_w, NK * 96);
+        for (int k = 0; k < d->n_kf; ++k) ((const uint8_t**)(h + h_kfp))[k] = d->kf[k]->d;
+    };
+
+    TrackArgs t;
+    memset(&t, 0, sizeof t);
+    t.T_run = (const double*)(hd + h_T); t.n_tracked = (const int32_t*)(hd + h_nt); t.min_tracked = d->min_tracked;
+    t.T_kf_w = (const double*)(hd + h_Tkf); t.kf_ptrs = (const uint8_t* const*)(hd + h_kfp); t.n_kf = d->n_kf;
+    t.mp_world = (const double*)(hd + h_mpw); t.mp_found = (const int32_t*)(hd + h_found); t.mp_bad = hd + h_bad; t.n_points = M;
+    t.obs_offset = (const int32_t*)(hd + h_off); t.obs_kf = (const int32_t*)(hd + h_okf); t.obs_px = (const float*)(hd + h_opx);
+    t.obs_level = (const int32_t*)(hd + h_olv); t.obs_bearing = (const double*)(hd + h_ob);
+    t.mask = d->mask ? hd + h_mask : nullptr; t.mask_stride = d->width;
+    t.fx = cam->fx; t.fy = cam->fy; t.cx = cam->cx; t.cy = cam->cy; t.width = cam->width; t.height = cam->height; t.levels = pl.levels;
+    t.cell_size = d->cell_size; t.grid_cols = grid_cols; t.grid_rows = grid_rows; t.max_matches = d->max_matches;
+    t.d_T = (double*)(g + g_T); t.d_Tkf = (double*)(g + g_Tkf); t.d_kf_ptrs = (const uint8_t**)(g + g_kfp);
+    t.pw = (double*)(g + g_pw); t.cell = (int32_t*)(g + g_cell); t.px0 = (double*)(g + g_px0); t.px = (double*)(g + g_px);
+    t.cand_kf = (int32_t*)(g + g_ck); t.cand_frame = (int32_t*)(g + g_cf); t.ref_px = (float*)(g + g_rp); t.ref_level = (int32_t*)(g + g_rl);
+    t.ref_bearing = (double*)(g + g_rb); t.init_blocked = g + g_ib; t.search_level = (int32_t*)(g + g_sl); t.converged = g + g_cv;
+    t.matches = (dsdtm_track_match*)(hd + h_match); t.counts = (int32_t*)(hd + h_cnt); t.T_opt = (double*)(hd + h_Topt);
+    t.po_bearing = (double*)(g + g_pob); t.po_world = (double*)(g + g_pow); t.po_level = (int32_t*)(g + g_pol); t.po_use = g + g_pou;
+    t.po_n = (int32_t*)(g + g_pon);
+
+    WarpKernelArgs wa;
+    memset(&wa, 0, sizeof wa);
+    for (int l = 0; l < pl.levels; ++l) { wa.lv[l].w = pl.w[l]; wa.lv[l].h = pl.h[l]; wa.lv[l].stride = pl.w[l]; wa.lv[l].off = (uint32_t)pl.off[l]; }
+    wa.kf_ptrs = (const uint8_t* const*)t.d_kf_ptrs; wa.T_kf_w = t.d_Tkf; wa.T_cur_w_arr = t.d_T; wa.cand_frame = t.cand_frame;
+    wa.cand_kf = t.cand_kf; wa.ref_px = t.ref_px; wa.ref_level = t.ref_level; wa.ref_bearing = t.ref_bearing; wa.p_world = t.pw;
+    wa.search_level = t.search_level; wa.m = M; wa.n_kf = d->n_kf; wa.max_search_level = max_search_level; wa.levels = pl.levels;
+    wa.n_frames = 1; wa.fx = cam->fx; wa.fy = cam->fy; wa.cx = cam->cx; wa.cy = cam->cy; wa.no_xcd = options().fmd_no_xcd;
+    A2DKernelArgs aa;
+    memset(&aa, 0, sizeof aa);
+    aa.cur_pyr = f->d; aa.level = t.search_level; aa.px_xy = t.px; aa.converged = t.converged; aa.m = M; aa.max_iters = d->align2d_iters;
+    aa.levels = pl.levels; aa.px_level0 = 1; aa.frame = t.cand_frame; aa.n_frames = 1; aa.pyr_pitch = f->pitch;
+    for (int l = 0; l < pl.levels; ++l) aa.lv[l] = wa.lv[l];
+
+    PoseOptArgs pa;
+    pa.n_frames = 1; pa.max_features = d->max_matches; pa.max_iterations = d->pose_opt.max_iterations;
+    pa.n_features = t.po_n; pa.bearing = t.po_bearing; pa.p_world = t.po_world; pa.level = t.po_level; pa.use = t.po_use;
+    pa.T_cur_w = t.T_opt; pa.residual_norm = (double*)(hd + h_rn); pa.summary = (dsdtm_pose_opt_summary*)(hd + h_sm);
+
+    volatile unsigned* h_flag = ctx->h_flags + dsdtm_ctx::FLAG_SINGLE;
+    *h_flag = 0;
+    LaunchMode mode;
+    mode.single = true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool multi_cu = false;
+        memcpy(h + h_T, d->T_seed, 96);                              // cur->Set_Pose(last->Get_Pose()) (src/Tracking.cpp:201)
+        memset(h + h_nt, 0, 4); memset(h + h_st, 0, sizeof(dsdtm_align_stats));
+        memset(h + h_cnt, 0, 16); memset(h + h_sm, 0, sizeof(dsdtm_pose_opt_summary));
+        if (run) { if (int rc = launch_batch(ctx, &b, cam, &d->align, stream, mode, &multi_cu)) return fail(rc); }
+        pack_map();
+        // 4. ReprojectPoint + Get_ClosetObs for every point; FindMatchDirect for every point that passed; the cell walk; the
+        //    features of the matches; PoseOptimization on them — the instantiation picked on the device by the match count,
+        //    as dsdtm_pose_optimization picks it on the host (same arithmetic, same bits as the four-call chain)
+        TRACK_TRY(track_reproject_launch(t, stream));
+        TRACK_TRY(match_launch(wa, aa, stream));
+        TRACK_TRY(track_replay_launch(t, stream));
+        pa.force_variant = 1; pa.only_lo = -1; pa.only_hi = 64;
+        TRACK_TRY(pose_opt_launch(pa, stream));
+        if (d->max_matches > 64) {
+            pa.force_variant = 2; pa.only_lo = 64; pa.only_hi = 256;
+            TRACK_TRY(pose_opt_launch(pa, stream));
+        }
+        TRACK_TRY(hipStreamSynchronize(stream));
+        if (!*h_flag) break;
+        *h_flag = 0;
+        if (!multi_cu || attempt == 1 || options().no_recover) {
+            for (int i = 0; i < dsdtm_ctx::MAX_STREAMS; ++i)
+                if (ctx->rings[i].used && ctx->rings[i].stream == ctx->stream)
+                    (void)hipMemset(ctx->d_counter + i * dsdtm_ctx::COUNTERS_PER_STREAM, 0, sizeof(unsigned) * dsdtm_ctx::COUNTERS_PER_STREAM);
+            set_err(ctx, multi_cu ? "sparse-align kernel: a wait for a partner workgroup timed out (re-run disabled: no_recover)"
+                                  : "sparse-align kernel: intra-workgroup hand-over timed out");
+            return fail(DSDTM_ERR_HIP);
+        }
+        mode.one_cu = true;                                          // Run cannot fail for scheduling reasons: once more, on one compute unit
+        ctx->recovered += 1;
+    }
+#undef TRACK_TRY
+    res->frame = f;
+    memcpy(res->T_run, h + h_T, 96);
+    res->n_tracked = *(const int32_t*)(h + h_nt);
+    memcpy(&res->stats, h + h_st, sizeof res->stats);
+    res->lost = res->n_tracked < d->min_tracked ? 1 : 0;
+    const int32_t* cnt = (const int32_t*)(h + h_cnt);
+    res->n_in_grid = cnt[0];
+    res->n_matches = res->lost ? 0 : cnt[1];
+    res->replay_full_scan = cnt[2];
+    if (res->lost) {
+        memcpy(res->T_opt, res->T_run, 96);
+    } else {
+        memcpy(res->T_opt, h + h_Topt, 96);
+        memcpy(&res->summary, h + h_sm, sizeof res->summary);
+        if (res->n_matches > 0) memcpy(matches, h + h_match, (size_t)res->n_matches * sizeof(dsdtm_track_match));
+        if (res->summary.n_residual_blocks > 0) memcpy(residual_norm, h + h_rn, (size_t)res->summary.n_residual_blocks * 8);
+    }
     return DSDTM_OK;
 }
 

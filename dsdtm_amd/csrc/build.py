@@ -26,7 +26,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.cpp", "sparse_align.hip", "align2d.hip", "pyrdown.hip", "warp.hip", "match.hip", "detect.hip", "pose_opt.hip"]
+SOURCES = ["api.cpp", "sparse_align.hip", "align2d.hip", "pyrdown.hip", "warp.hip", "match.hip", "detect.hip", "pose_opt.hip", "track.hip"]
 DIAG_SOURCES = ["selftest.hip"]                      # diagnostic build only
 HEADERS = ["kernels.h", "device_math.h", "warp_body.h", "align2d_body.h", "exports.map", os.path.join("..", "..", "include", "dsdtm_amd.h")]
 OUT = os.path.join(HERE, "libdsdtm_amd.so")

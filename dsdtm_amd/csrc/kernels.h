@@ -177,8 +177,37 @@ struct PoseOptArgs {
     double* T_cur_w;               // n_frames x 12 (in/out)
     double* residual_norm;         // n_frames x max_features
     dsdtm_pose_opt_summary* summary;   // n_frames
+    // dsdtm_track_frame (one frame whose feature count is only known on the device): the instantiation is picked by the
+    // RANGE the live count falls in, as dsdtm_pose_optimization picks it on the host — every candidate instantiation is
+    // enqueued and the ones whose range (only_lo, only_hi] does not hold the count return at once. 0, 0: no filter.
+    int only_lo = 0, only_hi = 0;
+    int force_variant = 0;         // 0: by n_frames / max_features; 1: one wave per frame; 2: four waves, features in registers (<= 256)
 };
 hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream);
+
+// One tracked frame in one submission (track.hip): what sits between Run, FindMatchDirect and the pose refinement.
+struct TrackArgs {
+    // from Run (host-mapped: the alignment kernel of a single pair writes its results there)
+    const double* T_run; const int32_t* n_tracked; int min_tracked;
+    // the local map as the caller flattened it (host-mapped, read once)
+    const double* T_kf_w; const uint8_t* const* kf_ptrs; int n_kf;
+    const double* mp_world; const int32_t* mp_found; const uint8_t* mp_bad; int n_points;
+    const int32_t* obs_offset; const int32_t* obs_kf; const float* obs_px; const int32_t* obs_level; const double* obs_bearing;
+    const uint8_t* mask; int mask_stride;
+    float fx, fy, cx, cy; int width, height, levels;
+    int cell_size, grid_cols, grid_rows, max_matches;
+    // device scratch: the columns the FindMatchDirect kernel reads / writes (candidate = map point)
+    double* d_T; double* d_Tkf; const uint8_t** d_kf_ptrs;
+    double* pw; int32_t* cell; double* px0; double* px; int32_t* cand_kf; int32_t* cand_frame; float* ref_px; int32_t* ref_level;
+    double* ref_bearing; uint8_t* init_blocked; int32_t* search_level; uint8_t* converged;
+    // outputs of the replay: the match list and counts (host-mapped), the pose refinement's feature columns (device)
+    dsdtm_track_match* matches; int32_t* counts;      // counts: [0] points in the grid, [1] matches, [2] 1 = the full scan ran
+    double* T_opt;                                    // host-mapped: the pose refinement's in/out pose, seeded with T_run
+    double* po_bearing; double* po_world; int32_t* po_level; uint8_t* po_use; int32_t* po_n;
+};
+hipError_t track_reproject_launch(const TrackArgs& args, hipStream_t stream);
+hipError_t track_replay_launch(const TrackArgs& args, hipStream_t stream);
+size_t track_replay_lds_bytes(int n_points, int n_cells, int radius);
 
 #ifdef DSDTM_DIAG
 // device self-test of the FP64 building blocks (wave reduction, LDLT, SE3); see selftest.hip (diagnostic build only)

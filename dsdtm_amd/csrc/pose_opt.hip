@@ -341,6 +341,7 @@ void pose_opt_kernel(PoseOptArgs a) {
     f.use = a.use + base;
     f.n = a.n_features ? a.n_features[frame] : a.max_features;
     if (f.n > a.max_features) f.n = a.max_features;
+    if (a.only_hi > 0 && !(f.n > a.only_lo && f.n <= a.only_hi)) return;     // dsdtm_track_frame: another instantiation takes this count
     double* Tio = a.T_cur_w + (size_t)frame * 12;
 
     // residual blocks (src/Optimizer.cpp:45-65)
@@ -546,6 +547,8 @@ hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream) {
     // a few frames (the live tracker refines one): latency counts, four waves share a frame's features;
     // batches: one wave per frame, the solver part is not repeated
     const bool no_cache = options().po_no_cache != 0;                          // diagnostic (A/B)
+    if (args.force_variant == 1) { hipLaunchKernelGGL((pose_opt_kernel<1, 0>), dim3((unsigned)args.n_frames), dim3(64), 0, stream, args); return hipGetLastError(); }
+    if (args.force_variant == 2) { hipLaunchKernelGGL((pose_opt_kernel<4, 1>), dim3((unsigned)args.n_frames), dim3(256), 0, stream, args); return hipGetLastError(); }
     if (args.n_frames <= 32 && args.max_features > 64 && args.max_features <= 256 && !no_cache)
         hipLaunchKernelGGL((pose_opt_kernel<4, 1>), dim3((unsigned)args.n_frames), dim3(256), 0, stream, args);
     else if (args.n_frames <= 32 && args.max_features > 256 && args.max_features <= 512 && !no_cache)

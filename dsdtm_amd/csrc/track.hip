@@ -1,0 +1,451 @@
+// track.hip — the two kernels dsdtm_track_frame adds between Run, FindMatchDirect and the pose refinement so that one
+// tracked frame (reference src/Tracking.cpp:199-256) is ONE submission:
+//
+//   track_reproject_kernel  UpdateLocalMap's ReprojectPoint for every local map point with the pose Run just produced
+//                           (src/Feature_alignment.cpp:54-69, Frame::World2Pixel src/Frame.cpp:318-323, Camera::IsInImage
+//                           src/Camera.cpp:187-193), MapPoint::Get_ClosetObs (src/MapPoint.cpp:133-174) and the reference-
+//                           pixel test of FindMatchDirect (:135-140): thread = map point; writes the candidate columns the
+//                           fused FindMatchDirect kernel (match.hip) reads.
+//   track_replay_kernel     the order-dependent part of SearchLocalPoints / ReprojectCell (:71-121) over the results of
+//                           that kernel, ONE workgroup: cells in index order, candidates by found count (stable), bad /
+//                           masked candidates skipped, first success per cell, a disc of radius cell_size around every
+//                           success that suppresses later candidates, stop after max_matches cells. Then the features the
+//                           matches become (px as cv::Point2f, level, bearing of Frame::Add_Feature src/Frame.cpp:83-92) as
+//                           the columns the pose-refinement kernel reads.
+//
+// The walk is sequential in the reference, but a candidate's fate depends only on EARLIER candidates that are close to it:
+// the earlier candidates of its own cell, and the earlier candidates whose disc (centre = their refined pixel, known for
+// every converged candidate before any decision is taken) covers its reprojected pixel. So the replay is a dataflow
+// evaluation of the same recurrence: every live candidate lists its possible blockers once, then decides as soon as they
+// have decided — rounds = the depth of the dependency chains (tens), not the number of candidates (hundreds). A candidate
+// with more possible blockers than a thread keeps (dense worlds) switches the workgroup to scanning all earlier candidates
+// each round: slower, the same decisions.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+#pragma clang fp contract(off)      // the reprojection follows the host layer's operation order (dsdtm_host.hpp), no FMA
+
+namespace dsdtm {
+
+namespace {
+
+// cvRound (OpenCV 2.4, SSE2 cvtsd2si): round half to even; callers have checked that v is finite and small
+__device__ __forceinline__ int cv_round(double v) { return (int)rint(v); }
+
+__device__ __forceinline__ bool in_image(int width, int height, double x, double y, int boundary, int level) {   // src/Camera.cpp:187-193
+    if (!(fabs(x) < 1e9) || !(fabs(y) < 1e9)) return false;       // (NaN / infinity / beyond any image: cvRound is undefined there)
+    const int xr = cv_round(x), yr = cv_round(y);
+    return xr >= boundary && xr < width / (1 << level) - boundary && yr >= boundary && yr < height / (1 << level) - boundary;
+}
+
+// mOw = -R^T t in the host layer's order (dsdtm_host.hpp Frame::Get_CameraCnt)
+__device__ __forceinline__ void camera_centre(const double* __restrict__ m, double& c0, double& c1, double& c2) {
+    c0 = -(m[0] * m[3] + m[4] * m[7] + m[8] * m[11]);
+    c1 = -(m[1] * m[3] + m[5] * m[7] + m[9] * m[11]);
+    c2 = -(m[2] * m[3] + m[6] * m[7] + m[10] * m[11]);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void track_reproject_kernel(const TrackArgs a) {
+    __shared__ double s_T[12];
+    __shared__ int s_lost;
+    const int tid = threadIdx.x;
+    if (tid < 12) s_T[tid] = a.T_run[tid];                         // (host-mapped: Run wrote it there)
+    if (tid == 12) s_lost = (a.n_tracked[0] < a.min_tracked) ? 1 : 0;
+    __syncthreads();
+    if (blockIdx.x == 0) {                                         // what the later kernels read from device memory
+        if (tid < 12) { a.d_T[tid] = s_T[tid]; a.T_opt[tid] = s_T[tid]; }
+        for (int i = tid; i < a.n_kf * 12; i += 256) a.d_Tkf[i] = a.T_kf_w[i];
+        for (int i = tid; i < a.n_kf; i += 256) a.d_kf_ptrs[i] = a.kf_ptrs[i];
+    }
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= a.n_points) return;
+    const double P0 = a.mp_world[3 * (size_t)i], P1 = a.mp_world[3 * (size_t)i + 1], P2 = a.mp_world[3 * (size_t)i + 2];
+    a.pw[3 * (size_t)i] = P0; a.pw[3 * (size_t)i + 1] = P1; a.pw[3 * (size_t)i + 2] = P2;
+    const double* m = s_T;
+    // Frame::World2Pixel (src/Frame.cpp:318-323) -> Camera::Camera2Pixel (src/Camera.cpp:167-171)
+    const double x = m[0] * P0 + m[1] * P1 + m[2] * P2 + m[3], y = m[4] * P0 + m[5] * P1 + m[6] * P2 + m[7],
+                 z = m[8] * P0 + m[9] * P1 + m[10] * P2 + m[11];
+    const double u = (double)a.fx * x / z + (double)a.cx, v = (double)a.fy * y / z + (double)a.cy;
+    const bool bad = a.mp_bad[i] != 0;                             // UpdateLocalMap skips bad points (src/Tracking.cpp:288)
+    const bool in_grid = !s_lost && !bad && in_image(a.width, a.height, u, v, 8, 0);      // ReprojectPoint (:54-69)
+    int cell = -1, best = -1, jbest = -1;
+    if (in_grid) {
+        cell = (int)(v / a.cell_size) * a.grid_cols + (int)(u / a.cell_size);             // :65
+        // MapPoint::Get_ClosetObs (src/MapPoint.cpp:133-174)
+        double c0, c1, c2;
+        camera_centre(m, c0, c1, c2);
+        double v0 = c0 - P0, v1 = c1 - P1, v2 = c2 - P2;
+        const double nv = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+        v0 /= nv; v1 /= nv; v2 /= nv;
+        double best_cos = 0.0;
+        int first = -1, jfirst = -1;
+        for (int j = a.obs_offset[i]; j < a.obs_offset[i + 1]; ++j) {
+            const int k = a.obs_kf[j];
+            if (first < 0) { first = k; jfirst = j; }
+            double k0, k1, k2;
+            camera_centre(a.T_kf_w + 12 * (size_t)k, k0, k1, k2);
+            double r0 = k0 - P0, r1 = k1 - P1, r2 = k2 - P2;
+            const double nr = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+            r0 /= nr; r1 /= nr; r2 /= nr;
+            const double cs = r0 * v0 + r1 * v1 + r2 * v2;
+            if (cs > best_cos) { best_cos = cs; best = k; jbest = j; }
+        }
+        if (best < 0) { best = first; jbest = jfirst; }
+        if (best_cos < 0.5) { best = -1; jbest = -1; }
+        if (jbest >= 0) {                                          // FindMatchDirect :138-140: the reference pixel 5 px inside its level
+            const int lv = a.obs_level[jbest];
+            const float rx = a.obs_px[2 * (size_t)jbest], ry = a.obs_px[2 * (size_t)jbest + 1];
+            const float s = (float)(1 << (lv < 0 ? 0 : (lv > 30 ? 30 : lv)));
+            if (lv < 0 || lv >= a.levels || !in_image(a.width, a.height, (double)(rx / s), (double)(ry / s), 5, lv)) { best = -1; jbest = -1; }
+        }
+    }
+    a.cell[i] = cell;
+    a.px0[2 * (size_t)i] = u; a.px0[2 * (size_t)i + 1] = v;
+    a.px[2 * (size_t)i] = u; a.px[2 * (size_t)i + 1] = v;          // in/out of the FindMatchDirect kernel
+    a.cand_kf[i] = best;                                           // -1: rejected by that kernel (search level -1, not converged)
+    a.cand_frame[i] = 0;
+    if (jbest >= 0) {
+        a.ref_px[2 * (size_t)i] = a.obs_px[2 * (size_t)jbest]; a.ref_px[2 * (size_t)i + 1] = a.obs_px[2 * (size_t)jbest + 1];
+        a.ref_level[i] = a.obs_level[jbest];
+        a.ref_bearing[3 * (size_t)i] = a.obs_bearing[3 * (size_t)jbest];
+        a.ref_bearing[3 * (size_t)i + 1] = a.obs_bearing[3 * (size_t)jbest + 1];
+        a.ref_bearing[3 * (size_t)i + 2] = a.obs_bearing[3 * (size_t)jbest + 2];
+    } else {
+        a.ref_px[2 * (size_t)i] = 0.0f; a.ref_px[2 * (size_t)i + 1] = 0.0f; a.ref_level[i] = 0;
+        a.ref_bearing[3 * (size_t)i] = 0.0; a.ref_bearing[3 * (size_t)i + 1] = 0.0; a.ref_bearing[3 * (size_t)i + 2] = 1.0;
+    }
+    // the mask test of ReprojectCell (:96) reads the ROUNDED reprojected pixel; the caller's mask at the start of the search
+    uint8_t blocked = 0;
+    if (in_grid && a.mask) blocked = a.mask[(size_t)cv_round(v) * a.mask_stride + cv_round(u)] != 255 ? 1 : 0;
+    a.init_blocked[i] = blocked;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the replay
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int RP_THREADS = 1024;
+constexpr int RP_BL = 16;            // possible blockers a thread keeps per candidate
+constexpr int RP_CAP = 16;           // live candidates per disc-centre cell before the workgroup falls back to the full scan
+enum : uint8_t { ST_UNKNOWN = 0, ST_ACCEPTED = 1, ST_REJ_FREE = 2, ST_REJ_TAKEN = 3, ST_DEAD = 4 };
+
+// half-widths of the rows cv::circle(img, c, r, v, -1) paints (OpenCV 2.4 drawing.cpp Circle(): midpoint circle filled by
+// horizontal spans; a row can be painted by several spans, the widest counts) — hw[|dy|], dy = -r..r
+__device__ void circle_half_widths(int radius, int16_t* hw) {
+    for (int i = 0; i <= radius; ++i) hw[i] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (hw[dy] < dx) hw[dy] = (int16_t)dx;
+        if (hw[dx] < dy) hw[dx] = (int16_t)dy;
+        dy += 1;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+// Dynamic LDS of the replay workgroup, carved by ONE function for the host (size) and the device (pointers)
+struct ReplayLds {
+    uint32_t* hist;      // [cells + 1] counts, then bin starts (exclusive scan); [cells] = n_in
+    uint32_t* cur;       // [cells] next free place of a bin; later: live candidates per disc-centre cell
+    unsigned long long* tmp;   // [mpad] keys in bin order
+    uint16_t* idx;       // [mpad] candidate (map point) of rank r
+    uint16_t* rcell;     // [mpad] its grid cell
+    int16_t* px;  int16_t* py;    // [mpad] rounded reprojected pixel
+    int16_t* qx;  int16_t* qy;    // [mpad] rounded refined pixel (disc centre)
+    uint8_t* state;      // [mpad]
+    uint16_t* bucket;    // [cells * RP_CAP] ranks of the live candidates of a disc-centre cell
+    int16_t* hw;         // [radius + 1]
+    uint32_t* wsum;      // [RP_THREADS / 64]
+    size_t bytes;
+};
+__host__ __device__ inline ReplayLds replay_layout(uint8_t* base, int n_points, int cells, int radius) {
+    const size_t mpad = ((size_t)n_points + 63) / 64 * 64;
+    ReplayLds L;
+    size_t o = 0;
+    auto take = [&](size_t bytes, size_t align) { o = (o + align - 1) / align * align; const size_t at = o; o += bytes; return base + at; };
+    L.tmp = (unsigned long long*)take(mpad * 8, 8);
+    L.hist = (uint32_t*)take(((size_t)cells + 1) * 4, 4);
+    L.cur = (uint32_t*)take((size_t)cells * 4, 4);
+    L.wsum = (uint32_t*)take((RP_THREADS / 64) * 4, 4);
+    L.idx = (uint16_t*)take(mpad * 2, 2);
+    L.rcell = (uint16_t*)take(mpad * 2, 2);
+    L.px = (int16_t*)take(mpad * 2, 2);
+    L.py = (int16_t*)take(mpad * 2, 2);
+    L.qx = (int16_t*)take(mpad * 2, 2);
+    L.qy = (int16_t*)take(mpad * 2, 2);
+    L.bucket = (uint16_t*)take((size_t)cells * RP_CAP * 2, 2);
+    L.hw = (int16_t*)take(((size_t)radius + 1) * 2, 2);
+    L.state = take(mpad, 1);
+    L.bytes = (o + 15) / 16 * 16;
+    return L;
+}
+}  // namespace
+
+size_t track_replay_lds_bytes(int n_points, int n_cells, int radius) { return replay_layout(nullptr, n_points, n_cells, radius).bytes; }
+
+template <int EPT>
+__global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    __shared__ int s_overflow, s_n_in;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = a.n_points, cells = a.grid_cols * a.grid_rows, R = a.cell_size;
+    const ReplayLds L = replay_layout(lds_raw, M, cells, R);
+    for (int c = tid; c <= cells; c += RP_THREADS) L.hist[c] = 0u;
+    if (tid == 0) { s_overflow = 0; circle_half_widths(R, L.hw); }
+    __syncthreads();
+
+    // ---- 1. the grid's cell lists in walk order: counting sort by cell, inside a cell by (found descending, list index) ----
+    unsigned long long key[EPT];
+    int kcell[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * RP_THREADS;                        // (coalesced reads of the candidate columns)
+        kcell[e] = -1;
+        key[e] = ~0ull;
+        if (i < M) {
+            const int c = a.cell[i];
+            if (c >= 0 && c < cells) {
+                kcell[e] = c;
+                const int f = a.mp_found[i];
+                key[e] = ((unsigned long long)(uint32_t)(0x7fffffffll - (long long)f) << 16) | (unsigned long long)i;   // :88,:123-126 (stable: list order)
+                atomicAdd(&L.hist[c], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the cell counts: consecutive cells per thread, wave scan, wave totals
+        const int cpt = (cells + RP_THREADS - 1) / RP_THREADS;     // <= 4 (cells <= 4096)
+        uint32_t c[4] = {0, 0, 0, 0}, sum = 0;
+        for (int q = 0; q < cpt; ++q) { const int cc = tid * cpt + q; c[q] = cc < cells ? L.hist[cc] : 0u; sum += c[q]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += up; }
+        if (lane == 63) L.wsum[wave] = inc;
+        __syncthreads();
+        uint32_t base = inc - sum;
+        for (int w = 0; w < wave; ++w) base += L.wsum[w];
+        for (int q = 0; q < cpt; ++q) { const int cc = tid * cpt + q; if (cc < cells) { L.hist[cc] = base; L.cur[cc] = base; } base += c[q]; }
+        if (tid == RP_THREADS - 1) { L.hist[cells] = base; s_n_in = (int)base; }
+    }
+    __syncthreads();
+    const int n_in = s_n_in;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (kcell[e] >= 0) L.tmp[atomicAdd(&L.cur[kcell[e]], 1u)] = ((unsigned long long)kcell[e] << 48) | key[e];
+    __syncthreads();
+    // a key's place inside its cell = its rank among the cell's keys (cells hold a handful of candidates)
+    unsigned long long mine[EPT];
+    int place[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int q = tid + e * RP_THREADS;
+        place[e] = -1;
+        if (q < n_in) {
+            const unsigned long long kq = L.tmp[q];
+            const int c = (int)(kq >> 48);
+            const uint32_t s0 = L.hist[c], e0 = L.hist[c + 1];
+            uint32_t rank = 0;
+            for (uint32_t r = s0; r < e0; ++r) rank += L.tmp[r] < kq ? 1u : 0u;
+            mine[e] = kq; place[e] = (int)(s0 + rank);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (place[e] >= 0) { L.idx[place[e]] = (uint16_t)(mine[e] & 0xffffu); L.rcell[place[e]] = (uint16_t)(mine[e] >> 48); }
+    __syncthreads();
+
+    // ---- 2. per rank: live? (converged, not bad, not masked at the start); reprojected and refined pixels, rounded ----
+    // thread t owns ranks t * EPT .. t * EPT + EPT - 1 from here on (contiguous: the final prefix count is a plain scan)
+    int my_idx[EPT];
+    bool live[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int r = tid * EPT + e;
+        live[e] = false; my_idx[e] = 0;
+        if (r < n_in) {
+            const int i = L.idx[r];
+            my_idx[e] = i;
+            // ReprojectCell: IsBad (:93), mask (:96), FindMatchDirect false (:101-104) — none of them has a side effect, so a
+            // candidate that fails any of them is simply not there
+            const bool ok = a.converged[i] != 0 && a.mp_bad[i] == 0 && a.init_blocked[i] == 0;
+            const double u0 = a.px0[2 * (size_t)i], v0 = a.px0[2 * (size_t)i + 1];
+            const double u1 = a.px[2 * (size_t)i], v1 = a.px[2 * (size_t)i + 1];
+            const bool fin = fabs(u1) < 30000.0 && fabs(v1) < 30000.0;       // (a converged pixel sits inside the image)
+            live[e] = ok && fin;
+            L.px[r] = (int16_t)cv_round(u0); L.py[r] = (int16_t)cv_round(v0);
+            L.qx[r] = live[e] ? (int16_t)cv_round(u1) : (int16_t)0; L.qy[r] = live[e] ? (int16_t)cv_round(v1) : (int16_t)0;
+            L.state[r] = live[e] ? ST_UNKNOWN : ST_DEAD;
+        }
+    }
+    __syncthreads();
+    // ---- 3. possible blockers: the previous live candidate of the same cell; live earlier candidates whose disc covers me ----
+    // live candidates binned by the grid cell of their disc centre (dword counters in L.cur, free after the sort)
+    for (int c = tid; c < cells; c += RP_THREADS) L.cur[c] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int r = tid * EPT + e;
+        if (r < n_in && live[e]) {
+            const int qc = min(max((int)L.qy[r] / R, 0), a.grid_rows - 1) * a.grid_cols + min(max((int)L.qx[r] / R, 0), a.grid_cols - 1);
+            const uint32_t slot = atomicAdd(&L.cur[qc], 1u);
+            if (slot < (uint32_t)RP_CAP) L.bucket[qc * RP_CAP + slot] = (uint16_t)r;
+            else s_overflow = 1;
+        }
+    }
+    __syncthreads();
+    uint16_t blk[EPT][RP_BL];
+    int nblk[EPT], pred[EPT];   // pred: the nearest earlier LIVE candidate of the same cell, or -1
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int r = tid * EPT + e;
+        nblk[e] = 0; pred[e] = -1;
+        if (r < n_in && live[e]) {
+            const int c = L.rcell[r];
+            for (int rr = r - 1; rr >= (int)L.hist[c]; --rr)
+                if (L.state[rr] == ST_UNKNOWN) { pred[e] = rr; break; }
+            const int x = L.px[r], y = L.py[r];
+            const int cx = x / R, cy = y / R;                       // (the reprojected pixel is inside the image)
+            for (int ny = max(cy - 1, 0); ny <= min(cy + 1, a.grid_rows - 1); ++ny)
+                for (int nx = max(cx - 1, 0); nx <= min(cx + 1, a.grid_cols - 1); ++nx) {
+                    const int qc = ny * a.grid_cols + nx;
+                    const int n = min((int)L.cur[qc], RP_CAP);
+                    for (int s = 0; s < n; ++s) {
+                        const int rr = L.bucket[qc * RP_CAP + s];
+                        if (rr >= r) continue;
+                        const int dy = y - (int)L.qy[rr], ady = dy < 0 ? -dy : dy;
+                        if (ady > R) continue;
+                        const int dx = x - (int)L.qx[rr], adx = dx < 0 ? -dx : dx;
+                        if (adx > (int)L.hw[ady]) continue;
+                        if (nblk[e] < RP_BL) {
+#pragma unroll
+                            for (int j = 0; j < RP_BL; ++j) if (j == nblk[e]) blk[e][j] = (uint16_t)rr;
+                            nblk[e]++;
+                        } else s_overflow = 1;
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    const bool full_scan = s_overflow != 0;
+    // ---- 4. the recurrence, evaluated as its inputs become known ----
+    for (;;) {
+        int changed = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int r = tid * EPT + e;
+            if (!(r < n_in && live[e]) || L.state[r] != ST_UNKNOWN) continue;
+            const uint8_t sp = pred[e] < 0 ? (uint8_t)ST_REJ_FREE : L.state[pred[e]];
+            if (sp == ST_UNKNOWN) continue;
+            uint8_t ns;
+            if (sp == ST_ACCEPTED || sp == ST_REJ_TAKEN) ns = ST_REJ_TAKEN;          // :115 the cell already has its match
+            else {
+                bool any_acc = false, any_unk = false;
+                if (!full_scan) {
+#pragma unroll
+                    for (int j = 0; j < RP_BL; ++j)
+                        if (j < nblk[e]) { const uint8_t s = L.state[blk[e][j]]; any_acc |= s == ST_ACCEPTED; any_unk |= s == ST_UNKNOWN; }
+                } else {
+                    const int x = L.px[r], y = L.py[r];
+                    for (int rr = 0; rr < r; ++rr) {
+                        const uint8_t s = L.state[rr];
+                        if (s != ST_ACCEPTED && s != ST_UNKNOWN) continue;
+                        const int dy = y - (int)L.qy[rr], ady = dy < 0 ? -dy : dy;
+                        if (ady > R) continue;
+                        const int dx = x - (int)L.qx[rr], adx = dx < 0 ? -dx : dx;
+                        if (adx > (int)L.hw[ady]) continue;
+                        any_acc |= s == ST_ACCEPTED; any_unk |= s == ST_UNKNOWN;
+                    }
+                }
+                if (any_acc) ns = ST_REJ_FREE;                                       // :96 masked by an earlier match's disc (:111)
+                else if (any_unk) continue;
+                else ns = ST_ACCEPTED;
+            }
+            L.state[r] = ns;
+            changed = 1;
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    // ---- 5. the matches in walk order, at most max_matches (:80); the features they become ----
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { const int r = tid * EPT + e; if (r < n_in && L.state[r] == ST_ACCEPTED) cnt++; }
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += up; }
+    if (lane == 63) L.wsum[wave] = inc;
+    __syncthreads();
+    uint32_t k = inc - cnt, total = 0;
+    for (int w = 0; w < RP_THREADS / 64; ++w) { if (w < wave) k += L.wsum[w]; total += L.wsum[w]; }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int r = tid * EPT + e;
+        if (!(r < n_in && L.state[r] == ST_ACCEPTED)) continue;
+        if (k < (uint32_t)a.max_matches) {
+            const int i = my_idx[e];
+            const float fx_ = (float)a.px[2 * (size_t)i], fy_ = (float)a.px[2 * (size_t)i + 1];   // Feature(px as cv::Point2f, :108)
+            const int lvl = a.search_level[i];
+            dsdtm_track_match mo;
+            mo.cell = (int)L.rcell[r]; mo.point = i; mo.px[0] = fx_; mo.px[1] = fy_; mo.level = lvl;
+            a.matches[k] = mo;
+            // Frame::Add_Feature (src/Frame.cpp:83-92): mNormal = Pixel2Camera(cv::Point2f, 1.0f) in float, normalised in double
+            const float one = 1.0f;
+            const double bx = (double)((one * (fx_ - a.cx)) / a.fx), by = (double)((one * (fy_ - a.cy)) / a.fy);
+            const double n = sqrt(bx * bx + by * by + 1.0 * 1.0);
+            a.po_bearing[3 * (size_t)k] = bx / n; a.po_bearing[3 * (size_t)k + 1] = by / n; a.po_bearing[3 * (size_t)k + 2] = 1.0 / n;
+            a.po_world[3 * (size_t)k] = a.pw[3 * (size_t)i]; a.po_world[3 * (size_t)k + 1] = a.pw[3 * (size_t)i + 1];
+            a.po_world[3 * (size_t)k + 2] = a.pw[3 * (size_t)i + 2];
+            a.po_level[k] = lvl; a.po_use[k] = 1;
+        }
+        k++;
+    }
+    if (tid == 0) {
+        const int nm = (int)(total < (uint32_t)a.max_matches ? total : (uint32_t)a.max_matches);
+        a.po_n[0] = nm;
+        a.counts[0] = n_in; a.counts[1] = nm; a.counts[2] = full_scan ? 1 : 0;
+    }
+}
+
+hipError_t track_reproject_launch(const TrackArgs& a, hipStream_t stream) {
+    // (at least one workgroup: block 0 also hands pose, keyframe poses and pointers to the later kernels)
+    const int blocks = a.n_points > 0 ? (a.n_points + 255) / 256 : 1;
+    hipLaunchKernelGGL(track_reproject_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <auto Kernel>
+static hipError_t replay_optin(size_t bytes) {
+    // more than 64 KB of dynamic LDS is an opt-in per kernel and device; harmless to repeat
+    return hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t track_replay_launch(const TrackArgs& a, hipStream_t stream) {
+    const size_t lds = track_replay_lds_bytes(a.n_points, a.grid_cols * a.grid_rows, a.cell_size);
+    if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+    const int ept = (a.n_points + RP_THREADS - 1) / RP_THREADS;
+    hipError_t e = hipSuccess;
+    if (ept <= 1) {
+        if (lds > 48 * 1024) e = replay_optin<track_replay_kernel<1>>(lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(track_replay_kernel<1>, dim3(1), dim3(RP_THREADS), lds, stream, a);
+    } else if (ept <= 2) {
+        if (lds > 48 * 1024) e = replay_optin<track_replay_kernel<2>>(lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(track_replay_kernel<2>, dim3(1), dim3(RP_THREADS), lds, stream, a);
+    } else if (ept <= 4) {
+        if (lds > 48 * 1024) e = replay_optin<track_replay_kernel<4>>(lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(track_replay_kernel<4>, dim3(1), dim3(RP_THREADS), lds, stream, a);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace dsdtm

@@ -326,6 +326,89 @@ int dsdtm_pose_optimization_batch_device(dsdtm_ctx* ctx, int n_frames, int max_f
                                          double* residual_norm, dsdtm_pose_opt_summary* summary,
                                          void* hip_stream);
 
+/* ---- One tracked frame in ONE submission (src/Tracking.cpp:199-256) ----------------- */
+/*
+ * Replaces, for a tracker that keeps its frames on the device, the chain Tracking runs per frame:
+ *   Frame construction (src/Frame.cpp:35-41 -> ComputeImagePyramid :74-81)           new frame: level-0 upload + pyramid
+ *   TrackWithLastFrame  (src/Tracking.cpp:199-217): Set_Pose(last pose); Sprase_ImgAlign::Run(cur, last)
+ *   UpdateLocalMap      (:258-312): Feature_Alignment::ResetGrid; ReprojectPoint for every local map point
+ *   TrackWithLocalMap   (:219-256): SearchLocalPoints (src/Feature_alignment.cpp:71-158: FindMatchDirect for every
+ *                       candidate, the cell walk with its order-dependent rules, see below) and
+ *                       Optimizer::PoseOptimization (src/Optimizer.cpp:20-79) on the features the search created.
+ * Through the entries above that is four synchronous calls with host work between them (0.28 ms wall for 0.18 ms of
+ * kernels); here everything is enqueued back to back on the context's stream — copy, pyramid, Run, reprojection + closest
+ * observation, FindMatchDirect for all points, the replay of the cell walk ON THE DEVICE, pose refinement — and the host
+ * waits ONCE, for a few hundred bytes of results in pinned memory.
+ *
+ * The device replay follows src/Feature_alignment.cpp:71-121 exactly: cells in index order (:75; mCellOrder is shuffled
+ * but unused), per cell the candidates by Get_FoundNums() descending, stable in ReprojectPoint order (:88, :123-126), bad
+ * points skipped (:93), the mask test on the ROUNDED reprojected pixel (:96), first success wins the cell (:115), a success
+ * paints a disc of radius cell_size at the rounded REFINED pixel (:111, cv::circle's filled midpoint circle) which can
+ * suppress candidates of later cells, stop after max_matches matched cells (:80). The caller's list of map points is
+ * the order ReprojectPoint would be called in (UpdateLocalMap walks the local keyframes' map points, :283-299); points the
+ * reference never projects (NULL, already projected for this frame) are simply not in the list; bad ones may be (mp_bad).
+ * Because the local map is handed over BEFORE Run, it is the caller's choice of local keyframes that is fixed early
+ * (the reference picks them with the pose Run produced, :263); visibility (ReprojectPoint's image test) and the closest
+ * observation (MapPoint::Get_ClosetObs, src/MapPoint.cpp:133-174) are evaluated on the device with the pose Run produced.
+ *
+ * Observations are flattened by the caller: point i has observations obs_offset[i] .. obs_offset[i+1]-1 in the iteration
+ * order of its mObservations map; observation j names keyframe obs_kf[j] (index into kf[]) and carries the observing
+ * feature's mpx (obs_px), mlevel (obs_level) and mNormal (obs_bearing).
+ * Limits: n_points <= 4096, grid cells <= 4096, max_matches <= 256, n_kf <= 4096 (DSDTM_ERR_INVALID beyond).
+ */
+typedef struct dsdtm_track_desc {
+    /* the new frame (src/Frame.cpp:35-41) */
+    const uint8_t* image; int32_t width, height, stride, levels;
+    /* Run(cur, ref): the last frame and its features, as dsdtm_sparse_align_frames */
+    const dsdtm_frame* ref;
+    const float* ref_px_xy; const double* ref_bearing; const double* ref_p_world; const uint8_t* ref_initial;
+    int32_t n_ref_features;
+    const double* T_ref_w;            /* 12 */
+    const double* T_seed;             /* 12: the pose Tracking seeds the new frame with (:201) */
+    dsdtm_align_params align;
+    int32_t min_tracked;              /* Tracking: Run's count below this (20, :208) => Lost: search and refinement are skipped */
+    /* the local map (UpdateLocalMap) */
+    const dsdtm_frame* const* kf; int32_t n_kf;
+    const double* T_kf_w;             /* n_kf x 12 */
+    int32_t n_points;
+    const double* mp_world;           /* n_points x 3  MapPoint::Get_Pose()      */
+    const int32_t* mp_found;          /* n_points      MapPoint::Get_FoundNums() */
+    const uint8_t* mp_bad;            /* n_points      MapPoint::IsBad()         */
+    const int32_t* obs_offset;        /* n_points + 1 */
+    const int32_t* obs_kf; const float* obs_px; const int32_t* obs_level; const double* obs_bearing;
+    const uint8_t* mask; int32_t mask_stride;   /* Frame::mImgMask at the start of the search (255 = free), or NULL = all free */
+    int32_t cell_size;                /* Camera.CellSize      */
+    int32_t max_pyr_levels;           /* Camera.MaxPyraLevels (search level cap = this - 3, src/Feature_alignment.cpp:144) */
+    int32_t max_matches;              /* 200 (src/Feature_alignment.cpp:80) */
+    int32_t align2d_iters;            /* 10  (:152) */
+    dsdtm_pose_opt_params pose_opt;
+} dsdtm_track_desc;
+typedef struct dsdtm_track_match {
+    int32_t cell;                     /* grid cell of the candidate (index order = creation order of the features)   */
+    int32_t point;                    /* index into the caller's map-point list: Feature::Mpt; IncreaseFound() is the caller's to apply (:106) */
+    float px[2];                      /* Feature::mpx: the refined pixel as cv::Point2f (:108)                        */
+    int32_t level;                    /* Feature::mlevel: the search level                                            */
+} dsdtm_track_match;
+typedef struct dsdtm_track_result {
+    dsdtm_frame* frame;               /* the new frame, resident on the device: the caller's to destroy */
+    double T_run[12];                 /* the pose Run handed to Set_Pose (:57); the seed when Run returned 0 by the Min_fts rule */
+    int32_t n_tracked;                /* Run's return value */
+    int32_t lost;                     /* 1: n_tracked < min_tracked — nothing below was computed (n_matches 0, T_opt = T_run) */
+    dsdtm_align_stats stats;
+    int32_t n_in_grid;                /* points ReprojectPoint put into the grid */
+    int32_t n_matches;
+    int32_t replay_full_scan;         /* diagnostic: 1 = a candidate had more possible blockers than the replay keeps per thread and the
+                                         workgroup scanned all earlier candidates each round instead (same decisions, slower) */
+    int32_t reserved;
+    double T_opt[12];                 /* the pose PoseOptimization hands to Set_Pose (src/Optimizer.cpp:78) */
+    dsdtm_pose_opt_summary summary;
+} dsdtm_track_result;
+/* matches: max_matches entries; residual_norm: max_matches doubles (the norms of GetReprojectReidual in feature = match
+ * order, for the EraseFound walk of src/Optimizer.cpp:80-92, which stays the caller's). The mask discs of the matches
+ * (:111) are the caller's to paint into its Frame::mImgMask from the match list if it keeps one. */
+int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const dsdtm_track_desc* desc,
+                      dsdtm_track_result* result, dsdtm_track_match* matches, double* residual_norm);
+
 /* Enqueues the alignment of all pairs on `hip_stream` (a hipStream_t, NULL = default
  * stream). Asynchronous: results are valid after the stream is synchronised. */
 int dsdtm_sparse_align_batch_device(dsdtm_ctx* ctx, const dsdtm_batch_desc* batch,

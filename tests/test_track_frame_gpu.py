@@ -1,0 +1,207 @@
+"""dsdtm_track_frame — one tracked frame (reference src/Tracking.cpp:199-256) in ONE submission: new frame -> Run ->
+ReprojectPoint + Get_ClosetObs -> FindMatchDirect for every point -> the cell walk of SearchLocalPoints replayed ON THE DEVICE
+-> PoseOptimization. Held to
+  * the sequential CPU restatement of the search (tests/search_restatement.py) on the quirk worlds, and told apart from all eight
+    S1 / W3 mutants of it at the case and check tests/mutant_runs.py names;
+  * the four-call chain (Sprase_ImgAlign / LocalPointSearch / Optimizer on device-resident frames) bit for bit over a tracked
+    sequence, map side effects included;
+  * the C ABI's argument checks."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dsdtm_amd import capi, search, synth, tracking
+from dsdtm_amd.frame import Config, Frame
+from dsdtm_amd.optimizer import Optimizer
+from dsdtm_amd.sparse_align import Sprase_ImgAlign
+from tests import helpers as H
+from tests import mutant_runs as M
+from tests import quirk_fixtures as Q
+from tests.test_search_gpu import make_world
+
+pytestmark = pytest.mark.gpu
+
+
+def track_search(ctx, name, **kw):
+    """A named search world through dsdtm_track_frame with Run switched off (no reference features, min_tracked 0: the pose stays
+    the seed = the world's current pose): (match list, mask painted from it) in the shape of quirk_fixtures.search_restated."""
+    cam, kfs, cur, mps, cell = Q.search_world(name)
+    last = Frame(cam, cur.mvImg_Pyr, cur.Get_Pose())            # any resident frame of the geometry; it has no features: Run returns 0
+    r = tracking.track_frame(ctx, cam, cur.mvImg_Pyr[0], 5, last, cur.Get_Pose(), (5, 0, 8, 15), 0, kfs, mps, cell_size=cell,
+                             max_pyr_levels=5, **kw)
+    assert r["n_tracked"] == 0 and not r["lost"] and np.array_equal(r["T_run"], cur.Get_Pose())
+    mask = np.full((cam.height, cam.width), 255, np.uint8)
+    m = r["matches"]
+    for q in m["px"]:
+        search.fill_circle(mask, search.cvRound(float(q[0])), search.cvRound(float(q[1])), cell, 0)
+    r["frame"].close()
+    return [(int(m["cell"][k]), int(m["point"][k]), float(m["px"][k][0]), float(m["px"][k][1]), int(m["level"][k])) for k in range(len(m))], mask, r
+
+
+@pytest.fixture(scope="module")
+def track_outputs(gpu_ctx):
+    return {name: track_search(gpu_ctx, name) for name in Q.SEARCH_WORLDS}
+
+
+@pytest.mark.parametrize("name", list(Q.SEARCH_WORLDS))
+def test_device_replay_equals_the_sequential_restatement(track_outputs, name):
+    lst, mask, r = track_outputs[name]
+    want = Q.search_restated(name)
+    assert Q.search_first_difference(want, (lst, mask)) is None
+    assert len(lst) >= 150 and len(lst) <= 200 and r["n_in_grid"] > 500
+    # and the committed outputs of the four-call chain (tests/golden/quirks.npz)
+    g = np.load(H.golden_path("quirks.npz"))
+    assert np.array_equal(np.array(lst, np.float64).reshape(-1, 5), g[f"search_{name}_matches"])
+    assert np.array_equal(np.packbits(mask == 255, axis=1), g[f"search_{name}_mask_rows"])
+
+
+@pytest.mark.parametrize("mutant", [m for m in M.ALL_MUTANTS if M.domain(m) == "search"])
+def test_device_replay_disagrees_with_every_search_mutant(track_outputs, mutant):
+    case, check, quirk, cite = M.TABLE[mutant]
+    name = case.split(":")[1]
+    out = M.cpu_outputs(mutant, domains=("search",), search_worlds=[name])
+    lst, mask, _ = track_outputs[name]
+    got = Q.search_first_difference(out[case], (lst, mask))
+    assert got == check, f"{mutant} ({quirk}, {cite}): {got!r} for the device replay against this mutant, expected {check!r}"
+
+
+def test_search_part_equals_the_speculative_host_replay_and_honours_a_mask(gpu_ctx):
+    """The same world through LocalPointSearch (speculative batch + HOST replay) and through the device replay, with a caller's
+    mask that already blocks a band of the image (Frame::mImgMask at the start of the search): same matches, same final mask."""
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5)
+    cam, kfs, cur, mps = make_world(9, n_points=800)
+    mask0 = np.full((cam.height, cam.width), 255, np.uint8)
+    mask0[150:260, :] = 0
+    mask0[:, 400:470] = 7
+    mps_h = copy.deepcopy(mps)
+    s = search.LocalPointSearch(cam, ctx=gpu_ctx, resident_frames=True)
+    s.ResetGrid()
+    for mp in mps_h:
+        if not mp.IsBad():
+            s.ReprojectPoint(cur, mp)
+    mask_h = mask0.copy()
+    idx = {id(mp): i for i, mp in enumerate(mps_h)}
+    want = [(g[0], idx[id(g[1])], float(g[2][0]), float(g[2][1]), g[3]) for g in s.SearchLocalPoints(cur, kfs, mask_h)]
+    last = Frame(cam, cur.mvImg_Pyr, cur.Get_Pose())
+    r = tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], 5, last, cur.Get_Pose(), (5, 0, 8, 15), 0, kfs, mps, mask=mask0.copy())
+    m = r["matches"]
+    got = [(int(m["cell"][k]), int(m["point"][k]), float(m["px"][k][0]), float(m["px"][k][1]), int(m["level"][k])) for k in range(len(m))]
+    assert got == want and 40 < len(got) < 200
+    mask_d = mask0.copy()
+    for q in m["px"]:
+        search.fill_circle(mask_d, search.cvRound(float(q[0])), search.cvRound(float(q[1])), 25, 0)
+    assert np.array_equal(mask_d, mask_h)
+    r["frame"].close()
+
+
+def test_tracked_sequence_one_call_per_frame_equals_the_four_call_chain(gpu_ctx):
+    """Seven frames tracked twice on copies of one world: through the four synchronous calls per frame (Run, SearchLocalPoints'
+    speculative batch + host replay, PoseOptimization — tests/test_tracking_sequence_gpu.py holds that chain to the CPU oracle)
+    and through ONE dsdtm_track_frame per frame. Every pose, count, iteration, match, refined pixel, residual decision and
+    map side effect (found counts, bad flags) must be the same, bit for bit, frame after frame — frame k is the reference
+    frame of frame k + 1, so any difference would also compound."""
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    n_kf, n_frames = 2, 7
+    cam, kfs, _, mps = make_world(21, n_points=700, n_kf=n_kf)
+    rng = np.random.default_rng(77)
+    tex = synth.make_texture(cam.height, cam.width, 21)
+    for k, kf in enumerate(kfs):
+        mpts = [None] * kf.n_features
+        for mp in mps:
+            if k in mp.mObservations:
+                mpts[mp.mObservations[k]] = mp
+        kf.mvMapPoints = mpts
+        kf.p_world = np.array([m_.mPose if m_ is not None else np.zeros(3) for m_ in mpts])
+        kf.initial = np.array([1 if m_ is not None else 0 for m_ in mpts], np.uint8)
+    worlds = [copy.deepcopy((kfs, mps)) for _ in range(2)]
+    T0 = np.vstack([kfs[n_kf - 1].Get_Pose(), [0, 0, 0, 1]])
+    imgs, xi = [], np.zeros(6)
+    for k in range(n_frames):
+        xi = xi + np.concatenate([rng.uniform(-0.012, 0.012, 3), rng.uniform(-0.006, 0.006, 3)])
+        imgs.append(synth.warp_plane(tex, cam, synth.se3_exp(xi) @ T0, 2.0))
+
+    # ---- four calls per frame ----
+    a_kfs, a_mps = worlds[0]
+    al = Sprase_ImgAlign(5, 0, 8, ctx=gpu_ctx, resident_frames=True)
+    srch = search.LocalPointSearch(cam, ctx=gpu_ctx, resident_frames=True)
+    a_idx = {id(mp): i for i, mp in enumerate(a_mps)}
+    a_log, last = [], a_kfs[n_kf - 1]
+    for k in range(n_frames):
+        cur = Frame(cam, synth.build_pyramid(imgs[k], 5), last.Get_Pose())
+        n = al.Run(cur, last)
+        T_run = cur.Get_Pose().copy()
+        srch.ResetGrid()
+        for mp in a_mps:
+            if not mp.IsBad():
+                srch.ReprojectPoint(cur, mp)
+        matches = srch.SearchLocalPoints(cur, a_kfs)
+        sm = Optimizer.PoseOptimization(cur, ctx=gpu_ctx)
+        a_log.append(dict(n=n, T_run=T_run, iters=list(al.last_stats["iters"]), matches=[(m[0], a_idx[id(m[1])], m[3]) for m in matches],
+                          px=np.array([m[2] for m in matches]), T_opt=cur.Get_Pose().copy(), po=(sm["iterations"], sm["termination"]),
+                          found=[mp.mnFound for mp in a_mps], bad=[mp.mbBad for mp in a_mps], n_feat=cur.n_features))
+        last = cur
+
+    # ---- one call per frame ----
+    b_kfs, b_mps = worlds[1]
+    trk = tracking.Tracker(cam, ctx=gpu_ctx, max_level=5, min_level=0, max_iters=8, min_tracked=20)
+    b_idx = {id(mp): i for i, mp in enumerate(b_mps)}
+    last = b_kfs[n_kf - 1]
+    for k in range(n_frames):
+        cur, n, matches = trk.TrackFrame(imgs[k], last, b_kfs, b_mps)
+        r, a = trk.last_result, a_log[k]
+        assert n == a["n"] and list(r["stats"]["iters"]) == a["iters"], k
+        assert np.array_equal(r["T_run"], a["T_run"]), f"frame {k}: Run pose"
+        assert [(m[0], b_idx[id(m[1])], m[3]) for m in matches] == a["matches"], f"frame {k}: match set"
+        assert np.array_equal(np.array([m[2] for m in matches]), a["px"]), f"frame {k}: refined pixels"
+        assert np.array_equal(cur.Get_Pose(), a["T_opt"]), f"frame {k}: refined pose"
+        assert (r["summary"]["iterations"], r["summary"]["termination"]) == a["po"], k
+        assert [mp.mnFound for mp in b_mps] == a["found"] and [mp.mbBad for mp in b_mps] == a["bad"], f"frame {k}: map side effects"
+        assert cur.n_features == a["n_feat"] and len(matches) >= 60
+        last = cur
+    assert a_log[-1]["n"] >= 40
+
+
+def test_lost_frame_skips_search_and_refinement(gpu_ctx):
+    """Run's count below Tracking's threshold (src/Tracking.cpp:208: < 20 => Lost): nothing after Run is computed — no matches,
+    T_opt = T_run — and the new frame is still handed over."""
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    cam, kfs, cur, mps = make_world(11, n_points=300)
+    ref = kfs[0]
+    nf = 40
+    bb = ref.bearing[:nf]
+    last = Frame(cam, ref.mvImg_Pyr, ref.Get_Pose())
+    last.set_features(ref.px[:nf], bb, bb * (2.0 / bb[:, 2:3]), np.ones(nf, np.uint8))
+    r = tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], 5, last, last.Get_Pose(), (5, 0, 8, 15), 1000, kfs, mps)
+    assert r["lost"] and 0 < r["n_tracked"] <= nf and len(r["matches"]) == 0 and np.array_equal(r["T_opt"], r["T_run"])
+    r2 = tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], 5, last, last.Get_Pose(), (5, 0, 8, 15), 20, kfs, mps)
+    assert not r2["lost"] and r2["n_tracked"] == r["n_tracked"] and np.array_equal(r2["T_run"], r["T_run"]) and len(r2["matches"]) > 50
+    r["frame"].close(); r2["frame"].close()
+
+
+def test_argument_checks(gpu_ctx):
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5)
+    cam, kfs, cur, mps = make_world(11, n_points=50)
+    last = Frame(cam, cur.mvImg_Pyr, cur.Get_Pose())
+    flat = tracking.flatten_local_map(kfs, mps)
+    ok = lambda **kw: tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], 5, last, cur.Get_Pose(), (5, 0, 8, 15), 0, kfs, mps, **kw)
+    ok()["frame"].close()
+    for kw in (dict(cell_size=0), dict(cell_size=3), dict(max_matches=0), dict(max_matches=257), dict(max_pyr_levels=2), dict(max_pyr_levels=9)):
+        with pytest.raises(capi.DsdtmError) as e:
+            ok(**kw)
+        assert e.value.status == capi.ERR_INVALID, kw
+    bad = dict(flat)
+    bad["okf"] = flat["okf"].copy(); bad["okf"][0] = 99            # an observation that names a keyframe outside the list
+    with pytest.raises(capi.DsdtmError):
+        ok(flat=bad)
+    bad = dict(flat)
+    bad["off"] = flat["off"].copy(); bad["off"][3] = bad["off"][2] - 1
+    with pytest.raises(capi.DsdtmError):
+        ok(flat=bad)
+    # a reference frame of another geometry
+    small = Frame(synth.Camera.tum(320, 240), synth.build_pyramid(cur.mvImg_Pyr[1], 5), cur.Get_Pose())
+    with pytest.raises(capi.DsdtmError):
+        tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], 5, small, cur.Get_Pose(), (5, 0, 8, 15), 0, kfs, mps)
+    # and the context still works
+    ok()["frame"].close()
