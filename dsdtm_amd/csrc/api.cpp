@@ -91,6 +91,7 @@ struct dsdtm_ctx {
     int num_cus = 256;
     // Pyramid buffers of destroyed frames, kept for the next frame of the same size: a live tracker creates and destroys one
     // frame per image, and hipMalloc / hipFree (which waits for the whole device) cost more than the pyramid kernel.
+    hipEvent_t track_event = nullptr;     // dsdtm_track_frame: the local map has arrived (copied up on copy_stream[0] beside Run)
     struct PooledFrame { size_t pitch; uint8_t* d; };
     static constexpr size_t FRAME_POOL = 8;
     std::vector<PooledFrame> frame_pool;
@@ -295,6 +296,7 @@ void dsdtm_destroy(dsdtm_ctx* ctx) {
     if (ctx->copy_fence) (void)hipEventDestroy(ctx->copy_fence);
     if (ctx->h_flags) (void)hipHostFree((void*)ctx->h_flags);
     for (auto& pf : ctx->frame_pool) (void)hipFree(pf.d);
+    if (ctx->track_event) (void)hipEventDestroy(ctx->track_event);
     delete ctx;
 }
 
@@ -1865,9 +1867,9 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
         (d->n_points > 0 && (!d->mp_world || !d->mp_found || !d->mp_bad || !d->obs_offset))) {
         set_err(ctx, "track: bad local map (at most 4096 keyframes and 4096 map points per call)"); return DSDTM_ERR_INVALID;
     }
-    if (d->cell_size <= 0 || d->cell_size > 1024 || d->max_matches <= 0 || d->max_matches > 256 || d->align2d_iters < 0 ||
+    if (d->cell_size <= 0 || d->cell_size > 127 || d->max_matches <= 0 || d->max_matches > 256 || d->align2d_iters < 0 ||
         d->pose_opt.max_iterations < 0 || (d->mask && d->mask_stride < d->width)) {
-        set_err(ctx, "track: bad search parameters (cell_size 1..1024, max_matches 1..256)"); return DSDTM_ERR_INVALID;
+        set_err(ctx, "track: bad search parameters (cell_size 1..127, max_matches 1..256)"); return DSDTM_ERR_INVALID;
     }
     const int max_search_level = d->max_pyr_levels - 3;                                      // src/Feature_alignment.cpp:144
     if (max_search_level < 0 || max_search_level >= d->levels) { set_err(ctx, "track: max_pyr_levels - 3 outside the pyramid"); return DSDTM_ERR_INVALID; }
@@ -1915,17 +1917,21 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     // ---- the pinned block (host-mapped): inputs, then results ----
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
-    const size_t h_img = take(img), h_mask = take(d->mask ? img : 0);
+    const size_t h_img = take(img);
     const size_t h_bear = take(nf * 24), h_pw = take(nf * 24), h_tr = take(96), h_px = take(nf * 8), h_ini = take(nf);
     const size_t h_T = take(96), h_nt = take(4), h_st = take(sizeof(dsdtm_align_stats));
+    // (the local map and the mask: one contiguous range, copied to the device in one piece)
+    const size_t h_map = o;
+    const size_t h_mask = take(d->mask ? img : 0);
     const size_t h_mpw = take(Mz * 24), h_found = take(Mz * 4), h_bad = take(Mz), h_off = take((Mz + 1) * 4), h_okf = take(NZ * 4),
                  h_opx = take(NZ * 8), h_olv = take(NZ * 4), h_ob = take(NZ * 24), h_Tkf = take(NK * 96), h_kfp = take(NK * sizeof(void*));
-    const size_t h_cnt = take(16), h_match = take(MM * sizeof(dsdtm_track_match)), h_Topt = take(96),
+    const size_t map_bytes = o - h_map;
+    const size_t h_cnt = take(64), h_match = take(MM * sizeof(dsdtm_track_match)), h_Topt = take(96),
                  h_sm = take(sizeof(dsdtm_pose_opt_summary)), h_rn = take(MM * 8);
     const size_t h_total = o;
     // ---- device scratch ----
     o = 0;
-    const size_t g_T = take(96), g_Tkf = take(NK * 96), g_kfp = take(NK * sizeof(void*)), g_pw = take(Mz * 24), g_cell = take(Mz * 4),
+    const size_t g_map = take(map_bytes), g_T = take(96), g_pw = take(Mz * 24), g_cell = take(Mz * 4),
                  g_px0 = take(Mz * 16), g_px = take(Mz * 16), g_ck = take(Mz * 4), g_cf = take(Mz * 4), g_rp = take(Mz * 8),
                  g_rl = take(Mz * 4), g_rb = take(Mz * 24), g_ib = take(Mz), g_sl = take(Mz * 4), g_cv = take(Mz),
                  g_pob = take(MM * 24), g_pow = take(MM * 24), g_pol = take(MM * 4), g_pou = take(MM), g_pon = take(4);
@@ -1940,7 +1946,12 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
 
     dsdtm_frame* f = nullptr;
     if (int rc = frame_alloc(ctx, pl, &f)) return rc;
-    auto fail = [&](int rc) { (void)hipStreamSynchronize(stream); dsdtm_frame_destroy(ctx, f); return rc; };
+    auto fail = [&](int rc) {
+        if (ctx->copy_stream[0]) (void)hipStreamSynchronize(ctx->copy_stream[0]);
+        (void)hipStreamSynchronize(stream);
+        dsdtm_frame_destroy(ctx, f);
+        return rc;
+    };
 #define TRACK_TRY(call)                                                                                        \
     do {                                                                                                       \
         hipError_t e_ = (call);                                                                                \
@@ -1948,9 +1959,21 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     } while (0)
 
     // 1. the new frame: level 0 crosses the link, the pyramid is built on the device (src/Frame.cpp:35-41, :74-81)
-    if (d->stride == d->width) memcpy(h + h_img, d->image, img);
-    else for (int y = 0; y < d->height; ++y) memcpy(h + h_img + (size_t)y * d->width, d->image + (size_t)y * d->stride, (size_t)d->width);
-    TRACK_TRY(hipMemcpyAsync(f->d, h + h_img, img, hipMemcpyHostToDevice, stream));
+    // (an image the caller keeps in pinned memory — hipHostMalloc / hipHostRegister, e.g. the capture buffer — goes up straight
+    // from there; anything else is staged through the context's pinned block first: 15 us of host memcpy for 640x480)
+    bool pinned_image = false;
+    if (d->stride == d->width) {
+        hipPointerAttribute_t pa_;
+        if (hipPointerGetAttributes(&pa_, d->image) == hipSuccess) pinned_image = pa_.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();                  // (an ordinary host pointer: not an error)
+    }
+    if (pinned_image) {
+        TRACK_TRY(hipMemcpyAsync(f->d, d->image, img, hipMemcpyHostToDevice, stream));
+    } else {
+        if (d->stride == d->width) memcpy(h + h_img, d->image, img);
+        else for (int y = 0; y < d->height; ++y) memcpy(h + h_img + (size_t)y * d->width, d->image + (size_t)y * d->stride, (size_t)d->width);
+        TRACK_TRY(hipMemcpyAsync(f->d, h + h_img, img, hipMemcpyHostToDevice, stream));
+    }
     if (int rc = dsdtm_pyrdown_batch_device(ctx, f->d, f->pitch, 1, pl.levels, pl.w, pl.h, st, pl.off, stream)) return fail(rc);
 
     // 2. Run(cur, ref) — while the GPU copies and builds the pyramid, the host packs what Run reads
@@ -1993,14 +2016,16 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     TrackArgs t;
     memset(&t, 0, sizeof t);
     t.T_run = (const double*)(hd + h_T); t.n_tracked = (const int32_t*)(hd + h_nt); t.min_tracked = d->min_tracked;
-    t.T_kf_w = (const double*)(hd + h_Tkf); t.kf_ptrs = (const uint8_t* const*)(hd + h_kfp); t.n_kf = d->n_kf;
-    t.mp_world = (const double*)(hd + h_mpw); t.mp_found = (const int32_t*)(hd + h_found); t.mp_bad = hd + h_bad; t.n_points = M;
-    t.obs_offset = (const int32_t*)(hd + h_off); t.obs_kf = (const int32_t*)(hd + h_okf); t.obs_px = (const float*)(hd + h_opx);
-    t.obs_level = (const int32_t*)(hd + h_olv); t.obs_bearing = (const double*)(hd + h_ob);
-    t.mask = d->mask ? hd + h_mask : nullptr; t.mask_stride = d->width;
+    const uint8_t* gm = g + g_map - h_map;                // the device copy of the map range: same offsets as in the pinned block
+    t.T_kf_w = (const double*)(gm + h_Tkf); t.kf_ptrs = (const uint8_t* const*)(gm + h_kfp); t.n_kf = d->n_kf;
+    t.mp_world = (const double*)(gm + h_mpw); t.mp_found = (const int32_t*)(gm + h_found); t.mp_bad = gm + h_bad; t.n_points = M;
+    t.obs_offset = (const int32_t*)(gm + h_off); t.obs_kf = (const int32_t*)(gm + h_okf); t.obs_px = (const float*)(gm + h_opx);
+    t.obs_level = (const int32_t*)(gm + h_olv); t.obs_bearing = (const double*)(gm + h_ob);
+    t.mask = d->mask ? gm + h_mask : nullptr; t.mask_stride = d->width;
     t.fx = cam->fx; t.fy = cam->fy; t.cx = cam->cx; t.cy = cam->cy; t.width = cam->width; t.height = cam->height; t.levels = pl.levels;
     t.cell_size = d->cell_size; t.grid_cols = grid_cols; t.grid_rows = grid_rows; t.max_matches = d->max_matches;
-    t.d_T = (double*)(g + g_T); t.d_Tkf = (double*)(g + g_Tkf); t.d_kf_ptrs = (const uint8_t**)(g + g_kfp);
+    track_disc_half_widths(d->cell_size, t.disc_hw);
+    t.d_T = (double*)(g + g_T);
     t.pw = (double*)(g + g_pw); t.cell = (int32_t*)(g + g_cell); t.px0 = (double*)(g + g_px0); t.px = (double*)(g + g_px);
     t.cand_kf = (int32_t*)(g + g_ck); t.cand_frame = (int32_t*)(g + g_cf); t.ref_px = (float*)(g + g_rp); t.ref_level = (int32_t*)(g + g_rl);
     t.ref_bearing = (double*)(g + g_rb); t.init_blocked = g + g_ib; t.search_level = (int32_t*)(g + g_sl); t.converged = g + g_cv;
@@ -2011,7 +2036,7 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     WarpKernelArgs wa;
     memset(&wa, 0, sizeof wa);
     for (int l = 0; l < pl.levels; ++l) { wa.lv[l].w = pl.w[l]; wa.lv[l].h = pl.h[l]; wa.lv[l].stride = pl.w[l]; wa.lv[l].off = (uint32_t)pl.off[l]; }
-    wa.kf_ptrs = (const uint8_t* const*)t.d_kf_ptrs; wa.T_kf_w = t.d_Tkf; wa.T_cur_w_arr = t.d_T; wa.cand_frame = t.cand_frame;
+    wa.kf_ptrs = t.kf_ptrs; wa.T_kf_w = t.T_kf_w; wa.T_cur_w_arr = t.d_T; wa.cand_frame = t.cand_frame;
     wa.cand_kf = t.cand_kf; wa.ref_px = t.ref_px; wa.ref_level = t.ref_level; wa.ref_bearing = t.ref_bearing; wa.p_world = t.pw;
     wa.search_level = t.search_level; wa.m = M; wa.n_kf = d->n_kf; wa.max_search_level = max_search_level; wa.levels = pl.levels;
     wa.n_frames = 1; wa.fx = cam->fx; wa.fy = cam->fy; wa.cx = cam->cx; wa.cy = cam->cy; wa.no_xcd = options().fmd_no_xcd;
@@ -2034,21 +2059,27 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
         bool multi_cu = false;
         memcpy(h + h_T, d->T_seed, 96);                              // cur->Set_Pose(last->Get_Pose()) (src/Tracking.cpp:201)
         memset(h + h_nt, 0, 4); memset(h + h_st, 0, sizeof(dsdtm_align_stats));
-        memset(h + h_cnt, 0, 16); memset(h + h_sm, 0, sizeof(dsdtm_pose_opt_summary));
+        memset(h + h_cnt, 0, 64); memset(h + h_sm, 0, sizeof(dsdtm_pose_opt_summary));
         if (run) { if (int rc = launch_batch(ctx, &b, cam, &d->align, stream, mode, &multi_cu)) return fail(rc); }
-        pack_map();
+        if (!packed_map) {
+            // the local map does not depend on Run: it is packed and copied up on a second stream WHILE Run runs (its reads —
+            // observation -> keyframe pose -> reference feature — are dependent chains: from host-mapped memory they cost the
+            // reprojection kernel 16 us, from HBM 4)
+            pack_map();
+            if (!ctx->copy_stream[0]) TRACK_TRY(hipStreamCreateWithFlags(&ctx->copy_stream[0], hipStreamNonBlocking));
+            TRACK_TRY(hipMemcpyAsync(g + g_map, h + h_map, map_bytes, hipMemcpyHostToDevice, ctx->copy_stream[0]));
+            // (waited for by the HOST, while Run runs: a device-side event wait costs the stream a 6-us bubble in front of the
+            // reprojection kernel; the kernels behind Run are still enqueued long before Run ends)
+            TRACK_TRY(hipStreamSynchronize(ctx->copy_stream[0]));
+        }
         // 4. ReprojectPoint + Get_ClosetObs for every point; FindMatchDirect for every point that passed; the cell walk; the
         //    features of the matches; PoseOptimization on them — the instantiation picked on the device by the match count,
         //    as dsdtm_pose_optimization picks it on the host (same arithmetic, same bits as the four-call chain)
         TRACK_TRY(track_reproject_launch(t, stream));
         TRACK_TRY(match_launch(wa, aa, stream));
         TRACK_TRY(track_replay_launch(t, stream));
-        pa.force_variant = 1; pa.only_lo = -1; pa.only_hi = 64;
+        pa.force_variant = 3;                                      // one wave / four waves by the match count, chosen by the kernel
         TRACK_TRY(pose_opt_launch(pa, stream));
-        if (d->max_matches > 64) {
-            pa.force_variant = 2; pa.only_lo = 64; pa.only_hi = 256;
-            TRACK_TRY(pose_opt_launch(pa, stream));
-        }
         TRACK_TRY(hipStreamSynchronize(stream));
         if (!*h_flag) break;
         *h_flag = 0;
@@ -2072,7 +2103,8 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     const int32_t* cnt = (const int32_t*)(h + h_cnt);
     res->n_in_grid = cnt[0];
     res->n_matches = res->lost ? 0 : cnt[1];
-    res->replay_full_scan = cnt[2];
+    res->replay_full_scan = cnt[2] == 1 ? 1 : 0;
+    if (cnt[2] == 2 && !res->lost) { set_err(ctx, "track: the replay of the cell walk did not settle"); dsdtm_frame_destroy(ctx, f); res->frame = nullptr; return DSDTM_ERR_HIP; }
     if (res->lost) {
         memcpy(res->T_opt, res->T_run, 96);
     } else {

@@ -181,7 +181,8 @@ struct PoseOptArgs {
     // RANGE the live count falls in, as dsdtm_pose_optimization picks it on the host — every candidate instantiation is
     // enqueued and the ones whose range (only_lo, only_hi] does not hold the count return at once. 0, 0: no filter.
     int only_lo = 0, only_hi = 0;
-    int force_variant = 0;         // 0: by n_frames / max_features; 1: one wave per frame; 2: four waves, features in registers (<= 256)
+    int force_variant = 0;         // 0: by n_frames / max_features; 1: one wave per frame; 2: four waves, features in registers (<= 256);
+                                   // 3: 1 or 2 by the frame's live count on the device (dsdtm_track_frame)
 };
 hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream);
 
@@ -189,15 +190,16 @@ hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream);
 struct TrackArgs {
     // from Run (host-mapped: the alignment kernel of a single pair writes its results there)
     const double* T_run; const int32_t* n_tracked; int min_tracked;
-    // the local map as the caller flattened it (host-mapped, read once)
+    // the local map as the caller flattened it (device memory: copied up on a second stream while Run runs)
     const double* T_kf_w; const uint8_t* const* kf_ptrs; int n_kf;
     const double* mp_world; const int32_t* mp_found; const uint8_t* mp_bad; int n_points;
     const int32_t* obs_offset; const int32_t* obs_kf; const float* obs_px; const int32_t* obs_level; const double* obs_bearing;
     const uint8_t* mask; int mask_stride;
     float fx, fy, cx, cy; int width, height, levels;
     int cell_size, grid_cols, grid_rows, max_matches;
+    int8_t disc_hw[128];                              // cv::circle's row half-widths for radius cell_size (track_disc_half_widths)
     // device scratch: the columns the FindMatchDirect kernel reads / writes (candidate = map point)
-    double* d_T; double* d_Tkf; const uint8_t** d_kf_ptrs;
+    double* d_T;
     double* pw; int32_t* cell; double* px0; double* px; int32_t* cand_kf; int32_t* cand_frame; float* ref_px; int32_t* ref_level;
     double* ref_bearing; uint8_t* init_blocked; int32_t* search_level; uint8_t* converged;
     // outputs of the replay: the match list and counts (host-mapped), the pose refinement's feature columns (device)
@@ -208,6 +210,7 @@ struct TrackArgs {
 hipError_t track_reproject_launch(const TrackArgs& args, hipStream_t stream);
 hipError_t track_replay_launch(const TrackArgs& args, hipStream_t stream);
 size_t track_replay_lds_bytes(int n_points, int n_cells, int radius);
+void track_disc_half_widths(int radius, int8_t* hw);   // radius <= 127
 
 #ifdef DSDTM_DIAG
 // device self-test of the FP64 building blocks (wave reduction, LDLT, SE3); see selftest.hip (diagnostic build only)

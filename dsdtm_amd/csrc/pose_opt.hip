@@ -324,9 +324,10 @@ __device__ __forceinline__ double gradient_max_norm(const SE3d& Tx, const double
 }  // namespace
 
 constexpr int PO_WAVES_PER_EU = 2;
+// The whole refinement of one frame by NW waves (FPL > 0: a lane's features in registers). A device function so that ONE
+// kernel can carry two instantiations and pick by the frame's live feature count (pose_opt_auto_kernel below).
 template <int NW, int FPL>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? PO_WAVES_PER_EU : 1, NW == 1 ? PO_WAVES_PER_EU : 2)))
-void pose_opt_kernel(PoseOptArgs a) {
+__device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
     constexpr bool LAT = NW > 1;
     constexpr bool CACHED = FPL > 0;
     const int frame = blockIdx.x;
@@ -542,8 +543,30 @@ void pose_opt_kernel(PoseOptArgs a) {
     }
 }
 
+template <int NW, int FPL>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? PO_WAVES_PER_EU : 1, NW == 1 ? PO_WAVES_PER_EU : 2)))
+void pose_opt_kernel(PoseOptArgs a) { pose_opt_body<NW, FPL>(a); }
+
+// dsdtm_track_frame: ONE frame whose feature count (<= 256) is only known on the device. dsdtm_pose_optimization picks the
+// instantiation on the host — one wave up to 64 features, four waves with the features in registers up to 256 — and the
+// summation order, hence the last bits of the result, follows that choice; here the same choice is made by the kernel, so
+// that the one-call frame gives the four-call chain's pose bit for bit (a second launch that only reads the count and
+// returns cost 4.7 us of a 200-us frame).
+__global__ __launch_bounds__(256) void pose_opt_auto_kernel(PoseOptArgs a) {
+    const int n = a.n_features ? a.n_features[blockIdx.x] : a.max_features;
+    if (n <= 64) {
+        if (threadIdx.x >= 64) return;
+        pose_opt_body<1, 0>(a);
+    } else pose_opt_body<4, 1>(a);
+}
+
 hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream) {
     if (args.n_frames <= 0) return hipSuccess;
+    if (args.force_variant == 3) {          // by the device-side count (max_features <= 256)
+        if (args.max_features > 256) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(pose_opt_auto_kernel, dim3((unsigned)args.n_frames), dim3(256), 0, stream, args);
+        return hipGetLastError();
+    }
     // a few frames (the live tracker refines one): latency counts, four waves share a frame's features;
     // batches: one wave per frame, the solver part is not repeated
     const bool no_cache = options().po_no_cache != 0;                          // diagnostic (A/B)

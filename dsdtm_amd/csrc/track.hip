@@ -56,11 +56,7 @@ __global__ __launch_bounds__(256) void track_reproject_kernel(const TrackArgs a)
     if (tid < 12) s_T[tid] = a.T_run[tid];                         // (host-mapped: Run wrote it there)
     if (tid == 12) s_lost = (a.n_tracked[0] < a.min_tracked) ? 1 : 0;
     __syncthreads();
-    if (blockIdx.x == 0) {                                         // what the later kernels read from device memory
-        if (tid < 12) { a.d_T[tid] = s_T[tid]; a.T_opt[tid] = s_T[tid]; }
-        for (int i = tid; i < a.n_kf * 12; i += 256) a.d_Tkf[i] = a.T_kf_w[i];
-        for (int i = tid; i < a.n_kf; i += 256) a.d_kf_ptrs[i] = a.kf_ptrs[i];
-    }
+    if (blockIdx.x == 0 && tid < 12) { a.d_T[tid] = s_T[tid]; a.T_opt[tid] = s_T[tid]; }      // for the later kernels / the refinement's in-out pose
     const int i = blockIdx.x * 256 + tid;
     if (i >= a.n_points) return;
     const double P0 = a.mp_world[3 * (size_t)i], P1 = a.mp_world[3 * (size_t)i + 1], P2 = a.mp_world[3 * (size_t)i + 2];
@@ -129,18 +125,64 @@ __global__ __launch_bounds__(256) void track_reproject_kernel(const TrackArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int RP_THREADS = 1024;
-constexpr int RP_BL = 16;            // possible blockers a thread keeps per candidate
-constexpr int RP_CAP = 16;           // live candidates per disc-centre cell before the workgroup falls back to the full scan
 enum : uint8_t { ST_UNKNOWN = 0, ST_ACCEPTED = 1, ST_REJ_FREE = 2, ST_REJ_TAKEN = 3, ST_DEAD = 4 };
 
+__device__ __forceinline__ uint32_t pack_xy(int x, int y) { return (uint32_t)(uint16_t)(int16_t)x | ((uint32_t)(uint16_t)(int16_t)y << 16); }
+__device__ __forceinline__ int unpack_x(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
+__device__ __forceinline__ int unpack_y(uint32_t v) { return (int)(int16_t)(v >> 16); }
+
+// Dynamic LDS of the replay workgroup, carved by ONE function for the host (size) and the device (pointers)
+struct ReplayLds {
+    unsigned long long* tmp;   // [mpad] keys in bin order
+    float* c_pxf;        // [mpad * 2] by candidate: the refined pixel as float (Feature::mpx)
+    uint32_t* hist;      // [cells + 1] counts, then bin starts (exclusive scan); [cells] = n_in
+    uint32_t* cur;       // [cells] next free place of a bin
+    uint32_t* wsum;      // [RP_THREADS / 64]
+    uint32_t* c_p;       // [mpad] by candidate: rounded reprojected pixel (x | y << 16)
+    uint32_t* c_q;       // [mpad] by candidate: rounded refined pixel = disc centre
+    uint32_t* P;         // [mpad] by rank
+    uint32_t* Q;         // [mpad] by rank
+    uint16_t* idx;       // [mpad] candidate (map point) of rank r
+    uint16_t* rcell;     // [mpad] its grid cell
+    int16_t* hw;         // [radius + 1]
+    uint8_t* c_live;     // [mpad] by candidate
+    int8_t* c_sl;        // [mpad] by candidate: search level
+    uint8_t* state;      // [mpad] by rank
+    size_t bytes;
+};
+__host__ __device__ inline ReplayLds replay_layout(uint8_t* base, int n_points, int cells, int radius) {
+    const size_t mpad = ((size_t)n_points + 63) / 64 * 64;
+    ReplayLds L;
+    size_t o = 0;
+    auto take = [&](size_t bytes, size_t align) { o = (o + align - 1) / align * align; const size_t at = o; o += bytes; return base + at; };
+    L.tmp = (unsigned long long*)take(mpad * 8, 8);
+    L.c_pxf = (float*)take(mpad * 8, 8);
+    L.hist = (uint32_t*)take(((size_t)cells + 1) * 4, 4);
+    L.cur = (uint32_t*)take((size_t)cells * 4, 4);
+    L.wsum = (uint32_t*)take((RP_THREADS / 64) * 4, 4);
+    L.c_p = (uint32_t*)take(mpad * 4, 4);
+    L.c_q = (uint32_t*)take(mpad * 4, 4);
+    L.P = (uint32_t*)take(mpad * 4, 4);
+    L.Q = (uint32_t*)take(mpad * 4, 4);
+    L.idx = (uint16_t*)take(mpad * 2, 2);
+    L.rcell = (uint16_t*)take(mpad * 2, 2);
+    L.hw = (int16_t*)take(((size_t)radius + 1) * 2, 2);
+    L.c_live = take(mpad, 1);
+    L.c_sl = (int8_t*)take(mpad, 1);
+    L.state = take(mpad, 1);
+    L.bytes = (o + 15) / 16 * 16;
+    return L;
+}
+}  // namespace
+
 // half-widths of the rows cv::circle(img, c, r, v, -1) paints (OpenCV 2.4 drawing.cpp Circle(): midpoint circle filled by
-// horizontal spans; a row can be painted by several spans, the widest counts) — hw[|dy|], dy = -r..r
-__device__ void circle_half_widths(int radius, int16_t* hw) {
+// horizontal spans; a row can be painted by several spans, the widest counts) — hw[|dy|], dy = -r..r; radius <= 127
+void track_disc_half_widths(int radius, int8_t* hw) {
     for (int i = 0; i <= radius; ++i) hw[i] = -1;
     int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
     while (dx >= dy) {
-        if (hw[dy] < dx) hw[dy] = (int16_t)dx;
-        if (hw[dx] < dy) hw[dx] = (int16_t)dy;
+        if (hw[dy] < dx) hw[dy] = (int8_t)dx;
+        if (hw[dx] < dy) hw[dx] = (int8_t)dy;
         dy += 1;
         err += plus;
         plus += 2;
@@ -151,44 +193,6 @@ __device__ void circle_half_widths(int radius, int16_t* hw) {
     }
 }
 
-// Dynamic LDS of the replay workgroup, carved by ONE function for the host (size) and the device (pointers)
-struct ReplayLds {
-    uint32_t* hist;      // [cells + 1] counts, then bin starts (exclusive scan); [cells] = n_in
-    uint32_t* cur;       // [cells] next free place of a bin; later: live candidates per disc-centre cell
-    unsigned long long* tmp;   // [mpad] keys in bin order
-    uint16_t* idx;       // [mpad] candidate (map point) of rank r
-    uint16_t* rcell;     // [mpad] its grid cell
-    int16_t* px;  int16_t* py;    // [mpad] rounded reprojected pixel
-    int16_t* qx;  int16_t* qy;    // [mpad] rounded refined pixel (disc centre)
-    uint8_t* state;      // [mpad]
-    uint16_t* bucket;    // [cells * RP_CAP] ranks of the live candidates of a disc-centre cell
-    int16_t* hw;         // [radius + 1]
-    uint32_t* wsum;      // [RP_THREADS / 64]
-    size_t bytes;
-};
-__host__ __device__ inline ReplayLds replay_layout(uint8_t* base, int n_points, int cells, int radius) {
-    const size_t mpad = ((size_t)n_points + 63) / 64 * 64;
-    ReplayLds L;
-    size_t o = 0;
-    auto take = [&](size_t bytes, size_t align) { o = (o + align - 1) / align * align; const size_t at = o; o += bytes; return base + at; };
-    L.tmp = (unsigned long long*)take(mpad * 8, 8);
-    L.hist = (uint32_t*)take(((size_t)cells + 1) * 4, 4);
-    L.cur = (uint32_t*)take((size_t)cells * 4, 4);
-    L.wsum = (uint32_t*)take((RP_THREADS / 64) * 4, 4);
-    L.idx = (uint16_t*)take(mpad * 2, 2);
-    L.rcell = (uint16_t*)take(mpad * 2, 2);
-    L.px = (int16_t*)take(mpad * 2, 2);
-    L.py = (int16_t*)take(mpad * 2, 2);
-    L.qx = (int16_t*)take(mpad * 2, 2);
-    L.qy = (int16_t*)take(mpad * 2, 2);
-    L.bucket = (uint16_t*)take((size_t)cells * RP_CAP * 2, 2);
-    L.hw = (int16_t*)take(((size_t)radius + 1) * 2, 2);
-    L.state = take(mpad, 1);
-    L.bytes = (o + 15) / 16 * 16;
-    return L;
-}
-}  // namespace
-
 size_t track_replay_lds_bytes(int n_points, int n_cells, int radius) { return replay_layout(nullptr, n_points, n_cells, radius).bytes; }
 
 template <int EPT>
@@ -196,27 +200,47 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     __shared__ int s_overflow, s_n_in;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int M = a.n_points, cells = a.grid_cols * a.grid_rows, R = a.cell_size;
+    const int M = a.n_points, cells = a.grid_cols * a.grid_rows, R = a.cell_size, cols = a.grid_cols;
     const ReplayLds L = replay_layout(lds_raw, M, cells, R);
     for (int c = tid; c <= cells; c += RP_THREADS) L.hist[c] = 0u;
-    if (tid == 0) { s_overflow = 0; circle_half_widths(R, L.hw); }
+    if (tid == 0) s_overflow = 0;
+    if (tid <= R) L.hw[tid] = (int16_t)a.disc_hw[tid];          // cv::circle's row half-widths, tabulated by the host (track_disc_half_widths)
     __syncthreads();
 
-    // ---- 1. the grid's cell lists in walk order: counting sort by cell, inside a cell by (found descending, list index) ----
+    // ---- 1. everything a candidate brings, read ONCE and coalesced (thread = candidate); the grid's cell lists in walk order:
+    //         counting sort by cell, inside a cell by (found descending, list index) ----
     unsigned long long key[EPT];
     int kcell[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * RP_THREADS;                        // (coalesced reads of the candidate columns)
+        const int i = tid + e * RP_THREADS;
         kcell[e] = -1;
         key[e] = ~0ull;
         if (i < M) {
             const int c = a.cell[i];
+            const int f = a.mp_found[i];
+            // ReprojectCell: IsBad (:93), mask (:96), FindMatchDirect false (:101-104) — none of them has a side effect, so a
+            // candidate that fails any of them is simply not there
+            const bool ok = a.converged[i] != 0 && a.mp_bad[i] == 0 && a.init_blocked[i] == 0;
+            const double u0 = a.px0[2 * (size_t)i], v0 = a.px0[2 * (size_t)i + 1];
+            const double u1 = a.px[2 * (size_t)i], v1 = a.px[2 * (size_t)i + 1];
+            const int sl = a.search_level[i];
             if (c >= 0 && c < cells) {
                 kcell[e] = c;
-                const int f = a.mp_found[i];
                 key[e] = ((unsigned long long)(uint32_t)(0x7fffffffll - (long long)f) << 16) | (unsigned long long)i;   // :88,:123-126 (stable: list order)
                 atomicAdd(&L.hist[c], 1u);
+                const bool live = ok && fabs(u1) < 30000.0 && fabs(v1) < 30000.0;      // (a converged pixel sits in or near the image)
+                const int px_ = cv_round(u0), py_ = cv_round(v0);
+                const int qx_ = live ? cv_round(u1) : px_, qy_ = live ? cv_round(v1) : py_;
+                L.c_p[i] = pack_xy(px_, py_);
+                L.c_q[i] = pack_xy(qx_, qy_);
+                L.c_live[i] = live ? 1 : 0;
+                L.c_sl[i] = (int8_t)sl;
+                L.c_pxf[2 * i] = (float)u1; L.c_pxf[2 * i + 1] = (float)v1;            // Feature(px as cv::Point2f, :108)
+                // the neighbourhood scan below looks two cells around a candidate: valid while a disc centre (the refined pixel)
+                // stays within one cell size of its candidate's reprojected pixel — otherwise every earlier candidate is scanned
+                const int ddx = qx_ - px_, ddy = qy_ - py_;
+                if ((ddx < 0 ? -ddx : ddx) > R || (ddy < 0 ? -ddy : ddy) > R) s_overflow = 1;
             }
         }
     }
@@ -241,30 +265,8 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
     for (int e = 0; e < EPT; ++e)
         if (kcell[e] >= 0) L.tmp[atomicAdd(&L.cur[kcell[e]], 1u)] = ((unsigned long long)kcell[e] << 48) | key[e];
     __syncthreads();
-    // a key's place inside its cell = its rank among the cell's keys (cells hold a handful of candidates)
-    unsigned long long mine[EPT];
-    int place[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int q = tid + e * RP_THREADS;
-        place[e] = -1;
-        if (q < n_in) {
-            const unsigned long long kq = L.tmp[q];
-            const int c = (int)(kq >> 48);
-            const uint32_t s0 = L.hist[c], e0 = L.hist[c + 1];
-            uint32_t rank = 0;
-            for (uint32_t r = s0; r < e0; ++r) rank += L.tmp[r] < kq ? 1u : 0u;
-            mine[e] = kq; place[e] = (int)(s0 + rank);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < EPT; ++e)
-        if (place[e] >= 0) { L.idx[place[e]] = (uint16_t)(mine[e] & 0xffffu); L.rcell[place[e]] = (uint16_t)(mine[e] >> 48); }
-    __syncthreads();
-
-    // ---- 2. per rank: live? (converged, not bad, not masked at the start); reprojected and refined pixels, rounded ----
-    // thread t owns ranks t * EPT .. t * EPT + EPT - 1 from here on (contiguous: the final prefix count is a plain scan)
+    // a key's place inside its cell = its rank among the cell's keys (cells hold a handful of candidates); thread t owns
+    // places t * EPT .. t * EPT + EPT - 1 (contiguous: the final prefix count is a plain scan)
     int my_idx[EPT];
     bool live[EPT];
 #pragma unroll
@@ -272,109 +274,177 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
         const int r = tid * EPT + e;
         live[e] = false; my_idx[e] = 0;
         if (r < n_in) {
-            const int i = L.idx[r];
+            // which key lands on place r? the one of r's cell with (r - start) smaller keys: every thread selects for its place
+            // (the cell of place r = the cell of the key that the scatter put there: places of a cell are a contiguous range)
+            const int c = (int)(L.tmp[r] >> 48);
+            const uint32_t s0 = L.hist[c], e0 = L.hist[c + 1], want = (uint32_t)r - s0;
+            unsigned long long sel = L.tmp[r];
+            if (e0 - s0 > 1u) {
+                for (uint32_t q = s0; q < e0; ++q) {
+                    const unsigned long long kq = L.tmp[q];
+                    uint32_t rank = 0;
+                    for (uint32_t j = s0; j < e0; ++j) rank += L.tmp[j] < kq ? 1u : 0u;
+                    if (rank == want) sel = kq;
+                }
+            }
+            const int i = (int)(sel & 0xffffu);
             my_idx[e] = i;
-            // ReprojectCell: IsBad (:93), mask (:96), FindMatchDirect false (:101-104) — none of them has a side effect, so a
-            // candidate that fails any of them is simply not there
-            const bool ok = a.converged[i] != 0 && a.mp_bad[i] == 0 && a.init_blocked[i] == 0;
-            const double u0 = a.px0[2 * (size_t)i], v0 = a.px0[2 * (size_t)i + 1];
-            const double u1 = a.px[2 * (size_t)i], v1 = a.px[2 * (size_t)i + 1];
-            const bool fin = fabs(u1) < 30000.0 && fabs(v1) < 30000.0;       // (a converged pixel sits inside the image)
-            live[e] = ok && fin;
-            L.px[r] = (int16_t)cv_round(u0); L.py[r] = (int16_t)cv_round(v0);
-            L.qx[r] = live[e] ? (int16_t)cv_round(u1) : (int16_t)0; L.qy[r] = live[e] ? (int16_t)cv_round(v1) : (int16_t)0;
+            live[e] = L.c_live[i] != 0;
+            L.idx[r] = (uint16_t)i; L.rcell[r] = (uint16_t)c;
+            L.P[r] = L.c_p[i]; L.Q[r] = live[e] ? L.c_q[i] : 0x7fff7fffu;       // (a dead candidate's disc is nowhere: no state test in the scans)
             L.state[r] = live[e] ? ST_UNKNOWN : ST_DEAD;
         }
     }
     __syncthreads();
-    // ---- 3. possible blockers: the previous live candidate of the same cell; live earlier candidates whose disc covers me ----
-    // live candidates binned by the grid cell of their disc centre (dword counters in L.cur, free after the sort)
-    for (int c = tid; c < cells; c += RP_THREADS) L.cur[c] = 0u;
-    __syncthreads();
+    const bool full_scan = s_overflow != 0;
+    // ---- 2. possible blockers of a live candidate: the previous live candidate of its cell (pred), and the live EARLIER
+    //         candidates whose disc covers its reprojected pixel — they sit at most two cells away, i.e. (ranks are in cell
+    //         order) in three contiguous rank ranges: cells cx-2..cx+2 of the rows cy-2, cy-1 and cy, cut at the candidate itself.
+    //         One 64-bit mask per range; a range of more than 64 ranks switches the workgroup to the full scan ----
+    int pred[EPT];
+    uint32_t lo[EPT][3];
+    unsigned long long bm[EPT][3];
+    int ovf = 0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int r = tid * EPT + e;
-        if (r < n_in && live[e]) {
-            const int qc = min(max((int)L.qy[r] / R, 0), a.grid_rows - 1) * a.grid_cols + min(max((int)L.qx[r] / R, 0), a.grid_cols - 1);
-            const uint32_t slot = atomicAdd(&L.cur[qc], 1u);
-            if (slot < (uint32_t)RP_CAP) L.bucket[qc * RP_CAP + slot] = (uint16_t)r;
-            else s_overflow = 1;
-        }
-    }
-    __syncthreads();
-    uint16_t blk[EPT][RP_BL];
-    int nblk[EPT], pred[EPT];   // pred: the nearest earlier LIVE candidate of the same cell, or -1
+        pred[e] = -1;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int r = tid * EPT + e;
-        nblk[e] = 0; pred[e] = -1;
+        for (int k = 0; k < 3; ++k) { lo[e][k] = 0; bm[e][k] = 0ull; }
         if (r < n_in && live[e]) {
             const int c = L.rcell[r];
             for (int rr = r - 1; rr >= (int)L.hist[c]; --rr)
                 if (L.state[rr] == ST_UNKNOWN) { pred[e] = rr; break; }
-            const int x = L.px[r], y = L.py[r];
-            const int cx = x / R, cy = y / R;                       // (the reprojected pixel is inside the image)
-            for (int ny = max(cy - 1, 0); ny <= min(cy + 1, a.grid_rows - 1); ++ny)
-                for (int nx = max(cx - 1, 0); nx <= min(cx + 1, a.grid_cols - 1); ++nx) {
-                    const int qc = ny * a.grid_cols + nx;
-                    const int n = min((int)L.cur[qc], RP_CAP);
-                    for (int s = 0; s < n; ++s) {
-                        const int rr = L.bucket[qc * RP_CAP + s];
-                        if (rr >= r) continue;
-                        const int dy = y - (int)L.qy[rr], ady = dy < 0 ? -dy : dy;
-                        if (ady > R) continue;
-                        const int dx = x - (int)L.qx[rr], adx = dx < 0 ? -dx : dx;
-                        if (adx > (int)L.hw[ady]) continue;
-                        if (nblk[e] < RP_BL) {
+            if (!full_scan) {
+                const int x = unpack_x(L.P[r]), y = unpack_y(L.P[r]);
+                const int cx = c % cols, cy = c / cols;
+                const int x0 = max(cx - 2, 0), x1 = min(cx + 2, cols - 1);
 #pragma unroll
-                            for (int j = 0; j < RP_BL; ++j) if (j == nblk[e]) blk[e][j] = (uint16_t)rr;
-                            nblk[e]++;
-                        } else s_overflow = 1;
+                for (int k = 0; k < 3; ++k) {
+                    const int row = cy - 2 + k;
+                    if (row < 0) continue;
+                    const uint32_t l0 = L.hist[row * cols + x0];
+                    uint32_t h0 = L.hist[row * cols + x1 + 1];
+                    if (h0 > (uint32_t)r) h0 = (uint32_t)r;
+                    if (h0 <= l0) continue;
+                    lo[e][k] = l0;
+                    if (h0 - l0 > 64u) { ovf = 1; continue; }
+                    unsigned long long m = 0ull;
+                    for (uint32_t rr = l0; rr < h0; rr += 4) {            // four at a time: their loads do not wait for each other
+                        uint32_t q[4];
+                        int ady[4];
+                        int16_t hwv[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) q[j] = L.Q[min(rr + (uint32_t)j, h0 - 1u)];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const int dy = y - unpack_y(q[j]); ady[j] = dy < 0 ? -dy : dy; hwv[j] = L.hw[min(ady[j], R)]; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int dx = x - unpack_x(q[j]), adx = dx < 0 ? -dx : dx;
+                            if (rr + (uint32_t)j < h0 && ady[j] <= R && adx <= (int)hwv[j]) m |= 1ull << (rr + (uint32_t)j - l0);
+                        }
                     }
+                    bm[e][k] = m;
                 }
-        }
-    }
-    __syncthreads();
-    const bool full_scan = s_overflow != 0;
-    // ---- 4. the recurrence, evaluated as its inputs become known ----
-    for (;;) {
-        int changed = 0;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int r = tid * EPT + e;
-            if (!(r < n_in && live[e]) || L.state[r] != ST_UNKNOWN) continue;
-            const uint8_t sp = pred[e] < 0 ? (uint8_t)ST_REJ_FREE : L.state[pred[e]];
-            if (sp == ST_UNKNOWN) continue;
-            uint8_t ns;
-            if (sp == ST_ACCEPTED || sp == ST_REJ_TAKEN) ns = ST_REJ_TAKEN;          // :115 the cell already has its match
-            else {
-                bool any_acc = false, any_unk = false;
-                if (!full_scan) {
-#pragma unroll
-                    for (int j = 0; j < RP_BL; ++j)
-                        if (j < nblk[e]) { const uint8_t s = L.state[blk[e][j]]; any_acc |= s == ST_ACCEPTED; any_unk |= s == ST_UNKNOWN; }
-                } else {
-                    const int x = L.px[r], y = L.py[r];
-                    for (int rr = 0; rr < r; ++rr) {
-                        const uint8_t s = L.state[rr];
-                        if (s != ST_ACCEPTED && s != ST_UNKNOWN) continue;
-                        const int dy = y - (int)L.qy[rr], ady = dy < 0 ? -dy : dy;
-                        if (ady > R) continue;
-                        const int dx = x - (int)L.qx[rr], adx = dx < 0 ? -dx : dx;
-                        if (adx > (int)L.hw[ady]) continue;
-                        any_acc |= s == ST_ACCEPTED; any_unk |= s == ST_UNKNOWN;
-                    }
-                }
-                if (any_acc) ns = ST_REJ_FREE;                                       // :96 masked by an earlier match's disc (:111)
-                else if (any_unk) continue;
-                else ns = ST_ACCEPTED;
             }
-            L.state[r] = ns;
-            changed = 1;
         }
-        if (!__syncthreads_or(changed)) break;
     }
-    // ---- 5. the matches in walk order, at most max_matches (:80); the features they become ----
+    const bool scan_all = __syncthreads_or(ovf) != 0 || full_scan;
+    // up to RP_BL blockers as a register list (polled in ONE batch of independent LDS reads per step); a candidate with more keeps its masks
+    constexpr int RP_BL = 8;
+    uint16_t bl[EPT][RP_BL];
+    int nbl[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        nbl[e] = 0;
+#pragma unroll
+        for (int j = 0; j < RP_BL; ++j) bl[e][j] = 0;
+        const int total_bits = __popcll(bm[e][0]) + __popcll(bm[e][1]) + __popcll(bm[e][2]);
+        if (total_bits <= RP_BL) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                unsigned long long mm = bm[e][k];
+                while (mm) {
+                    const int j = __builtin_ctzll(mm);
+                    mm &= mm - 1ull;
+                    const uint16_t v = (uint16_t)(lo[e][k] + (uint32_t)j);
+#pragma unroll
+                    for (int q = 0; q < RP_BL; ++q) if (q == nbl[e]) bl[e][q] = v;
+                    nbl[e]++;
+                }
+                bm[e][k] = 0ull;
+            }
+        } else nbl[e] = -1;                                        // masks
+    }
+    // ---- 3. the recurrence, evaluated as its inputs become known ----
+    // No barrier per round: a decision is one byte in LDS, visible to every wave of the workgroup as soon as it is written, and a
+    // candidate only ever waits for candidates of LOWER rank — the lowest undecided one can always decide, so every wave's loop
+    // ends (the iteration bound is a safety net that reports instead of hanging). The chains run along and across the cell rows:
+    // tens of dependent steps, each one batch of LDS reads.
+    int stuck = 0;
+    {
+        volatile uint8_t* const vs = L.state;
+        bool undecided[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { const int r = tid * EPT + e; undecided[e] = r < n_in && live[e]; }
+        unsigned spins = 0;
+        for (;;) {
+            bool left = false;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                if (!undecided[e]) continue;
+                const int r = tid * EPT + e;
+                // one batch: the predecessor's state and the listed blockers' (a dead rank 0.. read for unused slots is harmless)
+                const uint8_t sp = pred[e] < 0 ? (uint8_t)ST_REJ_FREE : vs[pred[e]];
+                uint8_t sb[RP_BL];
+#pragma unroll
+                for (int j = 0; j < RP_BL; ++j) sb[j] = vs[bl[e][j]];
+                uint8_t ns = ST_UNKNOWN;
+                if (sp == ST_ACCEPTED || sp == ST_REJ_TAKEN) ns = ST_REJ_TAKEN;      // :115 the cell already has its match
+                else if (sp != ST_UNKNOWN) {
+                    bool any_acc = false, any_unk = false;
+                    if (scan_all) {
+                        const int x = unpack_x(L.P[r]), y = unpack_y(L.P[r]);
+                        for (int rr = 0; rr < r; ++rr) {
+                            const uint8_t st_ = vs[rr];
+                            if (st_ != ST_ACCEPTED && st_ != ST_UNKNOWN) continue;
+                            const uint32_t q = L.Q[rr];
+                            const int dy = y - unpack_y(q), ady = dy < 0 ? -dy : dy;
+                            if (ady > R) continue;
+                            const int dx = x - unpack_x(q), adx = dx < 0 ? -dx : dx;
+                            if (adx > (int)L.hw[ady]) continue;
+                            any_acc |= st_ == ST_ACCEPTED; any_unk |= st_ == ST_UNKNOWN;
+                        }
+                    } else if (nbl[e] >= 0) {
+#pragma unroll
+                        for (int j = 0; j < RP_BL; ++j)
+                            if (j < nbl[e]) { any_acc |= sb[j] == ST_ACCEPTED; any_unk |= sb[j] == ST_UNKNOWN; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            unsigned long long mm = bm[e][k];
+                            while (mm) {
+                                const int j = __builtin_ctzll(mm);
+                                mm &= mm - 1ull;
+                                const uint8_t st_ = vs[lo[e][k] + j];
+                                any_acc |= st_ == ST_ACCEPTED;
+                                if (st_ != ST_UNKNOWN) bm[e][k] &= ~(1ull << j);     // decided: not polled again
+                            }
+                            any_unk |= bm[e][k] != 0ull;
+                        }
+                    }
+                    if (any_acc) ns = ST_REJ_FREE;                                   // :96 masked by an earlier match's disc (:111)
+                    else if (!any_unk) ns = ST_ACCEPTED;
+                }
+                if (ns != ST_UNKNOWN) { vs[r] = ns; undecided[e] = false; }
+                else left = true;
+            }
+            if (!__ballot(left)) break;
+            if (++spins > (1u << 16)) { stuck = 1; break; }                          // (never: see above)
+        }
+    }
+    const bool unsettled = __syncthreads_or(stuck) != 0;
+    // ---- 4. the matches in walk order, at most max_matches (:80); the features they become ----
     uint32_t cnt = 0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) { const int r = tid * EPT + e; if (r < n_in && L.state[r] == ST_ACCEPTED) cnt++; }
@@ -391,8 +461,8 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
         if (!(r < n_in && L.state[r] == ST_ACCEPTED)) continue;
         if (k < (uint32_t)a.max_matches) {
             const int i = my_idx[e];
-            const float fx_ = (float)a.px[2 * (size_t)i], fy_ = (float)a.px[2 * (size_t)i + 1];   // Feature(px as cv::Point2f, :108)
-            const int lvl = a.search_level[i];
+            const float fx_ = L.c_pxf[2 * i], fy_ = L.c_pxf[2 * i + 1];
+            const int lvl = (int)L.c_sl[i];
             dsdtm_track_match mo;
             mo.cell = (int)L.rcell[r]; mo.point = i; mo.px[0] = fx_; mo.px[1] = fy_; mo.level = lvl;
             a.matches[k] = mo;
@@ -410,7 +480,7 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
     if (tid == 0) {
         const int nm = (int)(total < (uint32_t)a.max_matches ? total : (uint32_t)a.max_matches);
         a.po_n[0] = nm;
-        a.counts[0] = n_in; a.counts[1] = nm; a.counts[2] = full_scan ? 1 : 0;
+        a.counts[0] = n_in; a.counts[1] = nm; a.counts[2] = unsettled ? 2 : (scan_all ? 1 : 0);   // 0 masks, 1 full scan, 2 did not settle (a bug)
     }
 }
 

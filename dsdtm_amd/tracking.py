@@ -47,48 +47,70 @@ def flatten_local_map(keyframes, map_points):
     return dict(pw=pw, found=found, bad=bad, off=off, okf=okf, opx=opx, olv=olv, ob=ob)
 
 
-def track_frame(ctx: capi.Context, cam, image, levels, last: Frame, T_seed, align, min_tracked, keyframes, map_points,
-                mask=None, cell_size=None, max_pyr_levels=None, max_matches=200, align2d_iters=10, po_iterations=100, flat=None):
+class TrackCall:
+    """One prepared dsdtm_track_frame call: the descriptor and every array it points at are built once (`__init__`), `run()`
+    is the library call alone — what a C++ Tracking pays per frame (bench_tracking.py times it; a frame's release is the
+    caller's: result["frame"].close())."""
+
+    def __init__(self, ctx: capi.Context, cam, image, levels, last: Frame, T_seed, align, min_tracked, keyframes, map_points,
+                 mask=None, cell_size=None, max_pyr_levels=None, max_matches=200, align2d_iters=10, po_iterations=100, flat=None):
+        self.ctx = ctx
+        image = np.ascontiguousarray(image, np.uint8)
+        cell_size = int(Config.Get("Camera.CellSize") if cell_size is None else cell_size)
+        max_pyr_levels = int(Config.Get("Camera.MaxPyraLevels") if max_pyr_levels is None else max_pyr_levels)
+        fm = flat if flat is not None else flatten_local_map(keyframes, map_points)
+        d = capi.TrackDesc()
+        d.image, d.width, d.height, d.stride, d.levels = image.ctypes.data, image.shape[1], image.shape[0], image.strides[0], int(levels)
+        dref = capi.device_frame_of(ctx, last)
+        d.ref = dref.handle
+        px = np.ascontiguousarray(last.px, np.float32)
+        bear, pw, ini = np.ascontiguousarray(last.bearing), np.ascontiguousarray(last.p_world), np.ascontiguousarray(last.initial, np.uint8)
+        d.ref_px_xy, d.ref_bearing, d.ref_p_world, d.ref_initial = px.ctypes.data, bear.ctypes.data, pw.ctypes.data, ini.ctypes.data
+        d.n_ref_features = last.n_features
+        Tr = np.ascontiguousarray(last.Get_Pose(), np.float64).reshape(12).copy()
+        Ts = np.ascontiguousarray(T_seed, np.float64).reshape(12).copy()
+        d.T_ref_w, d.T_seed = Tr.ctypes.data, Ts.ctypes.data
+        d.align = capi.AlignParams(*[int(v) for v in align])
+        d.min_tracked = int(min_tracked)
+        kfd = [capi.device_frame_of(ctx, k) for k in keyframes]
+        kfh = (C.c_void_p * max(1, len(keyframes)))(*[k.handle for k in kfd])
+        Tk = np.ascontiguousarray(np.array([k.Get_Pose() for k in keyframes], np.float64).reshape(len(keyframes), 12))
+        d.kf, d.n_kf, d.T_kf_w = C.cast(kfh, C.c_void_p), len(keyframes), Tk.ctypes.data
+        d.n_points = len(fm["found"])
+        d.mp_world, d.mp_found, d.mp_bad, d.obs_offset = fm["pw"].ctypes.data, fm["found"].ctypes.data, fm["bad"].ctypes.data, fm["off"].ctypes.data
+        d.obs_kf, d.obs_px, d.obs_level, d.obs_bearing = fm["okf"].ctypes.data, fm["opx"].ctypes.data, fm["olv"].ctypes.data, fm["ob"].ctypes.data
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            d.mask, d.mask_stride = mask.ctypes.data, mask.strides[0]
+        d.cell_size, d.max_pyr_levels, d.max_matches, d.align2d_iters = cell_size, max_pyr_levels, int(max_matches), int(align2d_iters)
+        d.pose_opt = capi.PoseOptParams(int(po_iterations), 0)
+        self.desc = d
+        self.res = capi.TrackResult()
+        self.matches = np.zeros(max(1, int(max_matches)), capi.TRACK_MATCH_DTYPE)
+        self.rn = np.zeros(max(1, int(max_matches)))
+        self.cs = capi.camera_struct(cam)
+        self._keep = (image, dref, px, bear, pw, ini, Tr, Ts, kfd, kfh, Tk, fm, mask)
+
+    def run_raw(self) -> int:
+        """The library call alone; returns its status (the new frame's handle is in self.res.frame)."""
+        return self.ctx.lib.dsdtm_track_frame(self.ctx.handle, C.byref(self.cs), C.byref(self.desc), C.byref(self.res),
+                                              self.matches.ctypes.data, self.rn.ctypes.data)
+
+    def run(self) -> dict:
+        self.ctx.check(self.run_raw())
+        res = self.res
+        sm = res.summary.as_dict()
+        return dict(frame=capi.DeviceFrame(self.ctx, C.c_void_p(res.frame)), T_run=np.array(list(res.T_run)).reshape(3, 4),
+                    n_tracked=int(res.n_tracked), lost=bool(res.lost), stats=res.stats.as_dict(), n_in_grid=int(res.n_in_grid),
+                    replay_full_scan=bool(res.replay_full_scan), matches=self.matches[:res.n_matches].copy(),
+                    T_opt=np.array(list(res.T_opt)).reshape(3, 4), summary=sm, residual_norm=self.rn[:sm["n_residual_blocks"]].copy())
+
+
+def track_frame(ctx: capi.Context, cam, image, levels, last: Frame, T_seed, align, min_tracked, keyframes, map_points, **kw):
     """dsdtm_track_frame. `last` and the keyframes are Frames whose pyramids are (made) resident on the device; `align` =
     (max_level, min_level, max_iters, min_fts). Returns a dict: frame (capi.DeviceFrame of the new image), T_run, n_tracked, lost,
     stats, n_in_grid, matches (structured array: cell, point, px, level), T_opt, summary, residual_norm."""
-    image = np.ascontiguousarray(image, np.uint8)
-    cell_size = int(Config.Get("Camera.CellSize") if cell_size is None else cell_size)
-    max_pyr_levels = int(Config.Get("Camera.MaxPyraLevels") if max_pyr_levels is None else max_pyr_levels)
-    fm = flat if flat is not None else flatten_local_map(keyframes, map_points)
-    d = capi.TrackDesc()
-    d.image, d.width, d.height, d.stride, d.levels = image.ctypes.data, image.shape[1], image.shape[0], image.strides[0], int(levels)
-    dref = capi.device_frame_of(ctx, last)
-    d.ref = dref.handle
-    px = np.ascontiguousarray(last.px, np.float32)
-    bear, pw, ini = np.ascontiguousarray(last.bearing), np.ascontiguousarray(last.p_world), np.ascontiguousarray(last.initial, np.uint8)
-    d.ref_px_xy, d.ref_bearing, d.ref_p_world, d.ref_initial = px.ctypes.data, bear.ctypes.data, pw.ctypes.data, ini.ctypes.data
-    d.n_ref_features = last.n_features
-    Tr = np.ascontiguousarray(last.Get_Pose(), np.float64).reshape(12).copy()
-    Ts = np.ascontiguousarray(T_seed, np.float64).reshape(12).copy()
-    d.T_ref_w, d.T_seed = Tr.ctypes.data, Ts.ctypes.data
-    d.align = capi.AlignParams(*[int(v) for v in align])
-    d.min_tracked = int(min_tracked)
-    kfh = (C.c_void_p * max(1, len(keyframes)))(*[capi.device_frame_of(ctx, k).handle for k in keyframes])
-    Tk = np.ascontiguousarray(np.array([k.Get_Pose() for k in keyframes], np.float64).reshape(len(keyframes), 12))
-    d.kf, d.n_kf, d.T_kf_w = C.cast(kfh, C.c_void_p), len(keyframes), Tk.ctypes.data
-    d.n_points = len(fm["found"])
-    d.mp_world, d.mp_found, d.mp_bad, d.obs_offset = fm["pw"].ctypes.data, fm["found"].ctypes.data, fm["bad"].ctypes.data, fm["off"].ctypes.data
-    d.obs_kf, d.obs_px, d.obs_level, d.obs_bearing = fm["okf"].ctypes.data, fm["opx"].ctypes.data, fm["olv"].ctypes.data, fm["ob"].ctypes.data
-    if mask is not None:
-        mask = np.ascontiguousarray(mask, np.uint8)
-        d.mask, d.mask_stride = mask.ctypes.data, mask.strides[0]
-    d.cell_size, d.max_pyr_levels, d.max_matches, d.align2d_iters = cell_size, max_pyr_levels, int(max_matches), int(align2d_iters)
-    d.pose_opt = capi.PoseOptParams(int(po_iterations), 0)
-    res = capi.TrackResult()
-    matches = np.zeros(int(max_matches), capi.TRACK_MATCH_DTYPE)
-    rn = np.zeros(int(max_matches))
-    cs = capi.camera_struct(cam)
-    ctx.check(ctx.lib.dsdtm_track_frame(ctx.handle, C.byref(cs), C.byref(d), C.byref(res), matches.ctypes.data, rn.ctypes.data))
-    sm = res.summary.as_dict()
-    return dict(frame=capi.DeviceFrame(ctx, C.c_void_p(res.frame)), T_run=np.array(list(res.T_run)).reshape(3, 4), n_tracked=int(res.n_tracked),
-                lost=bool(res.lost), stats=res.stats.as_dict(), n_in_grid=int(res.n_in_grid), replay_full_scan=bool(res.replay_full_scan), matches=matches[:res.n_matches].copy(),
-                T_opt=np.array(list(res.T_opt)).reshape(3, 4), summary=sm, residual_norm=rn[:sm["n_residual_blocks"]].copy())
+    return TrackCall(ctx, cam, image, levels, last, T_seed, align, min_tracked, keyframes, map_points, **kw).run()
 
 
 class Tracker:

@@ -354,7 +354,8 @@ int dsdtm_pose_optimization_batch_device(dsdtm_ctx* ctx, int n_frames, int max_f
  * Observations are flattened by the caller: point i has observations obs_offset[i] .. obs_offset[i+1]-1 in the iteration
  * order of its mObservations map; observation j names keyframe obs_kf[j] (index into kf[]) and carries the observing
  * feature's mpx (obs_px), mlevel (obs_level) and mNormal (obs_bearing).
- * Limits: n_points <= 4096, grid cells <= 4096, max_matches <= 256, n_kf <= 4096 (DSDTM_ERR_INVALID beyond).
+ * Limits: n_points <= 4096, grid cells <= 4096, cell_size <= 127, max_matches <= 256, n_kf <= 4096 (DSDTM_ERR_INVALID beyond).
+ * An image in pinned host memory (hipHostMalloc / hipHostRegister) is copied up straight from there; any other is staged first.
  */
 typedef struct dsdtm_track_desc {
     /* the new frame (src/Frame.cpp:35-41) */
