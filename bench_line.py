@@ -60,7 +60,7 @@ def secondary_line(entry):
     e = strip_notes(entry, 64)
     out = {"secondary": e.get("key") or e.get("workload", "")[:48]}
     for k in ("value", "unit", "value_four_streams", "us_per_frame", "run_wall_ms", "run_device_ms", "run_wall_ms_cpp", "new_frame_wall_ms",
-              "frame_wall_ms", "frame_device_ms", "frame_cpu_oracle_ms", "cpu_oracle_ms", "h2d_achieved_GBps", "h2d_fraction_of_ceiling",
+              "frame_wall_ms", "frame_wall_ms_pinned_image", "four_call_wall_ms", "frame_device_ms", "frame_cpu_oracle_ms", "cpu_oracle_ms", "h2d_achieved_GBps", "h2d_fraction_of_ceiling",
               "cpu_all_cores_alignments_per_s", "iterations"):
         if k in e:
             out[k] = e[k]

@@ -549,4 +549,114 @@ public:
     }
 };
 
+// ---- one tracked frame in ONE library call (src/Tracking.cpp:199-256) --------------------------------------
+// Tracking::TrackWithLastFrame + UpdateLocalMap + TrackWithLocalMap for a tracker whose frames live on the device:
+// dsdtm_track_frame enqueues the new frame's upload and pyramid, Run, ReprojectPoint + Get_ClosetObs for every local map
+// point, FindMatchDirect for all of them, the cell walk of SearchLocalPoints (replayed on the device) and
+// PoseOptimization back to back and waits once. What stays here is what the reference's classes leave on its objects:
+// the new Features (px, level, bearing, map point, mbInitial: src/Feature_alignment.cpp:108-114), IncreaseFound (:106),
+// the mask discs (:111), Set_Pose and the EraseFound walk (src/Optimizer.cpp:78-92). Same results as the four calls
+// above, bit for bit (tests/test_track_frame_gpu.py, tests/test_host_cpp.py).
+class Tracking {
+public:
+    Tracking(CameraPtr camera, int tMaxLevel, int tMinLevel, int tMaxIterators, int tMinTracked = 20)   // src/Tracking.cpp:20-37, :208
+        : mCam(camera), mMaxLevel(tMaxLevel), mMinLevel(tMinLevel), mMaxIters(tMaxIterators), mMinTracked(tMinTracked) {}
+
+    struct Result { int n_tracked = 0; bool lost = false; std::vector<Feature_Alignment::Match> matches; dsdtm_align_stats stats{};
+                    dsdtm_pose_opt_summary summary{}; SE3 T_run; };
+
+    // level0: the new image. `last`, the keyframes: frames whose pyramids are resident (ComputeImagePyramidOnDevice).
+    // local_points: the order UpdateLocalMap would hand them to ReprojectPoint (:283-299). img_mask: Frame::mImgMask or null.
+    FramePtr TrackFrame(const Image8& level0, const FramePtr& last, const std::vector<Frame*>& keyframes,
+                        const std::vector<MapPoint*>& local_points, Image8* img_mask, Result* out) {
+        const int levels = mMaxLevel;
+        const std::vector<Feature>& rf = last->mvFeatures;
+        const size_t n = rf.size(), M = local_points.size();
+        mPx.resize(2 * n); mBear.resize(3 * n); mPw.resize(3 * n); mIni.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            mPx[2 * i] = rf[i].mpx_x; mPx[2 * i + 1] = rf[i].mpx_y; mIni[i] = rf[i].mbInitial ? 1 : 0;
+            const std::array<double, 3>& pw = rf[i].Mpt ? rf[i].Mpt->Get_Pose() : rf[i].mMptPose;   // Run snapshots Mpt->Get_Pose() (:93)
+            for (int k = 0; k < 3; ++k) { mBear[3 * i + (size_t)k] = rf[i].mNormal[(size_t)k]; mPw[3 * i + (size_t)k] = pw[(size_t)k]; }
+        }
+        std::map<const Frame*, int> kf_index;
+        std::vector<const dsdtm_frame*> kd;
+        std::vector<double> Tk;
+        for (size_t k = 0; k < keyframes.size(); ++k) {
+            kf_index[keyframes[k]] = (int)k;
+            if (!keyframes[k]->mDev) throw std::runtime_error("Tracking::TrackFrame: keyframe pyramids must be resident on the device");
+            kd.push_back(keyframes[k]->mDev);
+            Tk.insert(Tk.end(), keyframes[k]->Get_Pose().m.begin(), keyframes[k]->Get_Pose().m.end());
+        }
+        if (!last->mDev) throw std::runtime_error("Tracking::TrackFrame: the last frame's pyramid must be resident on the device");
+        mMpw.resize(3 * M); mFound.resize(M); mBad.resize(M); mOff.assign(M + 1, 0);
+        mOkf.clear(); mOpx.clear(); mOlv.clear(); mOb.clear();
+        for (size_t i = 0; i < M; ++i) {
+            const MapPoint& mp = *local_points[i];
+            for (int k = 0; k < 3; ++k) mMpw[3 * i + (size_t)k] = mp.mPose[(size_t)k];
+            mFound[i] = mp.Get_FoundNums(); mBad[i] = mp.IsBad() ? 1 : 0;
+            for (const auto& o : mp.mObservations) {                       // iteration order of the map = Get_ClosetObs' order
+                const Feature& f = keyframes[(size_t)o.first]->mvFeatures[(size_t)o.second];
+                mOkf.push_back(o.first); mOpx.push_back(f.mpx_x); mOpx.push_back(f.mpx_y); mOlv.push_back(f.mlevel);
+                for (int k = 0; k < 3; ++k) mOb.push_back(f.mNormal[(size_t)k]);
+            }
+            mOff[i + 1] = (int32_t)mOkf.size();
+        }
+        const Camera& c = *mCam;
+        const dsdtm_camera cam{c.mfx, c.mfy, c.mcx, c.mcy, c.mf, c.mwidth, c.mheight};
+        dsdtm_track_desc d{};
+        d.image = level0.data.data(); d.width = level0.cols; d.height = level0.rows; d.stride = level0.step; d.levels = levels;
+        d.ref = last->mDev; d.ref_px_xy = mPx.data(); d.ref_bearing = mBear.data(); d.ref_p_world = mPw.data(); d.ref_initial = mIni.data();
+        d.n_ref_features = (int32_t)n; d.T_ref_w = last->Get_Pose().m.data(); d.T_seed = last->Get_Pose().m.data();     // :201
+        d.align.max_level = mMaxLevel; d.align.min_level = mMinLevel; d.align.max_iters = mMaxIters; d.align.min_fts = Config::Min_fts();
+        d.min_tracked = mMinTracked;
+        d.kf = kd.data(); d.n_kf = (int32_t)kd.size(); d.T_kf_w = Tk.data();
+        d.n_points = (int32_t)M; d.mp_world = mMpw.data(); d.mp_found = mFound.data(); d.mp_bad = mBad.data(); d.obs_offset = mOff.data();
+        d.obs_kf = mOkf.data(); d.obs_px = mOpx.data(); d.obs_level = mOlv.data(); d.obs_bearing = mOb.data();
+        if (img_mask) { d.mask = img_mask->data.data(); d.mask_stride = img_mask->step; }
+        d.cell_size = Config::CellSize(); d.max_pyr_levels = Config::MaxPyraLevels(); d.max_matches = 200; d.align2d_iters = 10;
+        d.pose_opt.max_iterations = 100; d.pose_opt.reserved = 0;
+        dsdtm_track_result r;
+        std::vector<dsdtm_track_match> ms(200);
+        std::vector<double> rn(200);
+        if (dsdtm_track_frame(detail::ctx(), &cam, &d, &r, ms.data(), rn.data()) != DSDTM_OK)
+            throw std::runtime_error(std::string("dsdtm_track_frame: ") + dsdtm_last_error(detail::ctx()));
+        FramePtr cur = std::make_shared<Frame>();
+        cur->mCamera = mCam;
+        cur->mvImg_Pyr.push_back(level0);                                  // (level 0 on the host; the pyramid lives on the device)
+        cur->mDev = r.frame;
+        SE3 T; std::copy(r.T_run, r.T_run + 12, T.m.begin());
+        cur->Set_Pose(T);                                                  // src/Sprase_ImageAlign.cpp:57
+        if (out) { out->n_tracked = r.n_tracked; out->lost = r.lost != 0; out->stats = r.stats; out->summary = r.summary; out->T_run = T; out->matches.clear(); }
+        if (r.lost) return cur;                                            // src/Tracking.cpp:208-214
+        for (int k = 0; k < r.n_matches; ++k) {
+            MapPoint* mp = local_points[(size_t)ms[(size_t)k].point];
+            mp->IncreaseFound();                                           // src/Feature_alignment.cpp:106
+            if (img_mask) FillCircle(*img_mask, cvRound((double)ms[(size_t)k].px[0]), cvRound((double)ms[(size_t)k].px[1]), Config::CellSize(), 0);   // :111
+            Feature f; f.mpx_x = ms[(size_t)k].px[0]; f.mpx_y = ms[(size_t)k].px[1]; f.mlevel = ms[(size_t)k].level;   // :108
+            f.Mpt = mp; f.mbInitial = true; f.mMptPose = mp->Get_Pose();    // :109
+            cur->Add_Feature(f);                                           // :113-114
+            if (out) { Feature_Alignment::Match mt; mt.cell = ms[(size_t)k].cell; mt.mp = mp; mt.px[0] = f.mpx_x; mt.px[1] = f.mpx_y; mt.level = f.mlevel; out->matches.push_back(mt); }
+        }
+        std::copy(r.T_opt, r.T_opt + 12, T.m.begin());
+        cur->Set_Pose(T);                                                  // src/Optimizer.cpp:78
+        Optimizer::LastSummary() = r.summary;
+        double thr = Config::LocalBAthreshhold();                          // :22-24
+        thr = thr / mCam->mf;
+        for (int i = 0; i < r.summary.n_residual_blocks && i < r.n_matches; ++i)     // :80-92 (every feature has a block: index = block)
+            if (rn[(size_t)i] > thr) {
+                MapPoint* mp = local_points[(size_t)ms[(size_t)i].point];
+                if (!mp->IsBad()) mp->EraseFound();
+            }
+        return cur;
+    }
+
+private:
+    CameraPtr mCam;
+    int mMaxLevel, mMinLevel, mMaxIters, mMinTracked;
+    std::vector<float> mPx, mOpx;
+    std::vector<double> mBear, mPw, mMpw, mOb;
+    std::vector<uint8_t> mIni, mBad;
+    std::vector<int32_t> mFound, mOff, mOkf, mOlv;
+};
+
 }  // namespace DSDTM

@@ -5,9 +5,11 @@
 //   TrackWithLocalMap    SearchLocalPoints(cur); Optimizer::PoseOptimization(cur)                       (:224, :236)
 // and the frame becomes `last` of the next one — which needs the complete features SearchLocalPoints leaves
 // behind (map point, mbInitial, bearing). Reads a world + frame sequence written by tests/test_host_cpp.py.
-//   usage: example_track <world.bin>
+//   usage: example_track <world.bin> [onecall]     onecall: every frame through ONE dsdtm_track_frame (Tracking::TrackFrame of the
+//                                                  host layer) instead of the four synchronous calls — the same lines are printed
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "dsdtm_host.hpp"
 
@@ -73,7 +75,27 @@ int main(int argc, char** argv) {
     std::vector<Frame*> kfp;
     for (auto& k : kfs) kfp.push_back(k.get());
     FramePtr last = kfs.back();
-    for (int k = 0; k < n_frames; ++k) {
+    const bool onecall = argc > 2 && std::string(argv[2]) == "onecall";
+    Tracking tracker(cam, 5, 0, 8, 20);
+    for (int k = 0; k < n_frames && onecall; ++k) {
+        Image8 im(W, H);
+        rd(f, im.data.data(), im.data.size());
+        std::vector<MapPoint*> local;
+        for (MapPoint& mp : mps) if (!mp.IsBad()) local.push_back(&mp);      // UpdateLocalMap skips bad points (:288)
+        Tracking::Result res;
+        FramePtr cur = tracker.TrackFrame(im, last, kfp, local, nullptr, &res);
+        std::printf("frame %d run %d pose", k, res.n_tracked);
+        for (double v : res.T_run.m) std::printf(" %.17g", v);
+        std::printf("\nmatches %zu", res.matches.size());
+        for (const auto& m : res.matches) std::printf(" %d %d %d %.9g %.9g", m.cell, (int)(m.mp - mps.data()), m.level, m.px[0], m.px[1]);
+        std::printf("\nrefined %d %d pose", res.summary.iterations, res.summary.termination);
+        for (double v : cur->Get_Pose().m) std::printf(" %.17g", v);
+        std::printf("\nmap");
+        for (const MapPoint& mp : mps) std::printf(" %d%s", mp.mnFound, mp.mbBad ? "b" : "");
+        std::printf("\n");
+        last = cur;
+    }
+    for (int k = 0; k < n_frames && !onecall; ++k) {
         FramePtr cur = std::make_shared<Frame>();
         cur->mCamera = cam;
         Image8 im(W, H);

@@ -54,7 +54,11 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
              ("dsdtm_stream_desc", capi.StreamDesc, ["row_stride", "image_pitch", "ref_image", "cur_image", "n_features", "stats"]),
              ("dsdtm_detect_params", capi.DetectParams, ["detection_threshold"]),
              ("dsdtm_pose_opt_params", capi.PoseOptParams, ["max_iterations"]),
-             ("dsdtm_pose_opt_summary", capi.PoseOptSummary, ["termination", "n_residual_blocks", "initial_cost", "final_cost", "x"])]
+             ("dsdtm_pose_opt_summary", capi.PoseOptSummary, ["termination", "n_residual_blocks", "initial_cost", "final_cost", "x"]),
+             ("dsdtm_track_desc", capi.TrackDesc, ["levels", "ref", "n_ref_features", "T_seed", "align", "min_tracked", "kf", "n_kf", "T_kf_w", "n_points",
+                                                   "mp_bad", "obs_offset", "obs_bearing", "mask", "mask_stride", "cell_size", "align2d_iters", "pose_opt"]),
+             ("dsdtm_track_match", capi.TrackMatch, ["point", "px", "level"]),
+             ("dsdtm_track_result", capi.TrackResult, ["T_run", "n_tracked", "lost", "stats", "n_in_grid", "n_matches", "replay_full_scan", "T_opt", "summary"])]
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "dsdtm_amd.h"', 'int main(void) {']
     for cname, _, fields in pairs:
         src.append(f'  printf("%zu", sizeof({cname}));')

@@ -202,6 +202,11 @@ def test_cpp_tracked_sequence_matches_the_python_mirror(tmp_path, gpu_ctx):
     dump_world(world, cam, kfs, cur0, mps, 5, 25, 5, frames=imgs)
     out = subprocess.run([exe, str(world)], capture_output=True, text=True, check=True).stdout.strip().split("\n")
     assert len(out) == 4 * n_frames
+    # the same six frames with ONE library call per frame (Tracking::TrackFrame of the host layer -> dsdtm_track_frame: reprojection,
+    # closest observation and the cell walk on the device instead of in the host layer): every printed line — poses to 17 digits,
+    # matches, pixels, refinement summaries, map counters — is the same
+    one = subprocess.run([exe, str(world), "onecall"], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert one == out
     # the Python mirror on the same world
     for k, kf in enumerate(kfs):
         mpts = [None] * kf.n_features
