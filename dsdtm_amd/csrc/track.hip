@@ -134,7 +134,6 @@ __device__ __forceinline__ int unpack_y(uint32_t v) { return (int)(int16_t)(v >>
 // Dynamic LDS of the replay workgroup, carved by ONE function for the host (size) and the device (pointers)
 struct ReplayLds {
     unsigned long long* tmp;   // [mpad] keys in bin order
-    float* c_pxf;        // [mpad * 2] by candidate: the refined pixel as float (Feature::mpx)
     uint32_t* hist;      // [cells + 1] counts, then bin starts (exclusive scan); [cells] = n_in
     uint32_t* cur;       // [cells] next free place of a bin
     uint32_t* wsum;      // [RP_THREADS / 64]
@@ -156,7 +155,6 @@ __host__ __device__ inline ReplayLds replay_layout(uint8_t* base, int n_points, 
     size_t o = 0;
     auto take = [&](size_t bytes, size_t align) { o = (o + align - 1) / align * align; const size_t at = o; o += bytes; return base + at; };
     L.tmp = (unsigned long long*)take(mpad * 8, 8);
-    L.c_pxf = (float*)take(mpad * 8, 8);
     L.hist = (uint32_t*)take(((size_t)cells + 1) * 4, 4);
     L.cur = (uint32_t*)take((size_t)cells * 4, 4);
     L.wsum = (uint32_t*)take((RP_THREADS / 64) * 4, 4);
@@ -236,7 +234,6 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
                 L.c_q[i] = pack_xy(qx_, qy_);
                 L.c_live[i] = live ? 1 : 0;
                 L.c_sl[i] = (int8_t)sl;
-                L.c_pxf[2 * i] = (float)u1; L.c_pxf[2 * i + 1] = (float)v1;            // Feature(px as cv::Point2f, :108)
                 // the neighbourhood scan below looks two cells around a candidate: valid while a disc centre (the refined pixel)
                 // stays within one cell size of its candidate's reprojected pixel — otherwise every earlier candidate is scanned
                 const int ddx = qx_ - px_, ddy = qy_ - py_;
@@ -461,7 +458,7 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
         if (!(r < n_in && L.state[r] == ST_ACCEPTED)) continue;
         if (k < (uint32_t)a.max_matches) {
             const int i = my_idx[e];
-            const float fx_ = L.c_pxf[2 * i], fy_ = L.c_pxf[2 * i + 1];
+            const float fx_ = (float)a.px[2 * (size_t)i], fy_ = (float)a.px[2 * (size_t)i + 1];     // Feature(px as cv::Point2f, :108)
             const int lvl = (int)L.c_sl[i];
             dsdtm_track_match mo;
             mo.cell = (int)L.rcell[r]; mo.point = i; mo.px[0] = fx_; mo.px[1] = fy_; mo.level = lvl;
