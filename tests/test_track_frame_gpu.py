@@ -96,6 +96,34 @@ def test_search_part_equals_the_speculative_host_replay_and_honours_a_mask(gpu_c
     r["frame"].close()
 
 
+@pytest.mark.parametrize("n_points,cell", [(4000, 25), (4096, 10), (4096, 40)])
+def test_large_and_dense_local_maps(gpu_ctx, n_points, cell):
+    """Up to the documented 4096 map points (four ranks per thread of the replay workgroup), small cells, and cells so
+    large that a candidate's neighbourhood holds more than 64 earlier ranks (the workgroup then scans every earlier candidate:
+    replay_full_scan): the device replay gives the host replay's matches (LocalPointSearch: speculative batch + host walk)."""
+    Config.Set("Camera.CellSize", cell); Config.Set("Camera.MaxPyraLevels", 5)
+    cam, kfs, cur, mps = make_world(13, n_points=n_points, cell=cell, obs_margin=3)
+    mps_h = copy.deepcopy(mps)
+    s = search.LocalPointSearch(cam, ctx=gpu_ctx, resident_frames=True)
+    s.ResetGrid()
+    for mp in mps_h:
+        if not mp.IsBad():
+            s.ReprojectPoint(cur, mp)
+    idx = {id(mp): i for i, mp in enumerate(mps_h)}
+    want = [(g[0], idx[id(g[1])], float(g[2][0]), float(g[2][1]), g[3]) for g in s.SearchLocalPoints(cur, kfs)]
+    last = Frame(cam, cur.mvImg_Pyr, cur.Get_Pose())
+    r = tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], 5, last, cur.Get_Pose(), (5, 0, 8, 15), 0, kfs, mps, cell_size=cell)
+    m = r["matches"]
+    got = [(int(m["cell"][k]), int(m["point"][k]), float(m["px"][k][0]), float(m["px"][k][1]), int(m["level"][k])) for k in range(len(m))]
+    assert got == want and len(got) >= 100
+    if cell == 40:
+        assert r["replay_full_scan"]          # 4096 candidates over 192 cells: > 64 ranks in a five-cell row range
+    if cell == 10:
+        assert not r["replay_full_scan"]      # 1.3 candidates per cell: the rank-range masks
+    r["frame"].close()
+    Config.Set("Camera.CellSize", 25)
+
+
 def test_tracked_sequence_one_call_per_frame_equals_the_four_call_chain(gpu_ctx):
     """Seven frames tracked twice on copies of one world: through the four synchronous calls per frame (Run, SearchLocalPoints'
     speculative batch + host replay, PoseOptimization — tests/test_tracking_sequence_gpu.py holds that chain to the CPU oracle)
