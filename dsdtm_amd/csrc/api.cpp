@@ -152,6 +152,7 @@ const OptionKey kOptionKeys[] = {
     {"no_recover", "DSDTM_NO_RECOVER", &dsdtm::Options::no_recover, true},
     {"team_no_wrap_clear", "DSDTM_TEAM_NO_WRAP_CLEAR", &dsdtm::Options::team_no_wrap_clear, true},
     {"warp_group", "DSDTM_WARP_GROUP", &dsdtm::Options::warp_group, false},
+    {"po_rows", "DSDTM_PO_ROWS", &dsdtm::Options::po_rows, false},
     {"a2d_group", "DSDTM_A2D_GROUP", &dsdtm::Options::a2d_group, false},
 };
 std::once_flag g_options_once;

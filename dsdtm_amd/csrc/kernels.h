@@ -66,6 +66,7 @@ struct Options {
     int warp_group = 0;        // DSDTM_WARP_GROUP: candidates per workgroup of the warp prelude (2, 8, 16, 32, 64; 0: by batch size)
     int team_no_wrap_clear = 0;  // DSDTM_TEAM_NO_WRAP_CLEAR: the team ring is NOT re-zeroed when the tag epoch wraps (A/B of that hazard only)
     int no_recover = 0;        // DSDTM_NO_RECOVER: a multi-CU launch that timed out is reported, not re-run (tests)
+    int po_rows = 1;           // DSDTM_PO_ROWS: batched pose refinement with four frames per wavefront (0: one frame per wavefront, rounds 1-5; A/B)
 };
 #ifdef DSDTM_DIAG
 Options& options();

@@ -166,11 +166,18 @@ __device__ __forceinline__ void block_residual_regs(const FeatRegs& c, const SE3
 // NW waves per frame: one for batches (the wave-uniform solver part is executed once per frame), four for a
 // few frames (the live tracker's single frame: the features spread over 256 lanes, every wave repeats the
 // solver part on the same totals and so takes the same decisions — no broadcast).
-template <int NW, int FPL>      // FPL: features per lane held in registers (0: read from memory at every evaluation)
+// GPW frames per wavefront (batches, round 6): 1, or 4 — a frame then owns a 16-lane ROW of the wave: its features stride over 16
+// lanes (four times the evaluations per lane), its totals are summed over the row, and the solver part below — two thirds of an
+// iteration's instructions, executed redundantly by all 64 lanes for ONE frame before — runs for four frames at once, each
+// row uniform in itself. Rows that take different branches (a rejected step, a frame that has converged) are serialised by
+// the hardware like any divergent code; nothing crosses a row.
+template <int NW, int FPL, int GPW = 1>      // FPL: features per lane held in registers (0: read from memory at every evaluation)
 __device__ void evaluate(const Frame& f, const FeatRegs* fr, int tid, const SE3d& T /* pose_of(x) */, double& cost, double* hg,
                          double* part, double* red, bool& ok) {
     constexpr bool LAT = NW > 1;
     constexpr bool CACHED = FPL > 0;
+    constexpr int LPF = 64 / GPW;                           // lanes per frame
+    static_assert(GPW == 1 || (NW == 1 && FPL == 0), "several frames per wave: one wave per workgroup, features from memory");
     const int lane = tid & 63, wave = tid >> 6;
     double c = 0.0, h[21], gg[6];
     bool bad = false;
@@ -179,7 +186,7 @@ __device__ void evaluate(const Frame& f, const FeatRegs* fr, int tid, const SE3d
 #pragma unroll
     for (int k = 0; k < 6; ++k) gg[k] = 0.0;
 #pragma unroll
-    for (int i = tid, j = 0; CACHED ? j < FPL : i < f.n; i += NW * 64, ++j) {
+    for (int i = (GPW == 1 ? tid : (lane & (LPF - 1))), j = 0; CACHED ? j < FPL : i < f.n; i += (GPW == 1 ? NW * 64 : LPF), ++j) {
         double r0, r1, px, py, pz;
         if constexpr (CACHED) {
             if (!fr[j].use) continue;
@@ -219,6 +226,24 @@ __device__ void evaluate(const Frame& f, const FeatRegs* fr, int tid, const SE3d
 #pragma unroll
     for (int k = 0; k < 6; ++k) row[21 + k] = gg[k];
     row[27] = c;
+    if constexpr (GPW > 1) {
+        // the row's 28 totals: lane gl of the row adds columns gl and gl + 16 over the row's 16 lanes, in lane order
+        const int g = lane / LPF, gl = lane & (LPF - 1);
+        const unsigned long long bad_row = (__ballot(bad) >> (g * LPF)) & ((1ull << LPF) - 1ull);
+        __syncthreads();                                    // (one wave per workgroup: orders the LDS writes and reads)
+        for (int col = gl; col < 28; col += LPF) {
+            double acc = 0.0;
+            const double* src = part + (size_t)(g * LPF) * PO_PART_STRIDE + col;
+#pragma unroll
+            for (int l = 0; l < LPF; ++l) acc += src[l * PO_PART_STRIDE];
+            hg[col] = acc;                                  // hg: this row's totals
+        }
+        __syncthreads();
+        cost = hg[27];
+        ok = bad_row == 0ull && isfinite(cost);
+        (void)red; (void)wave;
+        return;
+    }
     const unsigned long long bad_wave = __ballot(bad);
     __syncthreads();                                        // orders LDS writes and reads
     const int col = lane & 31, half = lane >> 5;
@@ -326,14 +351,17 @@ __device__ __forceinline__ double gradient_max_norm(const SE3d& Tx, const double
 constexpr int PO_WAVES_PER_EU = 2;
 // The whole refinement of one frame by NW waves (FPL > 0: a lane's features in registers). A device function so that ONE
 // kernel can carry two instantiations and pick by the frame's live feature count (pose_opt_auto_kernel below).
-template <int NW, int FPL>
+template <int NW, int FPL, int GPW = 1>
 __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
     constexpr bool LAT = NW > 1;
     constexpr bool CACHED = FPL > 0;
-    const int frame = blockIdx.x;
-    if (frame >= a.n_frames) return;
+    constexpr int LPF = 64 / GPW;                           // lanes per frame (GPW frames per wavefront, see evaluate)
+    constexpr unsigned long long ROWMASK = GPW == 1 ? ~0ull : ((1ull << (LPF & 63)) - 1ull);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int grp = GPW == 1 ? 0 : lane / LPF, gl = lane & (LPF - 1);
+    const int frame = GPW == 1 ? (int)blockIdx.x : (int)blockIdx.x * GPW + grp;
+    if (frame >= a.n_frames) return;
     const size_t base = (size_t)frame * a.max_features;
     Frame f;
     f.bearing = a.bearing + base * 3;
@@ -348,9 +376,10 @@ __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
     // residual blocks (src/Optimizer.cpp:45-65)
     int n_blocks = 0;
     if constexpr (!CACHED) {
-        for (int b0 = 0; b0 < f.n; b0 += 64) {
-            const int i = b0 + lane;
-            n_blocks += __popcll(__ballot(i < f.n && f.use[i]));
+        for (int b0 = 0; b0 < f.n; b0 += LPF) {
+            const int i = b0 + gl;
+            const unsigned long long m = __ballot(i < f.n && f.use[i]);
+            n_blocks += __popcll((m >> (grp * LPF)) & ROWMASK);
         }
     }
 
@@ -367,7 +396,8 @@ __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
 
     int termination = DSDTM_PO_MAX_ITERATIONS, iterations = 0, successful = 0;
     double x_cost = 0.0, initial_cost = 0.0;
-    __shared__ double s_hg[2][28];     // H (21), g (6), cost of the accepted point [cur] and of the candidate [cur ^ 1]
+    __shared__ double s_hg_all[GPW][2][28];     // per frame of the wave: H (21), g (6), cost of the accepted point [cur] and of the candidate [cur ^ 1]
+    double (*s_hg)[28] = s_hg_all[grp];
     __shared__ double s_part[NW * 64 * PO_PART_STRIDE];   // per-lane partials of one evaluation
     __shared__ double s_red[(2 * NW + 1) * 32];           // half-wave sums, then the waves' not-finite flags
     if constexpr (CACHED) {                                // residual blocks = used features over the NW waves
@@ -385,7 +415,7 @@ __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
     if (n_blocks == 0) {
         termination = DSDTM_PO_NO_RESIDUALS;
     } else {
-        evaluate<NW, FPL>(f, fr, tid, Tx, x_cost, s_hg[0], s_part, s_red, ok);
+        evaluate<NW, FPL, GPW>(f, fr, tid, Tx, x_cost, s_hg[0], s_part, s_red, ok);
         if (!ok) {
             termination = DSDTM_PO_EVALUATION_FAILED;
             x_cost = 0.0;
@@ -453,7 +483,7 @@ __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
                 pose_plus<LAT>(Tx, delta, cand);
                 bool cand_ok = finite6(cand);
                 const SE3d Tc = pose_of<LAT>(cand);
-                if (cand_ok) evaluate<NW, FPL>(f, fr, tid, Tc, cand_cost, s_hg[cur ^ 1], s_part, s_red, cand_ok);
+                if (cand_ok) evaluate<NW, FPL, GPW>(f, fr, tid, Tc, cand_cost, s_hg[cur ^ 1], s_part, s_red, cand_ok);
                 if (!cand_ok) cand_cost = DBL_MAX;
                 double diff[6];
 #pragma unroll
@@ -514,7 +544,7 @@ __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
         }
     }
     if (tid >= 64) return;                                  // results: the first wave (all waves hold the same state)
-    if (lane == 0) {
+    if (gl == 0) {
         Tio[0] = R[0]; Tio[1] = R[1]; Tio[2] = R[2];  Tio[3] = Tf.tx;
         Tio[4] = R[3]; Tio[5] = R[4]; Tio[6] = R[5];  Tio[7] = Tf.ty;
         Tio[8] = R[6]; Tio[9] = R[7]; Tio[10] = R[8]; Tio[11] = Tf.tz;
@@ -532,12 +562,13 @@ __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
         // GetReprojectReidual (src/Optimizer.cpp:297-317): raw residual norms, in residual-block order
         double* rn = a.residual_norm + base;
         int done = 0;
-        for (int b0 = 0; b0 < f.n; b0 += 64) {
-            const int i = b0 + lane;
+        for (int b0 = 0; b0 < f.n; b0 += LPF) {
+            const int i = b0 + gl;
             double r0 = 0.0, r1 = 0.0, px, py, pz;
             const bool u = block_residual(f, i, Tf, r0, r1, px, py, pz);
-            const unsigned long long m = __ballot(u);
-            if (u) rn[done + __popcll(m & ((1ull << lane) - 1ull))] = sqrt(r0 * r0 + r1 * r1);
+            const unsigned long long mw = __ballot(u);
+            const unsigned long long m = (mw >> (grp * LPF)) & ROWMASK;
+            if (u) rn[done + __popcll(m & ((1ull << gl) - 1ull))] = sqrt(r0 * r0 + r1 * r1);
             done += __popcll(m);
         }
     }
@@ -546,6 +577,11 @@ __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
 template <int NW, int FPL>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? PO_WAVES_PER_EU : 1, NW == 1 ? PO_WAVES_PER_EU : 2)))
 void pose_opt_kernel(PoseOptArgs a) { pose_opt_body<NW, FPL>(a); }
+
+// Batches: GPW frames per wavefront (16 or 32 lanes each), one wave per workgroup
+template <int GPW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PO_WAVES_PER_EU, PO_WAVES_PER_EU)))
+void pose_opt_rows_kernel(PoseOptArgs a) { pose_opt_body<1, 0, GPW>(a); }
 
 // dsdtm_track_frame: ONE frame whose feature count (<= 256) is only known on the device. dsdtm_pose_optimization picks the
 // instantiation on the host — one wave up to 64 features, four waves with the features in registers up to 256 — and the
@@ -570,6 +606,17 @@ hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream) {
     // a few frames (the live tracker refines one): latency counts, four waves share a frame's features;
     // batches: one wave per frame, the solver part is not repeated
     const bool no_cache = options().po_no_cache != 0;                          // diagnostic (A/B)
+    if (args.force_variant == 4 || (args.force_variant == 0 && args.n_frames > 32 && options().po_rows)) {
+        // batches: four frames per wavefront (round 6: the solver part of an iteration, two thirds of its instructions, runs for
+        // four frames at once)
+        // — as many frames per wave as still leave every wave slot of the GPU (256 CUs x 4 SIMDs x 2 waves) a wave: a wave's
+        // chain gets longer with every frame it carries, which only pays while the machine stays full (4096 x 200: one frame per
+        // wave 0.706 ms, two 0.6 ms, four 0.648 ms — half the slots empty; 16 384 x 200: 2.37 / - / 1.67 ms)
+        const int slots = 256 * 4 * PO_WAVES_PER_EU;
+        const int gpw = args.force_variant == 4 ? 4 : (args.n_frames >= 4 * slots ? 4 : (args.n_frames >= 2 * slots ? 2 : 1));
+        if (gpw == 4) { hipLaunchKernelGGL(pose_opt_rows_kernel<4>, dim3((unsigned)((args.n_frames + 3) / 4)), dim3(64), 0, stream, args); return hipGetLastError(); }
+        if (gpw == 2) { hipLaunchKernelGGL(pose_opt_rows_kernel<2>, dim3((unsigned)((args.n_frames + 1) / 2)), dim3(64), 0, stream, args); return hipGetLastError(); }
+    }
     if (args.force_variant == 1) { hipLaunchKernelGGL((pose_opt_kernel<1, 0>), dim3((unsigned)args.n_frames), dim3(64), 0, stream, args); return hipGetLastError(); }
     if (args.force_variant == 2) { hipLaunchKernelGGL((pose_opt_kernel<4, 1>), dim3((unsigned)args.n_frames), dim3(256), 0, stream, args); return hipGetLastError(); }
     if (args.n_frames <= 32 && args.max_features > 64 && args.max_features <= 256 && !no_cache)
