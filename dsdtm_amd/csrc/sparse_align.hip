@@ -341,9 +341,7 @@ __device__ __forceinline__ void grid_from_rows(const FeatureRegs& F, const RefGe
         }
 #pragma unroll
         for (int c = 0; c < 7; ++c) top[c] = bot[c];
-#ifndef DSDTM_EXP_GRID2                  // (round-6 experiment: without it the scheduler may keep two footprint rows in flight)
-        __builtin_amdgcn_sched_barrier(0);   // one footprint row in flight
-#endif
+        __builtin_amdgcn_sched_barrier(0);   // one footprint row in flight (two: measured flat, profiles/r06_headline.txt)
     }
 }
 
@@ -404,19 +402,6 @@ __device__ __forceinline__ PatchHess patch_hess_from_sums(double sxx, double sxy
     return h;
 }
 __device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs& P, double fs, bool use = true) {
-#ifdef DSDTM_EXP_HSUM2                   // round-6 experiment: six accumulation chains of eight instead of three of sixteen
-    double sxx = 0.0, sxy = 0.0, syy = 0.0, txx = 0.0, txy = 0.0, tyy = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double dx = P.g[i + 1][k + 2] - P.g[i + 1][k];
-            const double dy = P.g[i + 2][k + 1] - P.g[i][k + 1];
-            if (k & 1) { txx += dx * dx; txy += dx * dy; tyy += dy * dy; }
-            else { sxx += dx * dx; sxy += dx * dy; syy += dy * dy; }
-        }
-    return patch_hess_from_sums(sxx + txx, sxy + txy, syy + tyy, P.X, fs, use);
-#else
     double sxx = 0.0, sxy = 0.0, syy = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -427,7 +412,6 @@ __device__ __forceinline__ PatchHess patch_hess_factors(const PatchRegs& P, doub
             sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
         }
     return patch_hess_from_sums(sxx, sxy, syy, P.X, fs, use);
-#endif
 }
 
 // entry q (row-major upper triangle, 0..20) by compile-time index; 0 beyond
@@ -2233,16 +2217,9 @@ hipError_t sparse_align_launch(const SAKernelArgs& args, SAVariant variant, int 
             if (ws_windows && npad <= 1024) {
                 // everything a pass needs in LDS: window origins + windows + parked grid inputs (4 + 60 + 88 KB)
                 constexpr size_t lds = (16 + WS_DWORDS) * 1024 * sizeof(uint32_t);
-#ifdef DSDTM_EXP_WS16
-                // experiment (round 6): ONE patch per lane on 16 waves (four per SIMD at <= 128 VGPRs) instead of two patches per lane on 8
-                const hipError_t attr = optin_dynamic_lds<sparse_align_ws_kernel<16, 1024, true>>(lds);
-                if (attr != hipSuccess) return attr;
-                hipLaunchKernelGGL((sparse_align_ws_kernel<16, 1024, true>), grid, dim3(1024), lds, stream, args);
-#else
                 const hipError_t attr = optin_dynamic_lds<sparse_align_ws_kernel<WS_NPW, 1024, true>>(lds);
                 if (attr != hipSuccess) return attr;
                 hipLaunchKernelGGL((sparse_align_ws_kernel<WS_NPW, 1024, true>), grid, dim3(WS_THREADS), lds, stream, args);
-#endif
             } else if (allow_multi_cu && sparse_align_uses_duo(args.max_features, args.workspace != nullptr)) {
                 // one pair on two compute units, each half wholly in LDS; the exchange words are zeroed per launch
                 constexpr size_t lds = (16 + WS_DWORDS) * 1024 * sizeof(uint32_t);
