@@ -193,14 +193,15 @@ void track_disc_half_widths(int radius, int8_t* hw) {
 
 size_t track_replay_lds_bytes(int n_points, int n_cells, int radius) { return replay_layout(nullptr, n_points, n_cells, radius).bytes; }
 
-template <int EPT>
-__global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArgs a) {
+template <int EPT, int NT = RP_THREADS>
+__global__ __launch_bounds__(NT) void track_replay_kernel(const TrackArgs a) {
+    static_assert(NT % 64 == 0 && NT <= RP_THREADS, "threads of the replay workgroup");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     __shared__ int s_overflow, s_n_in;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = a.n_points, cells = a.grid_cols * a.grid_rows, R = a.cell_size, cols = a.grid_cols;
     const ReplayLds L = replay_layout(lds_raw, M, cells, R);
-    for (int c = tid; c <= cells; c += RP_THREADS) L.hist[c] = 0u;
+    for (int c = tid; c <= cells; c += NT) L.hist[c] = 0u;
     if (tid == 0) s_overflow = 0;
     if (tid <= R) L.hw[tid] = (int16_t)a.disc_hw[tid];          // cv::circle's row half-widths, tabulated by the host (track_disc_half_widths)
     __syncthreads();
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
     int kcell[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * RP_THREADS;
+        const int i = tid + e * NT;
         kcell[e] = -1;
         key[e] = ~0ull;
         if (i < M) {
@@ -243,8 +244,10 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
     }
     __syncthreads();
     {   // exclusive scan of the cell counts: consecutive cells per thread, wave scan, wave totals
-        const int cpt = (cells + RP_THREADS - 1) / RP_THREADS;     // <= 4 (cells <= 4096)
-        uint32_t c[4] = {0, 0, 0, 0}, sum = 0;
+        const int cpt = (cells + NT - 1) / NT;     // <= 16 (cells <= 4096, NT >= 256)
+        uint32_t c[16], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[q] = 0u;
         for (int q = 0; q < cpt; ++q) { const int cc = tid * cpt + q; c[q] = cc < cells ? L.hist[cc] : 0u; sum += c[q]; }
         uint32_t inc = sum;
 #pragma unroll
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
         uint32_t base = inc - sum;
         for (int w = 0; w < wave; ++w) base += L.wsum[w];
         for (int q = 0; q < cpt; ++q) { const int cc = tid * cpt + q; if (cc < cells) { L.hist[cc] = base; L.cur[cc] = base; } base += c[q]; }
-        if (tid == RP_THREADS - 1) { L.hist[cells] = base; s_n_in = (int)base; }
+        if (tid == NT - 1) { L.hist[cells] = base; s_n_in = (int)base; }
     }
     __syncthreads();
     const int n_in = s_n_in;
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(RP_THREADS) void track_replay_kernel(const TrackArg
     if (lane == 63) L.wsum[wave] = inc;
     __syncthreads();
     uint32_t k = inc - cnt, total = 0;
-    for (int w = 0; w < RP_THREADS / 64; ++w) { if (w < wave) k += L.wsum[w]; total += L.wsum[w]; }
+    for (int w = 0; w < NT / 64; ++w) { if (w < wave) k += L.wsum[w]; total += L.wsum[w]; }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int r = tid * EPT + e;

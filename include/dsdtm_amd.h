@@ -117,6 +117,12 @@ int dsdtm_device_count(void);
  *               tCurFrame->Set_Pose (:57). Untouched when *n_tracked==0 by the Min_fts rule.
  * n_tracked   : Run's return value (:59)
  * stats       : optional (may be NULL)
+ *
+ * Row strides (quirk Q7): the reference indexes the CURRENT image's base row with `cols` and its +1 row with
+ * `step` (src/Sprase_ImageAlign.cpp:272,278,281) — the same thing for the continuous cv::Mat every producer of the reference
+ * hands over (imread, pyrDown). This library indexes every row with `stride`: a pyramid with padded rows (stride > width) is
+ * read CORRECTLY here, where the reference itself would read the wrong pixels; for stride == width the two are identical.
+ * Host pyramids are repacked to stride == width on upload; the device entries accept padded rows as described.
  */
 int dsdtm_sparse_align(dsdtm_ctx* ctx,
                        const dsdtm_pyramid* ref, const dsdtm_pyramid* cur,
@@ -191,8 +197,12 @@ int dsdtm_detect_cells(dsdtm_ctx* ctx, const dsdtm_pyramid* host_pyramid, const 
  *           frame of the next (src/Tracking.cpp:204,224): with a dsdtm_frame its pyramid crosses
  *           PCIe once instead of twice, and dsdtm_frame_create_from_image sends level 0 only and
  *           builds the other levels with the library's bit-exact pyrDown.
- * A frame belongs to the context that created it and is immutable. dsdtm_frame_destroy waits for
- * the device's pending work (ctx may be NULL; a frame may be destroyed after its context). dsdtm_sparse_align_frames is dsdtm_sparse_align with the two host
+ * A frame belongs to the context that created it and is immutable. dsdtm_frame_destroy: with the frame's own, live context
+ * its buffer goes to that context's pool and serves the next frame of the same size (a tracker creates and destroys one
+ * frame per image: no allocation, no device-wide wait per frame); with ctx == NULL, another context, or after the context
+ * is gone (the pointer is compared, never dereferenced) the buffer is freed, which waits for the device's pending work.
+ * Destroy a frame only when no call that uses it is still running (every entry that takes a dsdtm_frame returns after its
+ * stream has drained). dsdtm_sparse_align_frames is dsdtm_sparse_align with the two host
  * pyramids replaced by frames (same results, bit for bit: it runs the same kernel).
  */
 typedef struct dsdtm_frame dsdtm_frame;

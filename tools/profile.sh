@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/r05_*: kernel trace + stats, then one counter group per pass (never --pmc
+# rocprofv3 passes behind profiles/r06_*: kernel trace + stats, then one counter group per pass (never --pmc
 # together with other trace domains). Usage on the GPU box: tools/profile.sh <outdir-under-gpurun_out>
 # Each "case" is one command line; cases: main (bench defaults: 8 launch streams), solo (one stream), n1000, n2000, the
 # secondary kernels (tools/kernels.py: pyrDown, Align2D), one tracked frame (tools/track_step.py: pyramid, single-pair

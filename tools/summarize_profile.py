@@ -1,7 +1,7 @@
 """Folds the rocprofv3 output of tools/profile.sh (per case: kernel-trace stats, kernel trace, one --pmc pass per
 counter group) into the summaries kept under profiles/:
-    <out>/r05_kernel_stats.csv     per case and kernel: calls, average / min / max duration
-    <out>/r05_bench_pmc.json       "profile_binary_sha": sha256 (16 hex digits) of the libdsdtm_amd.so the passes ran with —
+    <out>/r06_kernel_stats.csv     per case and kernel: calls, average / min / max duration
+    <out>/r06_bench_pmc.json       "profile_binary_sha": sha256 (16 hex digits) of the libdsdtm_amd.so the passes ran with —
                                    bench.py reports these numbers only while it loads that same binary;
                                    per case and kernel: counters per dispatch + "hbm_traffic_per_launch" entries (what
                                    bench.py's roofline.traffic reads): FETCH_SIZE and WRITE_SIZE are KiB per dispatch;
@@ -100,6 +100,9 @@ for case in sorted(os.listdir(src)):
         # (round 5: FindMatchDirect is ONE kernel, 16 candidates per 256-thread group, the warped patches stay in LDS)
         entry("match_kernel", [("match_kernel", (Mm + 15) // 16 * 256)],
               Mm * (4 + 4 + 8 + 4 + 24 + 24 + 16 + 16 + 4 + 1) + 2 * nfm * 640 * 480)
+        # Tracking's own constructor arguments (5 levels, cap 8, 190 patches): sparse_align_reg_kernel<3, 3> = 3 slots of 3 + 1 waves,
+        # one persistent workgroup per CU (round 6: its `traffic` was null — no entry here)
+        entry("sparse_align_reg_kernel<3, 3, false>", [("sparse_align_reg_kernel<3, 3, false>", 256 * 3 * 4 * 64)], 1024 * (2 * pyr5 + 190 * 57 + 292))
         strip_tasks = (640 // 4) * ((480 + 3) // 4)
         sel_tasks = (640 // 4) * 480
         entry("fast_score_strip_kernel+fast_select_rows_kernel+detect_decode_kernel",
@@ -117,7 +120,7 @@ for case in sorted(os.listdir(src)):
                     case=case, kernel=k, dispatches_per_launch=nd, algorithmic_bytes_per_launch=alg, fetch_bytes_raw=fetch,
                     fetch_bytes_gfx950_corrected=2.0 * fetch, write_bytes=write,
                     traffic_over_algorithmic=(2.0 * fetch + write) / alg))
-with open(os.path.join(src, "r05_kernel_stats.csv"), "w", newline="") as f:
+with open(os.path.join(src, "r06_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=["case", "kernel", "calls", "avg_ns", "min_ns", "max_ns", "total_ns", "percent"])
     w.writeheader()
     w.writerows(stats_rows)
@@ -144,7 +147,7 @@ for f in glob.glob(f"{src}/main/trace/**/*_kernel_trace.csv", recursive=True):
               union_span_ns=busy, union_span_per_launch_ns=busy / len(rows), launches_in_flight_avg=weighted / busy,
               first_start=st[0], last_end=max(en), wall_per_launch_ns=(max(en) - st[0]) / len(rows))
 pmc["overlap"] = ov
-json.dump(pmc, open(os.path.join(src, "r05_bench_pmc.json"), "w"), indent=1)
+json.dump(pmc, open(os.path.join(src, "r06_bench_pmc.json"), "w"), indent=1)
 print(json.dumps(ov, indent=1))
 print(json.dumps(pmc["hbm_traffic_per_launch"], indent=1))
 for r in stats_rows:
