@@ -609,13 +609,13 @@ def tracked_frame_entries(torch, dev, ctx, stream):
     flops = float(((its + 1) * blocks).sum()) * 330.0       # block evaluations x ~330 FP64 flops each
     tf = flops / (ms * 1e-3) / 1e12
     out.append({"key": "pose_opt", "workload": f"Optimizer::PoseOptimization: {F_} frames x {N_} features per call (Ceres trust-region LM restated, "
-                            f"{its.mean():.1f} iterations on average), one wavefront per frame",
+                            f"{its.mean():.1f} iterations on average), two frames per wavefront (four from 8192 frames on)",
                 "value": F_ / (ms * 1e-3), "unit": "refinements/s",
                 "roofline": {"bound": "fp64_vector", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "kernel": "pose_opt_kernel", "kernel_ms_avg": ms,
+                             "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "kernel": "pose_opt_rows_kernel", "kernel_ms_avg": ms,
                              "flops_per_launch": flops,
                              # HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes of this launch size (case poseopt)
-                             "traffic": pmc_traffic("pose_opt_kernel", F_ * (N_ * 61 + 2 * 96 + 64)),
+                             "traffic": pmc_traffic("pose_opt_", F_ * (N_ * 61 + 2 * 96 + 64)),
                              "algorithmic_bytes_per_launch": F_ * (N_ * 61 + 2 * 96 + 64),
                              "note": "~330 FP64 flops per residual-block evaluation x (iterations + 1) x blocks; the features of a frame "
                                      "(11 KB) stay in L1/L2: bound by the latency of its dependent FP64 chain, not by HBM"}})

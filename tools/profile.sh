@@ -8,7 +8,7 @@
 # split over two calls and their summaries merged by tools/merge_profiles.py.
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/${1:-prof}"
-CASES="${2:-main solo n1000 n2000 kernels track poseopt secondary}"
+CASES="${2:-main solo n1000 n2000 kernels track trackone poseopt secondary}"
 has() { [[ " $CASES " == *" $1 "* ]]; }
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -20,6 +20,8 @@ CASE[n1000]="$REPO/bench.py --patches 1000 --steps 20 --warmup 3 --streams 1 $CO
 CASE[n2000]="$REPO/bench.py --width 1280 --height 960 --patches 2000 --pairs 256 --steps 20 --warmup 3 --streams 1 $COMMON"
 CASE[kernels]="$REPO/tools/kernels.py"
 CASE[track]="$REPO/tools/track_step.py"
+# round 6: the same tracked frame through ONE dsdtm_track_frame call (pyramid, Run, reprojection, FindMatchDirect, replay, pose refinement)
+CASE[trackone]="$REPO/tools/track_frame_bench.py"
 CASE[poseopt]="$REPO/tools/pose_opt_bench.py 4096 200 nolatency"
 # the driver's command WITH its secondary entries: the launch sizes the line's Align2D / FindMatchDirect / detector / single-pair
 # entries use (their roofline.traffic reads this case)

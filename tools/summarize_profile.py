@@ -20,14 +20,14 @@ ALG = {   # case -> (kernel substring, algorithmic bytes per launch, dispatches 
     "kernels": ("pyrdown_kernel", 2048 * 504000, 3),
     # Optimizer::PoseOptimization, 4096 frames x 200 features per launch (tools/pose_opt_bench.py 4096 200 = bench.py's entry):
     # per feature bearing 24 + map point 24 + level 4 + flag 1 in, residual norm 8 out; per frame the pose in and out + summary
-    "poseopt": ("pose_opt_kernel", 4096 * (200 * 61 + 2 * 96 + 64), 1),
+    "poseopt": ("pose_opt_", 4096 * (200 * 61 + 2 * 96 + 64), 1),
 }
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with open(os.path.join(REPO, "dsdtm_amd", "csrc", "libdsdtm_amd.so"), "rb") as f:
     sha = hashlib.sha256(f.read()).hexdigest()[:16]
 sys.path.insert(0, REPO)
 from dsdtm_amd.csrc import build as hip_build
-stats_rows, pmc = [], {"round": 5, "profile_binary_sha": sha, "profile_source_sha": hip_build.source_sha(), "command": "tools/profile.sh (see the file for every command line)", "cases": {},
+stats_rows, pmc = [], {"round": 6, "profile_binary_sha": sha, "profile_source_sha": hip_build.source_sha(), "command": "tools/profile.sh (see the file for every command line)", "cases": {},
                        "hbm_traffic_per_launch": [], "fp64_per_launch": [], "overlap": {}}
 for case in sorted(os.listdir(src)):
     d = os.path.join(src, case)
@@ -37,7 +37,7 @@ for case in sorted(os.listdir(src)):
         for r in csv.DictReader(open(f)):
             if "dsdtm" not in r["Name"]:
                 continue                              # torch's data-generation kernels are not ours to report
-            if case not in ("track", "poseopt", "kernels", "secondary") and "sparse_align" not in r["Name"]:
+            if case not in ("track", "trackone", "poseopt", "kernels", "secondary") and "sparse_align" not in r["Name"]:
                 continue                              # bench cases: the kernel of record only (pyramids there are set-up)
             stats_rows.append(dict(case=case, kernel=r["Name"], calls=r["Calls"], avg_ns=r["AverageNs"], min_ns=r["MinNs"],
                                    max_ns=r["MaxNs"], total_ns=r["TotalDurationNs"], percent=r["Percentage"]))
