@@ -191,6 +191,28 @@ def test_tracked_sequence_one_call_per_frame_equals_the_four_call_chain(gpu_ctx)
     assert a_log[-1]["n"] >= 40
 
 
+@pytest.mark.parametrize("nf", [600, 1000])
+def test_run_of_a_large_reference_frame_goes_through_the_team_kernel(gpu_ctx, nf):
+    """A last frame with 600 / 1000 features: `Run` inside the one-call frame is spread over 3 / 4 compute units (the team kernel, with
+    its transparent re-run should a partner wait run out) exactly as dsdtm_sparse_align_frames spreads it: same pose, count and
+    iterations, bit for bit; the search and the refinement behind it follow from that pose."""
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    cam, kfs, cur, mps = make_world(17, n_points=1800)
+    ref = kfs[0]
+    assert ref.n_features >= nf
+    bb = ref.bearing[:nf]
+    last = Frame(cam, ref.mvImg_Pyr, ref.Get_Pose())
+    last.set_features(ref.px[:nf], bb, bb * (2.0 / bb[:, 2:3]), np.ones(nf, np.uint8))
+    al = Sprase_ImgAlign(5, 0, 8, ctx=gpu_ctx, resident_frames=True)
+    c4 = Frame(cam, cur.mvImg_Pyr, last.Get_Pose())
+    n4 = al.Run(c4, last)
+    r = tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], 5, last, last.Get_Pose(), (5, 0, 8, 15), 20, kfs, mps[:900])
+    assert r["n_tracked"] == n4 and n4 > nf // 2 and list(r["stats"]["iters"]) == list(al.last_stats["iters"])
+    assert np.array_equal(r["T_run"], c4.Get_Pose())
+    assert len(r["matches"]) > 100 and r["summary"]["n_residual_blocks"] == len(r["matches"])
+    r["frame"].close()
+
+
 def test_lost_frame_skips_search_and_refinement(gpu_ctx):
     """Run's count below Tracking's threshold (src/Tracking.cpp:208: < 20 => Lost): nothing after Run is computed — no matches,
     T_opt = T_run — and the new frame is still handed over."""
