@@ -1978,11 +1978,13 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     if (int rc = dsdtm_pyrdown_batch_device(ctx, f->d, f->pitch, 1, pl.levels, pl.w, pl.h, st, pl.off, stream)) return fail(rc);
 
     // 2. Run(cur, ref) — while the GPU copies and builds the pyramid, the host packs what Run reads
-    memcpy(h + h_bear, d->ref_bearing, nf * 24);
-    memcpy(h + h_pw, d->ref_p_world, nf * 24);
+    if (nf) {
+        memcpy(h + h_bear, d->ref_bearing, nf * 24);
+        memcpy(h + h_pw, d->ref_p_world, nf * 24);
+        memcpy(h + h_px, d->ref_px_xy, nf * 8);
+        memcpy(h + h_ini, d->ref_initial, nf);
+    }
     memcpy(h + h_tr, d->T_ref_w, 96);
-    memcpy(h + h_px, d->ref_px_xy, nf * 8);
-    memcpy(h + h_ini, d->ref_initial, nf);
     // Run() (:34-38): too few features -> 0, the pose untouched. Decided on the host: no launch.
     const bool run = d->n_ref_features >= d->align.min_fts && d->align.max_level - 1 >= d->align.min_level && d->n_ref_features > 0;
     dsdtm_batch_desc b;

@@ -345,10 +345,12 @@ static bool track_frame_packing() {
                 double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
                 dsdtm_track_desc d{};
                 d.image = img.data(); d.width = W; d.height = H; d.stride = W + 3; d.levels = L;
-                d.ref = ref; d.ref_px_xy = px.data(); d.ref_bearing = be.data(); d.ref_p_world = pw.data(); d.ref_initial = ini.data(); d.n_ref_features = n;
+                d.ref = ref; d.n_ref_features = n;
+                if (n) { d.ref_px_xy = px.data(); d.ref_bearing = be.data(); d.ref_p_world = pw.data(); d.ref_initial = ini.data(); }   // (none: NULL columns)
                 d.T_ref_w = T; d.T_seed = T; d.align = params(); d.min_tracked = 0;
-                d.kf = kf; d.n_kf = 2; d.T_kf_w = Tk.data(); d.n_points = M; d.mp_world = mpw.data(); d.mp_found = found.data(); d.mp_bad = bad.data();
-                d.obs_offset = off.data(); d.obs_kf = okf.data(); d.obs_px = opx.data(); d.obs_level = olv.data(); d.obs_bearing = ob.data();
+                d.kf = kf; d.n_kf = 2; d.T_kf_w = Tk.data(); d.n_points = M;
+                if (M) { d.mp_world = mpw.data(); d.mp_found = found.data(); d.mp_bad = bad.data(); d.obs_offset = off.data(); }                // (no points: NULL columns)
+                if (!okf.empty()) { d.obs_kf = okf.data(); d.obs_px = opx.data(); d.obs_level = olv.data(); d.obs_bearing = ob.data(); }
                 if (with_mask) { d.mask = mask.data(); d.mask_stride = W + 1; }
                 d.cell_size = 8; d.max_pyr_levels = L + 1; d.max_matches = 200; d.align2d_iters = 10; d.pose_opt.max_iterations = 100;
                 dsdtm_track_result r;

@@ -255,3 +255,47 @@ def test_argument_checks(gpu_ctx):
         tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], 5, small, cur.Get_Pose(), (5, 0, 8, 15), 0, kfs, mps)
     # and the context still works
     ok()["frame"].close()
+
+
+def test_two_trackers_on_one_gpu_from_two_threads(gpu_ctx):
+    """Live tracking of one sequence is a dependent chain: more throughput = more trackers (replicas), each with its own context
+    (DESIGN §7). Two contexts on device 0 driven from two host threads at once, 12 frames each on worlds of their own: every call
+    returns what the same call returns alone (the contexts share nothing: staging, streams, frame pools, timeout words)."""
+    import threading
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    worlds = []
+    for seed in (31, 32):
+        cam, kfs, cur, mps = make_world(seed, n_points=700)
+        ref = kfs[0]
+        nf = 250
+        bb = ref.bearing[:nf]
+        last = Frame(cam, ref.mvImg_Pyr, ref.Get_Pose())
+        last.set_features(ref.px[:nf], bb, bb * (2.0 / bb[:, 2:3]), np.ones(nf, np.uint8))
+        worlds.append((cam, kfs, cur, mps, last))
+
+    def run(ctx, w, n):
+        cam, kfs, cur, mps, last = w
+        call = tracking.TrackCall(ctx, cam, cur.mvImg_Pyr[0], 5, last, last.Get_Pose(), (5, 0, 8, 15), 20, kfs, mps)
+        out = []
+        for _ in range(n):
+            r = call.run()
+            out.append((r["T_run"].copy(), r["n_tracked"], r["matches"].copy(), r["T_opt"].copy(), r["summary"]["iterations"]))
+            r["frame"].close()
+        return out
+
+    alone = [run(gpu_ctx, w, 1)[0] for w in worlds]
+    ctxs = [capi.Context(0), capi.Context(0)]
+    res = [None, None]
+    th = [threading.Thread(target=lambda k=k: res.__setitem__(k, run(ctxs[k], worlds[k], 12))) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert res[k] is not None and len(res[k]) == 12
+        for T_run, n, m, T_opt, its in res[k]:
+            assert np.array_equal(T_run, alone[k][0]) and n == alone[k][1] and np.array_equal(m, alone[k][2])
+            assert np.array_equal(T_opt, alone[k][3]) and its == alone[k][4]
+        assert len(alone[k][2]) > 60
+    for c in ctxs:
+        c.close()
