@@ -1161,6 +1161,10 @@ def main():
     rank_checks = None
     if world > 1 and args.rank_check_pairs > 0:
         n_chk = max(1, min(args.rank_check_pairs, args.pairs))
+        if rank == 0:                         # the checker's library is (re)built by ONE rank if it is stale, never by all of them at once
+            from tests import oracle_lib
+            oracle_lib.load()
+        barrier()
         mine = rank_parity(d, cam_struct, prm, n_chk, max(1, usable_cpus() // world))
         rank_checks = shard.gather_over_ranks(mine, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
 

@@ -611,7 +611,8 @@ hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream) {
         // four frames at once)
         // — as many frames per wave as still leave every wave slot of the GPU (256 CUs x 4 SIMDs x 2 waves) a wave: a wave's
         // chain gets longer with every frame it carries, which only pays while the machine stays full (4096 x 200: one frame per
-        // wave 0.706 ms, two 0.6 ms, four 0.648 ms — half the slots empty; 16 384 x 200: 2.37 / - / 1.67 ms)
+        // wave 0.706 ms, two 0.541 ms, four 0.648 ms — half the slots empty; 16 384 x 200: 2.37 / - / 1.67 ms; two frames per wave at ONE
+        // wave per SIMD, which features in LDS would need: 0.868 ms)
         const int slots = 256 * 4 * PO_WAVES_PER_EU;
         const int gpw = args.force_variant == 4 ? 4 : (args.n_frames >= 4 * slots ? 4 : (args.n_frames >= 2 * slots ? 2 : 1));
         if (gpw == 4) { hipLaunchKernelGGL(pose_opt_rows_kernel<4>, dim3((unsigned)((args.n_frames + 3) / 4)), dim3(64), 0, stream, args); return hipGetLastError(); }
