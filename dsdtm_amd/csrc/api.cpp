@@ -1919,8 +1919,11 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = align_up(o + bytes, 256); return at; };
     const size_t h_img = take(img);
+    // (Run's range: what it reads, then its in/out pose, count and statistics — moved to the device in one piece, see below)
+    const size_t h_run = o;
     const size_t h_bear = take(nf * 24), h_pw = take(nf * 24), h_tr = take(96), h_px = take(nf * 8), h_ini = take(nf);
     const size_t h_T = take(96), h_nt = take(4), h_st = take(sizeof(dsdtm_align_stats));
+    const size_t run_bytes = o - h_run, run_out_bytes = o - h_T;
     // (the local map and the mask: one contiguous range, copied to the device in one piece)
     const size_t h_map = o;
     const size_t h_mask = take(d->mask ? img : 0);
@@ -1932,10 +1935,10 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     const size_t h_total = o;
     // ---- device scratch ----
     o = 0;
-    const size_t g_map = take(map_bytes), g_T = take(96), g_pw = take(Mz * 24), g_cell = take(Mz * 4),
+    const size_t g_run = take(run_bytes), g_map = take(map_bytes), g_pw = take(Mz * 24), g_cell = take(Mz * 4),
                  g_px0 = take(Mz * 16), g_px = take(Mz * 16), g_ck = take(Mz * 4), g_cf = take(Mz * 4), g_rp = take(Mz * 8),
                  g_rl = take(Mz * 4), g_rb = take(Mz * 24), g_ib = take(Mz), g_sl = take(Mz * 4), g_cv = take(Mz),
-                 g_pob = take(MM * 24), g_pow = take(MM * 24), g_pol = take(MM * 4), g_pou = take(MM), g_pon = take(4);
+                 g_pob = take(MM * 24), g_pow = take(MM * 24), g_pol = take(MM * 4), g_pou = take(MM), g_pon = take(4), g_Topt = take(96);
     const size_t g_total = o;
     if (int rc = ensure_stage(ctx, h_total > g_total ? h_total : g_total)) return rc;
     uint8_t* h = (uint8_t*)ctx->h_pinned;
@@ -1959,25 +1962,29 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
         if (e_ != hipSuccess) { set_err(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return fail(DSDTM_ERR_HIP); } \
     } while (0)
 
-    // 1. the new frame: level 0 crosses the link, the pyramid is built on the device (src/Frame.cpp:35-41, :74-81)
-    // (an image the caller keeps in pinned memory — hipHostMalloc / hipHostRegister, e.g. the capture buffer — goes up straight
-    // from there; anything else is staged through the context's pinned block first: 15 us of host memcpy for 640x480)
+    // 1. the new frame: level 0 crosses the link, the pyramid is built on the device (src/Frame.cpp:35-41, :74-81); with it
+    //    what Run(cur, ref) reads and its in/out pose: ONE kernel (ingest_kernel, pyrdown.hip) on the compute stream reads both
+    //    from host-mapped pinned memory — no copy operation in front of the first kernel (the hand-over from the copy engine
+    //    costs 7-8 us), and Run reads its 57 bytes per feature from HBM instead of over the link.
+    // (an image the caller keeps in pinned memory — hipHostMalloc / hipHostRegister, e.g. the capture buffer — is read straight
+    // from there; anything else is staged through the context's pinned block first: 5-15 us of host memcpy for 640x480)
     bool pinned_image = false;
     if (d->stride == d->width) {
         hipPointerAttribute_t pa_;
         if (hipPointerGetAttributes(&pa_, d->image) == hipSuccess) pinned_image = pa_.type == hipMemoryTypeHost;
         else (void)hipGetLastError();                  // (an ordinary host pointer: not an error)
     }
-    if (pinned_image) {
-        TRACK_TRY(hipMemcpyAsync(f->d, d->image, img, hipMemcpyHostToDevice, stream));
-    } else {
+    const void* img_dev = nullptr;                     // the image as the device sees it in host memory
+    if (pinned_image && !(((size_t)d->image) & 15)) {
+        void* p_ = nullptr;
+        if (hipHostGetDevicePointer(&p_, (void*)d->image, 0) == hipSuccess) img_dev = p_;
+        else (void)hipGetLastError();
+    }
+    if (!pinned_image) {
         if (d->stride == d->width) memcpy(h + h_img, d->image, img);
         else for (int y = 0; y < d->height; ++y) memcpy(h + h_img + (size_t)y * d->width, d->image + (size_t)y * d->stride, (size_t)d->width);
-        TRACK_TRY(hipMemcpyAsync(f->d, h + h_img, img, hipMemcpyHostToDevice, stream));
+        img_dev = hd + h_img;
     }
-    if (int rc = dsdtm_pyrdown_batch_device(ctx, f->d, f->pitch, 1, pl.levels, pl.w, pl.h, st, pl.off, stream)) return fail(rc);
-
-    // 2. Run(cur, ref) — while the GPU copies and builds the pyramid, the host packs what Run reads
     if (nf) {
         memcpy(h + h_bear, d->ref_bearing, nf * 24);
         memcpy(h + h_pw, d->ref_p_world, nf * 24);
@@ -1985,17 +1992,31 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
         memcpy(h + h_ini, d->ref_initial, nf);
     }
     memcpy(h + h_tr, d->T_ref_w, 96);
+    auto seed_run = [&]() {
+        memcpy(h + h_T, d->T_seed, 96);                              // cur->Set_Pose(last->Get_Pose()) (src/Tracking.cpp:201)
+        memset(h + h_nt, 0, 4); memset(h + h_st, 0, sizeof(dsdtm_align_stats));
+    };
+    seed_run();
+    if (img_dev) TRACK_TRY(ingest_launch(img_dev, f->d, img, hd + h_run, g + g_run, run_bytes, stream));
+    else {      // (a pinned image the device cannot address, or one that is not 16-byte aligned: the copy engine)
+        TRACK_TRY(hipMemcpyAsync(f->d, pinned_image ? (const void*)d->image : (const void*)(h + h_img), img, hipMemcpyHostToDevice, stream));
+        TRACK_TRY(ingest_launch(nullptr, nullptr, 0, hd + h_run, g + g_run, run_bytes, stream));
+    }
+    if (int rc = dsdtm_pyrdown_batch_device(ctx, f->d, f->pitch, 1, pl.levels, pl.w, pl.h, st, pl.off, stream)) return fail(rc);
+
+    // 2. Run(cur, ref) on the device copy of its range
     // Run() (:34-38): too few features -> 0, the pose untouched. Decided on the host: no launch.
     const bool run = d->n_ref_features >= d->align.min_fts && d->align.max_level - 1 >= d->align.min_level && d->n_ref_features > 0;
+    uint8_t* const gr = g + g_run - h_run;              // device address of the pinned block's offset X inside Run's range: gr + X
     dsdtm_batch_desc b;
     memset(&b, 0, sizeof b);
     b.n_pairs = 1; b.max_features = d->n_ref_features; b.levels = pl.levels;
     for (int l = 0; l < pl.levels; ++l) { b.width[l] = pl.w[l]; b.height[l] = pl.h[l]; b.stride[l] = pl.w[l]; b.level_offset[l] = pl.off[l]; }
     b.pyr_pitch = d->ref->pitch;
     b.ref_pyr = d->ref->d; b.cur_pyr = f->d;
-    b.px_xy = (const float*)(hd + h_px); b.bearing = (const double*)(hd + h_bear); b.p_world = (const double*)(hd + h_pw);
-    b.initial = hd + h_ini; b.T_ref_w = (const double*)(hd + h_tr); b.T_cur_w = (double*)(hd + h_T);
-    b.n_tracked = (int32_t*)(hd + h_nt); b.stats = (dsdtm_align_stats*)(hd + h_st);
+    b.px_xy = (const float*)(gr + h_px); b.bearing = (const double*)(gr + h_bear); b.p_world = (const double*)(gr + h_pw);
+    b.initial = gr + h_ini; b.T_ref_w = (const double*)(gr + h_tr); b.T_cur_w = (double*)(gr + h_T);
+    b.n_tracked = (int32_t*)(gr + h_nt); b.stats = (dsdtm_align_stats*)(gr + h_st);
     if (d->ref->pitch != f->pitch) { set_err(ctx, "track: pyramid pitches differ"); return fail(DSDTM_ERR_INVALID); }
 
     // 3. the local map, packed once (the retry below re-uses it)
@@ -2018,7 +2039,8 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
 
     TrackArgs t;
     memset(&t, 0, sizeof t);
-    t.T_run = (const double*)(hd + h_T); t.n_tracked = (const int32_t*)(hd + h_nt); t.min_tracked = d->min_tracked;
+    t.T_run = (const double*)(gr + h_T); t.n_tracked = (const int32_t*)(gr + h_nt); t.min_tracked = d->min_tracked;
+    t.run_out_dev = gr + h_T; t.run_out_host = hd + h_T; t.run_out_n16 = (int)(run_out_bytes / 16);
     const uint8_t* gm = g + g_map - h_map;                // the device copy of the map range: same offsets as in the pinned block
     t.T_kf_w = (const double*)(gm + h_Tkf); t.kf_ptrs = (const uint8_t* const*)(gm + h_kfp); t.n_kf = d->n_kf;
     t.mp_world = (const double*)(gm + h_mpw); t.mp_found = (const int32_t*)(gm + h_found); t.mp_bad = gm + h_bad; t.n_points = M;
@@ -2028,18 +2050,17 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     t.fx = cam->fx; t.fy = cam->fy; t.cx = cam->cx; t.cy = cam->cy; t.width = cam->width; t.height = cam->height; t.levels = pl.levels;
     t.cell_size = d->cell_size; t.grid_cols = grid_cols; t.grid_rows = grid_rows; t.max_matches = d->max_matches;
     track_disc_half_widths(d->cell_size, t.disc_hw);
-    t.d_T = (double*)(g + g_T);
     t.pw = (double*)(g + g_pw); t.cell = (int32_t*)(g + g_cell); t.px0 = (double*)(g + g_px0); t.px = (double*)(g + g_px);
     t.cand_kf = (int32_t*)(g + g_ck); t.cand_frame = (int32_t*)(g + g_cf); t.ref_px = (float*)(g + g_rp); t.ref_level = (int32_t*)(g + g_rl);
     t.ref_bearing = (double*)(g + g_rb); t.init_blocked = g + g_ib; t.search_level = (int32_t*)(g + g_sl); t.converged = g + g_cv;
-    t.matches = (dsdtm_track_match*)(hd + h_match); t.counts = (int32_t*)(hd + h_cnt); t.T_opt = (double*)(hd + h_Topt);
+    t.matches = (dsdtm_track_match*)(hd + h_match); t.counts = (int32_t*)(hd + h_cnt); t.T_opt = (double*)(g + g_Topt);
     t.po_bearing = (double*)(g + g_pob); t.po_world = (double*)(g + g_pow); t.po_level = (int32_t*)(g + g_pol); t.po_use = g + g_pou;
     t.po_n = (int32_t*)(g + g_pon);
 
     WarpKernelArgs wa;
     memset(&wa, 0, sizeof wa);
     for (int l = 0; l < pl.levels; ++l) { wa.lv[l].w = pl.w[l]; wa.lv[l].h = pl.h[l]; wa.lv[l].stride = pl.w[l]; wa.lv[l].off = (uint32_t)pl.off[l]; }
-    wa.kf_ptrs = t.kf_ptrs; wa.T_kf_w = t.T_kf_w; wa.T_cur_w_arr = t.d_T; wa.cand_frame = t.cand_frame;
+    wa.kf_ptrs = t.kf_ptrs; wa.T_kf_w = t.T_kf_w; wa.T_cur_w_arr = t.T_run; wa.cand_frame = t.cand_frame;
     wa.cand_kf = t.cand_kf; wa.ref_px = t.ref_px; wa.ref_level = t.ref_level; wa.ref_bearing = t.ref_bearing; wa.p_world = t.pw;
     wa.search_level = t.search_level; wa.m = M; wa.n_kf = d->n_kf; wa.max_search_level = max_search_level; wa.levels = pl.levels;
     wa.n_frames = 1; wa.fx = cam->fx; wa.fy = cam->fy; wa.cx = cam->cx; wa.cy = cam->cy; wa.no_xcd = options().fmd_no_xcd;
@@ -2052,7 +2073,7 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     PoseOptArgs pa;
     pa.n_frames = 1; pa.max_features = d->max_matches; pa.max_iterations = d->pose_opt.max_iterations;
     pa.n_features = t.po_n; pa.bearing = t.po_bearing; pa.p_world = t.po_world; pa.level = t.po_level; pa.use = t.po_use;
-    pa.T_cur_w = t.T_opt; pa.residual_norm = (double*)(hd + h_rn); pa.summary = (dsdtm_pose_opt_summary*)(hd + h_sm);
+    pa.T_cur_w = t.T_opt; pa.T_mirror = (double*)(hd + h_Topt); pa.residual_norm = (double*)(hd + h_rn); pa.summary = (dsdtm_pose_opt_summary*)(hd + h_sm);
 
     volatile unsigned* h_flag = ctx->h_flags + dsdtm_ctx::FLAG_SINGLE;
     *h_flag = 0;
@@ -2060,8 +2081,10 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     mode.single = true;
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool multi_cu = false;
-        memcpy(h + h_T, d->T_seed, 96);                              // cur->Set_Pose(last->Get_Pose()) (src/Tracking.cpp:201)
-        memset(h + h_nt, 0, 4); memset(h + h_st, 0, sizeof(dsdtm_align_stats));
+        if (attempt) {                                               // once more: Run's range again, from the seed
+            seed_run();
+            TRACK_TRY(ingest_launch(nullptr, nullptr, 0, hd + h_run, g + g_run, run_bytes, stream));
+        }
         memset(h + h_cnt, 0, 64); memset(h + h_sm, 0, sizeof(dsdtm_pose_opt_summary));
         if (run) { if (int rc = launch_batch(ctx, &b, cam, &d->align, stream, mode, &multi_cu)) return fail(rc); }
         if (!packed_map) {
@@ -2078,8 +2101,7 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
         // 4. ReprojectPoint + Get_ClosetObs for every point; FindMatchDirect for every point that passed; the cell walk; the
         //    features of the matches; PoseOptimization on them — the instantiation picked on the device by the match count,
         //    as dsdtm_pose_optimization picks it on the host (same arithmetic, same bits as the four-call chain)
-        TRACK_TRY(track_reproject_launch(t, stream));
-        TRACK_TRY(match_launch(wa, aa, stream));
+        TRACK_TRY(track_match_launch(t, wa, aa, stream));
         TRACK_TRY(track_replay_launch(t, stream));
         pa.force_variant = 3;                                      // one wave / four waves by the match count, chosen by the kernel
         TRACK_TRY(pose_opt_launch(pa, stream));

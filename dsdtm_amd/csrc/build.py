@@ -28,7 +28,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.cpp", "sparse_align.hip", "align2d.hip", "pyrdown.hip", "warp.hip", "match.hip", "detect.hip", "pose_opt.hip", "track.hip"]
 DIAG_SOURCES = ["selftest.hip"]                      # diagnostic build only
-HEADERS = ["kernels.h", "device_math.h", "warp_body.h", "align2d_body.h", "exports.map", os.path.join("..", "..", "include", "dsdtm_amd.h")]
+HEADERS = ["kernels.h", "device_math.h", "warp_body.h", "align2d_body.h", "match_body.h", "exports.map", os.path.join("..", "..", "include", "dsdtm_amd.h")]
 OUT = os.path.join(HERE, "libdsdtm_amd.so")
 OUT_DIAG = os.path.join(HERE, "libdsdtm_amd_diag.so")
 TAG = OUT + ".tag"

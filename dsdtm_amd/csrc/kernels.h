@@ -138,6 +138,9 @@ hipError_t pyrdown_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int sw, 
 hipError_t pyrdown_fused_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, int levels, const int* w, const int* h,
                                 const int* stride, const size_t* off, int band, hipStream_t stream, bool* launched);
 
+// host-mapped pinned memory -> device by a kernel (a frame's level 0 + one small second range; see pyrdown.hip)
+hipError_t ingest_launch(const void* src, void* dst, size_t bytes, const void* src2, void* dst2, size_t bytes2, hipStream_t stream);
+
 // Warp prelude: groups of 2 / 64 candidates per 128-thread workgroup (lane = candidate for the FP64 chain, thread = sample for the patches).
 struct WarpKernelArgs {
     const uint8_t* kf_pyr;        // n_kf packed pyramids, pitch kf_pitch ...
@@ -184,13 +187,17 @@ struct PoseOptArgs {
     int only_lo = 0, only_hi = 0;
     int force_variant = 0;         // 0: by n_frames / max_features; 1: one wave per frame; 2: four waves, features in registers (<= 256);
                                    // 3: 1 or 2 by the frame's live count on the device (dsdtm_track_frame)
+    double* T_mirror = nullptr;    // optional, n_frames x 12: the refined pose once more (dsdtm_track_frame: T_cur_w in device memory — the
+                                   // kernel does not start with a read over the link — and the caller's pinned block here)
 };
 hipError_t pose_opt_launch(const PoseOptArgs& args, hipStream_t stream);
 
 // One tracked frame in one submission (track.hip): what sits between Run, FindMatchDirect and the pose refinement.
 struct TrackArgs {
-    // from Run (host-mapped: the alignment kernel of a single pair writes its results there)
+    // from Run (device memory). The caller reads pose, count and statistics in its pinned block: block 0 of the fused
+    // reprojection + FindMatchDirect kernel forwards them there (run_out_n16 x 16 bytes; posted writes — nothing on the device waits for the link)
     const double* T_run; const int32_t* n_tracked; int min_tracked;
+    const void* run_out_dev; void* run_out_host; int run_out_n16;
     // the local map as the caller flattened it (device memory: copied up on a second stream while Run runs)
     const double* T_kf_w; const uint8_t* const* kf_ptrs; int n_kf;
     const double* mp_world; const int32_t* mp_found; const uint8_t* mp_bad; int n_points;
@@ -200,15 +207,16 @@ struct TrackArgs {
     int cell_size, grid_cols, grid_rows, max_matches;
     int8_t disc_hw[128];                              // cv::circle's row half-widths for radius cell_size (track_disc_half_widths)
     // device scratch: the columns the FindMatchDirect kernel reads / writes (candidate = map point)
-    double* d_T;
     double* pw; int32_t* cell; double* px0; double* px; int32_t* cand_kf; int32_t* cand_frame; float* ref_px; int32_t* ref_level;
     double* ref_bearing; uint8_t* init_blocked; int32_t* search_level; uint8_t* converged;
     // outputs of the replay: the match list and counts (host-mapped), the pose refinement's feature columns (device)
     dsdtm_track_match* matches; int32_t* counts;      // counts: [0] points in the grid, [1] matches, [2] 1 = the full scan ran
-    double* T_opt;                                    // host-mapped: the pose refinement's in/out pose, seeded with T_run
+    double* T_opt;                                    // device: the pose refinement's in/out pose, seeded with T_run
     double* po_bearing; double* po_world; int32_t* po_level; uint8_t* po_use; int32_t* po_n;
 };
-hipError_t track_reproject_launch(const TrackArgs& args, hipStream_t stream);
+// reprojection of every local map point + FindMatchDirect for it (wa / aa: the fused FindMatchDirect kernel's arguments over the
+// candidate columns of `args`)
+hipError_t track_match_launch(const TrackArgs& args, const WarpKernelArgs& wa, const A2DKernelArgs& aa, hipStream_t stream);
 hipError_t track_replay_launch(const TrackArgs& args, hipStream_t stream);
 size_t track_replay_lds_bytes(int n_points, int n_cells, int radius);
 void track_disc_half_widths(int radius, int8_t* hw);   // radius <= 127

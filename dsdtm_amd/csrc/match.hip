@@ -18,26 +18,19 @@
 
 #pragma clang fp contract(off)      // file scope: the FP64 chain of warp_body.h and the float sums of align2d_body.h
 
-#include "warp_body.h"
-#include "align2d_body.h"
+#include "match_body.h"
 
 namespace dsdtm {
 
-constexpr int MATCH_G = 16;         // candidates per Align2D round of a 256-thread group (= features per group of align2d_rows_kernel<4>)
-
 // CH = candidates per workgroup (a multiple of MATCH_G, at most 64): phase 1 runs once for all of them — CH lanes of the first
-// wavefront, one FP64 chain each — then phases 2 and 3 go through them MATCH_G at a time. Measured (tools/fmd_bench.py,
-// 51 200 candidates / one frame's 816): CH = 16: 62.4 / 17.2 us; 32: 65.3 / 26.2 us; 64: 70.7 / 43.4 us (the two-kernel path:
-// 64.8 / 18.2 us) — the rounds, not the chain, are what a workgroup spends its time on, and amortising the chain only
-// serialises them. CH = 16 is the product shape; the others stay behind DSDTM_MATCH_GROUP for the record.
+// wavefront, one FP64 chain each — then phases 2 and 3 go through them MATCH_G at a time (match_body.h). Measured
+// (tools/fmd_bench.py, 51 200 candidates / one frame's 816): CH = 16: 62.4 / 17.2 us; 32: 65.3 / 26.2 us; 64: 70.7 / 43.4 us (the
+// two-kernel path: 64.8 / 18.2 us) — the rounds, not the chain, are what a workgroup spends its time on, and amortising the chain
+// only serialises them. CH = 16 is the product shape; the others stay behind DSDTM_MATCH_GROUP for the record.
 template <int CH>
 __global__ __launch_bounds__(256) void match_kernel(const WarpKernelArgs a, const A2DKernelArgs b) {
     static_assert(CH % MATCH_G == 0 && CH <= 64, "candidates per workgroup");
-    __shared__ WarpCand s_c[CH];
-    __shared__ int s_sl[CH];                                            // search level of the group's candidates (-1: rejected)
-    __shared__ __attribute__((aligned(16))) uint8_t s_pb[MATCH_G * 100];
-    __shared__ __attribute__((aligned(16))) uint8_t s_pp[MATCH_G * 64];
-    __shared__ __attribute__((aligned(16))) float s_prod[MATCH_G][192];
+    __shared__ MatchShared<CH> sh;
     // XCD-aware block numbering (workgroups go to the 8 XCDs round-robin, each XCD has its own L2): every XCD takes a contiguous
     // range of candidate groups, i.e. of current frames / keyframes, instead of every eighth group of every frame — each
     // frame's images are then fetched by one L2 instead of by all eight. The work per group is uniform, so the ranges balance.
@@ -50,40 +43,11 @@ __global__ __launch_bounds__(256) void match_kernel(const WarpKernelArgs a, cons
     const int tid = threadIdx.x;
     const int nb = a.m - cb < CH ? a.m - cb : CH;
     if (tid < nb) {
-        s_c[tid] = warp_candidate(a, cb + tid);
-        s_sl[tid] = a.search_level[cb + tid];                           // written by warp_candidate (this thread)
+        sh.c[tid] = warp_candidate(a, cb + tid);
+        sh.sl[tid] = a.search_level[cb + tid];                          // written by warp_candidate (this thread)
     }
     __syncthreads();
-    constexpr int PPL = 4, LPF = 64 / PPL, FPW = 64 / LPF;
-    const int lane = tid & 63;
-    const int slot = (tid >> 6) * FPW + lane / LPF, l = lane % LPF;
-    for (int sub = 0; sub < CH && sub < nb; sub += MATCH_G) {
-        const int c0 = cb + sub;
-        const int ng = nb - sub < MATCH_G ? nb - sub : MATCH_G;
-        warp_samples<256>(s_c + sub, ng, tid, s_pb, s_pp);
-        __syncthreads();
-        // ---- Align2DGaussNewton (:318-417) on the patches in LDS; candidate = slot of the round ----
-        const int f = c0 + slot;
-        const bool exists = slot < ng;
-        const int lvl = exists ? s_sl[sub + slot] : -1;
-        const int fr = (exists && b.frame) ? b.frame[f] : 0;
-        const bool valid = exists && !(lvl < 0 || lvl >= b.levels || fr < 0 || (b.frame && fr >= b.n_frames));
-        if (exists && !valid && l == 0) b.converged[f] = 0;             // rejected candidate: "not converged", pixel untouched
-        const LevelGeom lg = b.lv[valid ? lvl : 0];
-        const uint8_t* __restrict__ img = b.cur_pyr + (size_t)fr * b.pyr_pitch + lg.off;
-        const double lscale = (b.px_level0 && valid) ? (double)(1 << lvl) : 1.0;
-        float u, v;
-        bool converged;
-        align2d_rows_feature<PPL>(valid, img, lg, lg.stride * lg.h, (const uint8_t*)(s_pb + (exists ? slot : 0) * 100),
-                                  (const uint8_t*)(s_pp + (exists ? slot : 0) * 64), s_prod[slot],
-                                  valid ? b.px_xy[2 * (size_t)f] : 0.0, valid ? b.px_xy[2 * (size_t)f + 1] : 0.0, lscale, b.max_iters, lane, u, v, converged);
-        if (valid && l == 0) {
-            b.px_xy[2 * (size_t)f] = (double)u * lscale;                // :414 always written back (:154-156 back to level 0)
-            b.px_xy[2 * (size_t)f + 1] = (double)v * lscale;
-            b.converged[f] = converged ? 1 : 0;
-        }
-        if (CH > MATCH_G) __syncthreads();                              // the next round overwrites the patches
-    }
+    match_rounds<CH>(a, b, sh, cb, nb, tid);
 }
 
 hipError_t match_launch(const WarpKernelArgs& wa, const A2DKernelArgs& aa, hipStream_t stream) {

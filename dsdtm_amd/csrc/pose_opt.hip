@@ -548,6 +548,12 @@ __device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
         Tio[0] = R[0]; Tio[1] = R[1]; Tio[2] = R[2];  Tio[3] = Tf.tx;
         Tio[4] = R[3]; Tio[5] = R[4]; Tio[6] = R[5];  Tio[7] = Tf.ty;
         Tio[8] = R[6]; Tio[9] = R[7]; Tio[10] = R[8]; Tio[11] = Tf.tz;
+        if (a.T_mirror) {
+            double* Tm = a.T_mirror + (size_t)frame * 12;
+            Tm[0] = R[0]; Tm[1] = R[1]; Tm[2] = R[2];  Tm[3] = Tf.tx;
+            Tm[4] = R[3]; Tm[5] = R[4]; Tm[6] = R[5];  Tm[7] = Tf.ty;
+            Tm[8] = R[6]; Tm[9] = R[7]; Tm[10] = R[8]; Tm[11] = Tf.tz;
+        }
         dsdtm_pose_opt_summary& sm = a.summary[frame];
         sm.iterations = iterations;
         sm.successful_steps = successful;

@@ -286,8 +286,11 @@ __device__ __forceinline__ void pf_stage(const uint8_t* __restrict__ src, int ss
     }
 }
 
-template <int K>     // K = number of downsampling steps (levels - 1), 2..4
-__global__ __launch_bounds__(256) void pyrdown_fused_kernel(const PyrFusedArgs a) {
+// NT = threads per workgroup, RG = output rows per task of the level-0 stage. Batches: 256 threads, 8 rows (every input row
+// loaded once per 2..3 outputs — HBM traffic). A single frame (dsdtm_track_frame: 15 bands on 15 of 256 compute units) is
+// bound by how long ONE workgroup takes for its chain of stages, not by traffic: 1024 threads and short tasks.
+template <int K, int NT = 256, int RG = PF_ROWS_G>     // K = number of downsampling steps (levels - 1), 2..4
+__global__ __launch_bounds__(NT) void pyrdown_fused_kernel(const PyrFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pf_lds[];
     int img, band;
     pd_block(img, band);
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void pyrdown_fused_kernel(const PyrFusedArgs a
     }
     uint8_t* __restrict__ base = a.pyr + (size_t)img * a.pyr_pitch;
     // level 0 (HBM) -> level 1 (LDS + owned rows)
-    pf_stage<false, true, PF_ROWS_G>(base + a.off[0], a.stride[0], 0, a.w[0], a.h[0], lo[1], hi[1], a.w[1],
+    pf_stage<false, true, RG>(base + a.off[0], a.stride[0], 0, a.w[0], a.h[0], lo[1], hi[1], a.w[1],
                           pf_lds + a.lds_off[1], a.lds_stride[1], base + a.off[1], a.stride[1], olo[1], ohi[1]);
     __syncthreads();
 #pragma unroll
@@ -344,7 +347,8 @@ hipError_t pyrdown_fused_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, in
         int nb = (want_groups + n_images - 1) / n_images;
         nb = nb < 4 ? 4 : nb;
         band = (h[K] + nb - 1) / nb;
-        if (band < 2) band = 2;
+        const int min_band = (long long)n_images * h[K] <= 256 ? 1 : 2;      // a single frame: one workgroup per row of the coarsest level
+        if (band < min_band) band = min_band;
     }
     if (band > h[K]) band = h[K];
     size_t lds = 0;
@@ -373,11 +377,46 @@ hipError_t pyrdown_fused_launch(uint8_t* pyr, size_t pyr_pitch, int n_images, in
         PyrFusedArgs b = a;
         b.pyr = pyr + (size_t)i0 * pyr_pitch;
         const dim3 grid((unsigned)a.n_bands, 1u, (unsigned)nz);
+        if (K == 4 && (long long)a.n_bands * nz <= 256) {      // fewer workgroups than compute units: what counts is one workgroup's chain
+            // (one 640x480 frame, 5 levels, same box: 256 threads x 8 rows 10.8 us; 1024 x 2: 9.9; 1024 x 4: 9.9; 512 x 2: 10.8;
+            //  1024 x 1: 10.3; 1024 x 2 with bands of one row: 9.4)
+            hipLaunchKernelGGL((pyrdown_fused_kernel<4, 1024, 2>), grid, dim3(1024), lds, stream, b);
+            continue;
+        }
         if (K == 2) hipLaunchKernelGGL(pyrdown_fused_kernel<2>, grid, dim3(256), lds, stream, b);
         else if (K == 3) hipLaunchKernelGGL(pyrdown_fused_kernel<3>, grid, dim3(256), lds, stream, b);
         else hipLaunchKernelGGL(pyrdown_fused_kernel<4>, grid, dim3(256), lds, stream, b);
     }
     *launched = true;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// A new frame's level 0 (and a second, small range: what Run reads) from HOST-MAPPED pinned memory to the device, by a
+// kernel on the compute stream instead of a copy operation in front of it. For one 640x480 frame the copy engine is not
+// slower at moving the bytes (8 us) — what costs is the hand-over from the copy engine to the compute queue: the first
+// kernel behind a copy starts 7-8 us after the copy's end (rocprofv3 --memory-copy-trace, profiles/r06_track_frame.txt),
+// while a kernel behind a kernel starts at once. Every lane moves 16 bytes; 75 workgroups keep 300 KB of reads in
+// flight over the link.
+typedef unsigned int ingest_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ingest_kernel(const ingest_u32x4* __restrict__ src, ingest_u32x4* __restrict__ dst, unsigned n16,
+                                                     const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, unsigned n_tail,
+                                                     const ingest_u32x4* __restrict__ src2, ingest_u32x4* __restrict__ dst2, unsigned n16_2) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) dst[i] = __builtin_nontemporal_load(src + i);
+    else if (i - n16 < n16_2) dst2[i - n16] = __builtin_nontemporal_load(src2 + (i - n16));
+    if (i < n_tail) dst_tail[i] = src_tail[i];
+}
+
+hipError_t ingest_launch(const void* src, void* dst, size_t bytes, const void* src2, void* dst2, size_t bytes2, hipStream_t stream) {
+    // src, dst 16-byte aligned; bytes2 a multiple of 16 (the caller's pinned block and device scratch: 256-byte sections)
+    if ((((size_t)src | (size_t)dst | (size_t)src2 | (size_t)dst2) & 15) || (bytes2 & 15) || bytes >= (1ull << 35) || bytes2 >= (1ull << 35))
+        return hipErrorInvalidValue;
+    const unsigned n16 = (unsigned)(bytes / 16), n_tail = (unsigned)(bytes & 15), n16_2 = (unsigned)(bytes2 / 16);
+    const unsigned total = n16 + n16_2 > n_tail ? n16 + n16_2 : n_tail;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(ingest_kernel, dim3((total + 255u) / 256u), dim3(256), 0, stream, (const ingest_u32x4*)src, (ingest_u32x4*)dst, n16,
+                       (const uint8_t*)src + (size_t)n16 * 16, (uint8_t*)dst + (size_t)n16 * 16, n_tail, (const ingest_u32x4*)src2, (ingest_u32x4*)dst2, n16_2);
     return hipGetLastError();
 }
 

@@ -25,7 +25,9 @@
 
 #include "kernels.h"
 
-#pragma clang fp contract(off)      // the reprojection follows the host layer's operation order (dsdtm_host.hpp), no FMA
+#pragma clang fp contract(off)      // the reprojection follows the host layer's operation order (dsdtm_host.hpp), no FMA;
+                                    // file scope: also the FP64 chain of warp_body.h and the float sums of align2d_body.h
+#include "match_body.h"
 
 namespace dsdtm {
 
@@ -49,30 +51,18 @@ __device__ __forceinline__ void camera_centre(const double* __restrict__ m, doub
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void track_reproject_kernel(const TrackArgs a) {
-    __shared__ double s_T[12];
-    __shared__ int s_lost;
-    const int tid = threadIdx.x;
-    const int i = blockIdx.x * 256 + tid;
-    const bool have = i < a.n_points;
-    // the point's own columns do not depend on the pose: their loads are in flight while the pose crosses the link
-    const size_t ic = have ? (size_t)i : 0;
-    const double P0 = have ? a.mp_world[3 * ic] : 0.0, P1 = have ? a.mp_world[3 * ic + 1] : 0.0, P2 = have ? a.mp_world[3 * ic + 2] : 1.0;
-    const bool bad_in = have ? a.mp_bad[ic] != 0 : true;
-    const int o_lo = have ? a.obs_offset[ic] : 0, o_hi = have ? a.obs_offset[ic + 1] : 0;
-    if (tid < 12) s_T[tid] = a.T_run[tid];                         // (host-mapped: Run wrote it there)
-    if (tid == 12) s_lost = (a.n_tracked[0] < a.min_tracked) ? 1 : 0;
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < 12) { a.d_T[tid] = s_T[tid]; a.T_opt[tid] = s_T[tid]; }      // for the later kernels / the refinement's in-out pose
-    if (!have) return;
+// ReprojectPoint + Get_ClosetObs + the reference-pixel test for map point i with the pose m (3x4, LDS): writes the
+// candidate columns of point i (thread = map point)
+__device__ __forceinline__ void reproject_point(const TrackArgs& a, int i, const double* m, bool lost) {
+    const double P0 = a.mp_world[3 * (size_t)i], P1 = a.mp_world[3 * (size_t)i + 1], P2 = a.mp_world[3 * (size_t)i + 2];
+    const bool bad = a.mp_bad[i] != 0;                             // UpdateLocalMap skips bad points (src/Tracking.cpp:288)
+    const int o_lo = a.obs_offset[i], o_hi = a.obs_offset[i + 1];
     a.pw[3 * (size_t)i] = P0; a.pw[3 * (size_t)i + 1] = P1; a.pw[3 * (size_t)i + 2] = P2;
-    const double* m = s_T;
     // Frame::World2Pixel (src/Frame.cpp:318-323) -> Camera::Camera2Pixel (src/Camera.cpp:167-171)
     const double x = m[0] * P0 + m[1] * P1 + m[2] * P2 + m[3], y = m[4] * P0 + m[5] * P1 + m[6] * P2 + m[7],
                  z = m[8] * P0 + m[9] * P1 + m[10] * P2 + m[11];
     const double u = (double)a.fx * x / z + (double)a.cx, v = (double)a.fy * y / z + (double)a.cy;
-    const bool bad = bad_in;                                       // UpdateLocalMap skips bad points (src/Tracking.cpp:288)
-    const bool in_grid = !s_lost && !bad && in_image(a.width, a.height, u, v, 8, 0);      // ReprojectPoint (:54-69)
+    const bool in_grid = !lost && !bad && in_image(a.width, a.height, u, v, 8, 0);           // ReprojectPoint (:54-69)
     int cell = -1, best = -1, jbest = -1;
     if (in_grid) {
         cell = (int)(v / a.cell_size) * a.grid_cols + (int)(u / a.cell_size);             // :65
@@ -106,8 +96,8 @@ __global__ __launch_bounds__(256) void track_reproject_kernel(const TrackArgs a)
     }
     a.cell[i] = cell;
     a.px0[2 * (size_t)i] = u; a.px0[2 * (size_t)i + 1] = v;
-    a.px[2 * (size_t)i] = u; a.px[2 * (size_t)i + 1] = v;          // in/out of the FindMatchDirect kernel
-    a.cand_kf[i] = best;                                           // -1: rejected by that kernel (search level -1, not converged)
+    a.px[2 * (size_t)i] = u; a.px[2 * (size_t)i + 1] = v;          // in/out of FindMatchDirect
+    a.cand_kf[i] = best;                                           // -1: rejected by FindMatchDirect (search level -1, not converged)
     a.cand_frame[i] = 0;
     if (jbest >= 0) {
         a.ref_px[2 * (size_t)i] = a.obs_px[2 * (size_t)jbest]; a.ref_px[2 * (size_t)i + 1] = a.obs_px[2 * (size_t)jbest + 1];
@@ -123,6 +113,37 @@ __global__ __launch_bounds__(256) void track_reproject_kernel(const TrackArgs a)
     uint8_t blocked = 0;
     if (in_grid && a.mask) blocked = a.mask[(size_t)cv_round(v) * a.mask_stride + cv_round(u)] != 255 ? 1 : 0;
     a.init_blocked[i] = blocked;
+}
+
+// One kernel from Run's pose to the FindMatchDirect results of every local map point: the fused FindMatchDirect kernel
+// (match.hip: 16 candidates per 256-thread group) whose phase-1 lanes first reproject their map point — the candidate columns
+// a lane writes are the ones it reads back in the next statement. (Round 6 first ran the reprojection as a kernel of its own,
+// thread = point: 7.4 us in front of a 13.7-us kernel, most of it the fixed cost of one more dependent launch.)
+__global__ __launch_bounds__(256) void track_match_kernel(const TrackArgs t, const WarpKernelArgs a, const A2DKernelArgs b) {
+    __shared__ MatchShared<MATCH_G> sh;
+    __shared__ double s_T[12];
+    __shared__ int s_lost;
+    unsigned lb = blockIdx.x;
+    {
+        const unsigned q = gridDim.x / 8u;                         // XCD-aware block numbering, as match_kernel
+        if (!a.no_xcd && lb < q * 8u) lb = (lb % 8u) * q + lb / 8u;
+    }
+    const int cb = (int)lb * MATCH_G;
+    const int tid = threadIdx.x;
+    const int nb = t.n_points - cb < MATCH_G ? t.n_points - cb : MATCH_G;
+    if (tid < 12) s_T[tid] = t.T_run[tid];
+    if (tid == 12) s_lost = (t.n_tracked[0] < t.min_tracked) ? 1 : 0;
+    if (lb == 0 && tid >= 64 && tid - 64 < t.run_out_n16)          // Run's pose, count, statistics -> the caller's pinned block
+        ((uint4*)t.run_out_host)[tid - 64] = ((const uint4*)t.run_out_dev)[tid - 64];
+    __syncthreads();
+    if (lb == 0 && tid < 12) t.T_opt[tid] = s_T[tid];              // the refinement's in/out pose starts from Run's
+    if (tid < nb) {
+        reproject_point(t, cb + tid, s_T, s_lost != 0);
+        sh.c[tid] = warp_candidate(a, cb + tid);
+        sh.sl[tid] = a.search_level[cb + tid];                     // written by warp_candidate (this thread)
+    }
+    __syncthreads();
+    match_rounds<MATCH_G>(a, b, sh, cb, nb, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -490,10 +511,11 @@ __global__ __launch_bounds__(NT) void track_replay_kernel(const TrackArgs a) {
     }
 }
 
-hipError_t track_reproject_launch(const TrackArgs& a, hipStream_t stream) {
-    // (at least one workgroup: block 0 also hands pose, keyframe poses and pointers to the later kernels)
-    const int blocks = a.n_points > 0 ? (a.n_points + 255) / 256 : 1;
-    hipLaunchKernelGGL(track_reproject_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+hipError_t track_match_launch(const TrackArgs& t, const WarpKernelArgs& wa, const A2DKernelArgs& aa, hipStream_t stream) {
+    if (wa.m != t.n_points || aa.m != t.n_points || t.run_out_n16 < 0 || t.run_out_n16 > 192) return hipErrorInvalidValue;
+    // (at least one workgroup: block 0 also forwards Run's results and seeds the refinement's pose)
+    const int blocks = t.n_points > 0 ? (t.n_points + MATCH_G - 1) / MATCH_G : 1;
+    hipLaunchKernelGGL(track_match_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, wa, aa);
     return hipGetLastError();
 }
 

@@ -365,6 +365,15 @@ hipError_t pyrdown_launch(uint8_t* pyr, size_t pitch, int n, int sw, int sh, int
     });
     return hipSuccess;
 }
+hipError_t ingest_launch(const void* src, void* dst, size_t bytes, const void* src2, void* dst2, size_t bytes2, hipStream_t stream) {
+    FAIL_POINT("ingest_launch");
+    if ((((size_t)src | (size_t)dst | (size_t)src2 | (size_t)dst2) & 15) || (bytes2 & 15)) return hipErrorInvalidValue;
+    generic("ingest", stream, [=]() {                // (host-mapped pinned memory -> device: both ranges whole)
+        if (bytes) memcpy(dst, src, bytes);
+        if (bytes2) memcpy(dst2, src2, bytes2);
+    });
+    return hipSuccess;
+}
 hipError_t pyrdown_fused_launch(uint8_t*, size_t, int, int, const int*, const int*, const int*, const size_t*, int, hipStream_t, bool* launched) {
     *launched = false;                              // (the per-level launches above cover the same host path)
     return hipSuccess;
@@ -406,18 +415,25 @@ hipError_t pose_opt_launch(const PoseOptArgs& a, hipStream_t stream) {
 }
 size_t track_replay_lds_bytes(int n_points, int n_cells, int radius) { return ((size_t)n_points + 63) / 64 * 64 * 31 + (size_t)n_cells * 8 + (size_t)radius * 2 + 256; }   // (the real layout's size)
 void track_disc_half_widths(int radius, int8_t* hw) { for (int i = 0; i <= radius; ++i) hw[i] = (int8_t)radius; }
-hipError_t track_reproject_launch(const TrackArgs& a, hipStream_t stream) {
-    FAIL_POINT("track_reproject_launch");
-    generic("track_reproject", stream, [=]() {
+hipError_t track_match_launch(const TrackArgs& a, const WarpKernelArgs& wa, const A2DKernelArgs& aa, hipStream_t stream) {
+    FAIL_POINT("track_match_launch");
+    if (wa.m != a.n_points || aa.m != a.n_points) return hipErrorInvalidValue;
+    generic("track_match", stream, [=]() {
         const size_t M = (size_t)a.n_points;
         touch(a.T_run, 96); touch(a.n_tracked, 4); touch(a.T_kf_w, (size_t)a.n_kf * 96); touch(a.kf_ptrs, (size_t)a.n_kf * sizeof(void*));
         touch(a.mp_world, M * 24); touch(a.mp_found, M * 4); touch(a.mp_bad, M); touch(a.obs_offset, (M + 1) * 4);
         const size_t nnz = M ? (size_t)a.obs_offset[M] : 0;
         touch(a.obs_kf, nnz * 4); touch(a.obs_px, nnz * 8); touch(a.obs_level, nnz * 4); touch(a.obs_bearing, nnz * 24);
         touch(a.mask, a.mask ? (size_t)a.mask_stride * a.height : 0);
-        memmove(a.d_T, a.T_run, 96); memmove(a.T_opt, a.T_run, 96);
+        memmove(a.T_opt, a.T_run, 96);
+        memmove(a.run_out_host, a.run_out_dev, (size_t)a.run_out_n16 * 16);      // Run's pose, count, statistics -> the pinned block
         touch_w(a.pw, M * 24); touch_w(a.px0, M * 16); touch_w(a.px, M * 16); touch_w(a.ref_px, M * 8); touch_w(a.ref_bearing, M * 24); touch_w(a.init_blocked, M);
         for (size_t i = 0; i < M; ++i) { a.cell[i] = -1; a.cand_kf[i] = -1; a.cand_frame[i] = 0; a.ref_level[i] = 0; a.init_blocked[i] = 0; }
+        // the FindMatchDirect half over the columns just written
+        if (wa.T_cur_w_arr != a.T_run || wa.cand_kf != a.cand_kf || wa.p_world != a.pw || aa.px_xy != a.px) abort();
+        warp_body(wa);
+        touch(aa.cur_pyr, pyr_bytes(aa.lv)); touch_w(aa.px_xy, M * 16);
+        for (size_t i = 0; i < M; ++i) aa.converged[i] = 1;
     });
     return hipSuccess;
 }
