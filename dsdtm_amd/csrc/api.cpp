@@ -1216,7 +1216,11 @@ extern "C" int dsdtm_frame_create_from_image(dsdtm_ctx* ctx, const uint8_t* leve
     uint8_t* hp = (uint8_t*)ctx->h_pinned;
     if (stride == width) memcpy(hp, level0, (size_t)width * height);
     else for (int y = 0; y < height; ++y) memcpy(hp + (size_t)y * width, level0 + (size_t)y * stride, width);
-    hipError_t e = hipMemcpyAsync(f->d, hp, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream);
+    // level 0 enters through a kernel on the compute stream (ingest_kernel, pyrdown.hip): no copy operation in front of the
+    // pyramid kernel — the hand-over from the copy engine to the compute queue costs more than the 8 us of the copy itself
+    void* hpd = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&hpd, hp, 0);
+    if (e == hipSuccess) e = ingest_launch(hpd, f->d, (size_t)width * height, nullptr, nullptr, 0, ctx->stream);
     int rc = DSDTM_OK;
     if (e == hipSuccess) rc = dsdtm_pyrdown_batch_device(ctx, f->d, f->pitch, 1, levels, pl.w, pl.h, st, pl.off, ctx->stream);
     if (e == hipSuccess && rc == DSDTM_OK) e = hipStreamSynchronize(ctx->stream);

@@ -55,7 +55,9 @@ class TrackCall:
     def __init__(self, ctx: capi.Context, cam, image, levels, last: Frame, T_seed, align, min_tracked, keyframes, map_points,
                  mask=None, cell_size=None, max_pyr_levels=None, max_matches=200, align2d_iters=10, po_iterations=100, flat=None):
         self.ctx = ctx
-        image = np.ascontiguousarray(image, np.uint8)
+        image = np.asarray(image)
+        if image.dtype != np.uint8 or image.ndim != 2 or image.strides[1] != 1 or image.strides[0] < image.shape[1]:
+            image = np.ascontiguousarray(image, np.uint8)      # (a row-strided uint8 view goes down as it is: d.stride)
         cell_size = int(Config.Get("Camera.CellSize") if cell_size is None else cell_size)
         max_pyr_levels = int(Config.Get("Camera.MaxPyraLevels") if max_pyr_levels is None else max_pyr_levels)
         fm = flat if flat is not None else flatten_local_map(keyframes, map_points)

@@ -191,6 +191,55 @@ def test_tracked_sequence_one_call_per_frame_equals_the_four_call_chain(gpu_ctx)
     assert a_log[-1]["n"] >= 40
 
 
+@pytest.mark.parametrize("width,height", [(640, 480), (636, 478)])
+def test_every_way_the_image_can_arrive_gives_the_same_frame(gpu_ctx, width, height):
+    """Level 0 reaches the device on four paths (api.cpp, dsdtm_track_frame step 1): a pageable image is staged through the context's
+    pinned block and read from there by ingest_kernel; a pinned, 16-byte aligned image is read by that kernel straight from the
+    caller's buffer; a pinned image at an odd address goes through the copy engine; a row-strided image is packed row by row first.
+    Same bytes on the device, so the same Run pose, match list and refined pose, bit for bit. 636 x 478: the byte count is not a
+    multiple of 16 (the kernel's byte tail) and the level widths are not multiples of 8 (one pyrDown launch per level)."""
+    import torch
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    cam, kfs, cur, mps = make_world(31, n_points=500, n_kf=2, width=width, height=height)
+    ref = kfs[0]
+    nf = min(ref.n_features, 200)
+    bb = ref.bearing[:nf]
+    last = Frame(cam, ref.mvImg_Pyr, ref.Get_Pose())
+    last.set_features(ref.px[:nf], bb, bb * (2.0 / bb[:, 2:3]), np.ones(nf, np.uint8))
+    img = np.ascontiguousarray(cur.mvImg_Pyr[0])
+    n = width * height
+    assert (n % 16 == 0) == (width == 640)
+    pin = torch.empty(n + 64, dtype=torch.uint8).pin_memory()
+    pin_s = torch.empty(height * (width + 24), dtype=torch.uint8).pin_memory()
+    flat = pin.numpy()
+    base = flat.ctypes.data
+    assert base % 16 == 0
+    aligned = flat[:n].reshape(height, width); aligned[:] = img
+    strided = pin_s.numpy().reshape(height, width + 24)[:, :width]; strided[:] = img
+    pageable_strided = np.zeros((height, width + 7), np.uint8)[:, :width]; pageable_strided[:] = img
+
+    def run(image):
+        r = tracking.track_frame(gpu_ctx, cam, image, 5, last, ref.Get_Pose(), (5, 0, 8, 15), 20, kfs, mps)
+        r["frame"].close()
+        return r
+    want = run(img)
+    assert want["n_tracked"] >= 100 and len(want["matches"]) >= 40 and not want["lost"]
+    got = {"pinned, aligned": run(aligned), "pinned, row-strided": run(strided), "pageable, row-strided": run(pageable_strided)}
+    odd = flat[4:4 + n].reshape(height, width); odd[:] = img           # (shares the buffer with `aligned`, which has been used)
+    assert odd.ctypes.data % 16 == 4
+    got["pinned, odd address"] = run(odd)
+    for name, r in got.items():
+        assert r["n_tracked"] == want["n_tracked"] and np.array_equal(r["T_run"], want["T_run"]), name
+        assert list(r["stats"]["iters"]) == list(want["stats"]["iters"]), name
+        assert np.array_equal(r["matches"], want["matches"]) and np.array_equal(r["T_opt"], want["T_opt"]), name
+        assert np.array_equal(r["residual_norm"], want["residual_norm"]), name
+    # and the frame dsdtm_frame_create_from_image builds (same kernel, from the staging block) is the frame Run aligns against
+    al = Sprase_ImgAlign(5, 0, 8, ctx=gpu_ctx, resident_frames=True)
+    cur2 = Frame(cam, [img], ref.Get_Pose())
+    cur2._device_frame = capi.DeviceFrame.from_image(gpu_ctx, img, 5)
+    assert al.Run(cur2, last) == want["n_tracked"] and np.array_equal(cur2.Get_Pose(), want["T_run"])
+
+
 @pytest.mark.parametrize("nf", [600, 1000])
 def test_run_of_a_large_reference_frame_goes_through_the_team_kernel(gpu_ctx, nf):
     """A last frame with 600 / 1000 features: `Run` inside the one-call frame is spread over 3 / 4 compute units (the team kernel, with
