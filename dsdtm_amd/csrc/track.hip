@@ -163,15 +163,12 @@ struct ReplayLds {
     uint32_t* hist;      // [cells + 1] counts, then bin starts (exclusive scan); [cells] = n_in
     uint32_t* cur;       // [cells] next free place of a bin
     uint32_t* wsum;      // [RP_THREADS / 64]
-    uint32_t* c_p;       // [mpad] by candidate: rounded reprojected pixel (x | y << 16)
-    uint32_t* c_q;       // [mpad] by candidate: rounded refined pixel = disc centre
-    uint32_t* P;         // [mpad] by rank
-    uint32_t* Q;         // [mpad] by rank
+    uint32_t* P;         // [mpad] by rank: rounded reprojected pixel (x | y << 16)
+    uint32_t* Q;         // [mpad] by rank: rounded refined pixel = disc centre (a dead candidate's: nowhere)
     uint16_t* idx;       // [mpad] candidate (map point) of rank r
     uint16_t* rcell;     // [mpad] its grid cell
     int16_t* hw;         // [radius + 1]
-    uint8_t* c_live;     // [mpad] by candidate
-    int8_t* c_sl;        // [mpad] by candidate: search level
+    int8_t* sl;          // [mpad] by rank: search level
     uint8_t* state;      // [mpad] by rank
     size_t bytes;
 };
@@ -184,15 +181,12 @@ __host__ __device__ inline ReplayLds replay_layout(uint8_t* base, int n_points, 
     L.hist = (uint32_t*)take(((size_t)cells + 1) * 4, 4);
     L.cur = (uint32_t*)take((size_t)cells * 4, 4);
     L.wsum = (uint32_t*)take((RP_THREADS / 64) * 4, 4);
-    L.c_p = (uint32_t*)take(mpad * 4, 4);
-    L.c_q = (uint32_t*)take(mpad * 4, 4);
     L.P = (uint32_t*)take(mpad * 4, 4);
     L.Q = (uint32_t*)take(mpad * 4, 4);
     L.idx = (uint16_t*)take(mpad * 2, 2);
     L.rcell = (uint16_t*)take(mpad * 2, 2);
     L.hw = (int16_t*)take(((size_t)radius + 1) * 2, 2);
-    L.c_live = take(mpad, 1);
-    L.c_sl = (int8_t*)take(mpad, 1);
+    L.sl = (int8_t*)take(mpad, 1);
     L.state = take(mpad, 1);
     L.bytes = (o + 15) / 16 * 16;
     return L;
@@ -236,11 +230,14 @@ __global__ __launch_bounds__(NT) void track_replay_kernel(const TrackArgs a) {
     //         counting sort by cell, inside a cell by (found descending, list index) ----
     unsigned long long key[EPT];
     int kcell[EPT];
+    uint32_t cp[EPT], cq[EPT];          // rounded reprojected / refined pixel of the thread's candidates
+    int csl[EPT];                       // search level; bit 8: live
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * NT;
         kcell[e] = -1;
         key[e] = ~0ull;
+        cp[e] = cq[e] = 0u; csl[e] = 0;
         if (i < M) {
             const int c = a.cell[i];
             const int f = a.mp_found[i];
@@ -257,10 +254,9 @@ __global__ __launch_bounds__(NT) void track_replay_kernel(const TrackArgs a) {
                 const bool live = ok && fabs(u1) < 30000.0 && fabs(v1) < 30000.0;      // (a converged pixel sits in or near the image)
                 const int px_ = cv_round(u0), py_ = cv_round(v0);
                 const int qx_ = live ? cv_round(u1) : px_, qy_ = live ? cv_round(v1) : py_;
-                L.c_p[i] = pack_xy(px_, py_);
-                L.c_q[i] = pack_xy(qx_, qy_);
-                L.c_live[i] = live ? 1 : 0;
-                L.c_sl[i] = (int8_t)sl;
+                cp[e] = pack_xy(px_, py_);
+                cq[e] = live ? pack_xy(qx_, qy_) : 0x7fff7fffu;          // (a dead candidate's disc is nowhere: no state test in the scans)
+                csl[e] = (sl & 0xff) | (live ? 0x100 : 0);
                 // the neighbourhood scan below looks two cells around a candidate: valid while a disc centre (the refined pixel)
                 // stays within one cell size of its candidate's reprojected pixel — otherwise every earlier candidate is scanned
                 const int ddx = qx_ - px_, ddy = qy_ - py_;
@@ -291,37 +287,32 @@ __global__ __launch_bounds__(NT) void track_replay_kernel(const TrackArgs a) {
     for (int e = 0; e < EPT; ++e)
         if (kcell[e] >= 0) L.tmp[atomicAdd(&L.cur[kcell[e]], 1u)] = ((unsigned long long)kcell[e] << 48) | key[e];
     __syncthreads();
-    // a key's place inside its cell = its rank among the cell's keys (cells hold a handful of candidates); thread t owns
-    // places t * EPT .. t * EPT + EPT - 1 (contiguous: the final prefix count is a plain scan)
+    // a key's place inside its cell = the number of smaller keys in the cell's range of `tmp` (cells hold a handful of candidates):
+    // every candidate counts for itself and parks what the walk needs of it at its place (rank)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if (kcell[e] < 0) continue;
+        const int c = kcell[e];
+        const uint32_t s0 = L.hist[c], e0 = L.hist[c + 1];
+        const unsigned long long mine = ((unsigned long long)c << 48) | key[e];
+        uint32_t rank = 0;
+        for (uint32_t q = s0; q < e0; ++q) rank += L.tmp[q] < mine ? 1u : 0u;
+        const uint32_t r = s0 + rank;
+        L.idx[r] = (uint16_t)(tid + e * NT); L.rcell[r] = (uint16_t)c;
+        L.P[r] = cp[e]; L.Q[r] = cq[e];
+        L.sl[r] = (int8_t)(csl[e] & 0xff);
+        L.state[r] = (csl[e] & 0x100) ? ST_UNKNOWN : ST_DEAD;
+    }
+    __syncthreads();
+    // from here on thread t owns places t * EPT .. t * EPT + EPT - 1 (contiguous: the final prefix count is a plain scan)
     int my_idx[EPT];
     bool live[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int r = tid * EPT + e;
         live[e] = false; my_idx[e] = 0;
-        if (r < n_in) {
-            // which key lands on place r? the one of r's cell with (r - start) smaller keys: every thread selects for its place
-            // (the cell of place r = the cell of the key that the scatter put there: places of a cell are a contiguous range)
-            const int c = (int)(L.tmp[r] >> 48);
-            const uint32_t s0 = L.hist[c], e0 = L.hist[c + 1], want = (uint32_t)r - s0;
-            unsigned long long sel = L.tmp[r];
-            if (e0 - s0 > 1u) {
-                for (uint32_t q = s0; q < e0; ++q) {
-                    const unsigned long long kq = L.tmp[q];
-                    uint32_t rank = 0;
-                    for (uint32_t j = s0; j < e0; ++j) rank += L.tmp[j] < kq ? 1u : 0u;
-                    if (rank == want) sel = kq;
-                }
-            }
-            const int i = (int)(sel & 0xffffu);
-            my_idx[e] = i;
-            live[e] = L.c_live[i] != 0;
-            L.idx[r] = (uint16_t)i; L.rcell[r] = (uint16_t)c;
-            L.P[r] = L.c_p[i]; L.Q[r] = live[e] ? L.c_q[i] : 0x7fff7fffu;       // (a dead candidate's disc is nowhere: no state test in the scans)
-            L.state[r] = live[e] ? ST_UNKNOWN : ST_DEAD;
-        }
+        if (r < n_in) { my_idx[e] = (int)L.idx[r]; live[e] = L.state[r] == ST_UNKNOWN; }
     }
-    __syncthreads();
     const bool full_scan = s_overflow != 0;
     // ---- 2. possible blockers of a live candidate: the previous live candidate of its cell (pred), and the live EARLIER
     //         candidates whose disc covers its reprojected pixel — they sit at most two cells away, i.e. (ranks are in cell
@@ -489,7 +480,7 @@ __global__ __launch_bounds__(NT) void track_replay_kernel(const TrackArgs a) {
         if (k < (uint32_t)a.max_matches) {
             const int i = my_idx[e];
             const float fx_ = (float)a.px[2 * (size_t)i], fy_ = (float)a.px[2 * (size_t)i + 1];     // Feature(px as cv::Point2f, :108)
-            const int lvl = (int)L.c_sl[i];
+            const int lvl = (int)L.sl[r];
             dsdtm_track_match mo;
             mo.cell = (int)L.rcell[r]; mo.point = i; mo.px[0] = fx_; mo.px[1] = fy_; mo.level = lvl;
             a.matches[k] = mo;

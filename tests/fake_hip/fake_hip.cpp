@@ -413,7 +413,7 @@ hipError_t pose_opt_launch(const PoseOptArgs& a, hipStream_t stream) {
     });
     return hipSuccess;
 }
-size_t track_replay_lds_bytes(int n_points, int n_cells, int radius) { return ((size_t)n_points + 63) / 64 * 64 * 31 + (size_t)n_cells * 8 + (size_t)radius * 2 + 256; }   // (the real layout's size)
+size_t track_replay_lds_bytes(int n_points, int n_cells, int radius) { return ((size_t)n_points + 63) / 64 * 64 * 22 + (size_t)n_cells * 8 + (size_t)radius * 2 + 256; }   // (the real layout's size)
 void track_disc_half_widths(int radius, int8_t* hw) { for (int i = 0; i <= radius; ++i) hw[i] = (int8_t)radius; }
 hipError_t track_match_launch(const TrackArgs& a, const WarpKernelArgs& wa, const A2DKernelArgs& aa, hipStream_t stream) {
     FAIL_POINT("track_match_launch");
