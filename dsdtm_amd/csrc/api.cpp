@@ -1972,19 +1972,26 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     //    costs 7-8 us), and Run reads its 57 bytes per feature from HBM instead of over the link.
     // (an image the caller keeps in pinned memory — hipHostMalloc / hipHostRegister, e.g. the capture buffer — is read straight
     // from there; anything else is staged through the context's pinned block first: 5-15 us of host memcpy for 640x480)
-    bool pinned_image = false;
-    if (d->stride == d->width) {
+    // (an image that already lives in this device's memory — a capture or decode pipeline on the GPU — is read from there by the same
+    // kernel, or by a device-to-device copy when it is strided or not 16-byte aligned)
+    bool pinned_image = false, device_image = false;
+    {
         hipPointerAttribute_t pa_;
-        if (hipPointerGetAttributes(&pa_, d->image) == hipSuccess) pinned_image = pa_.type == hipMemoryTypeHost;
-        else (void)hipGetLastError();                  // (an ordinary host pointer: not an error)
+        if (hipPointerGetAttributes(&pa_, d->image) == hipSuccess) {
+            device_image = pa_.type == hipMemoryTypeDevice;
+            pinned_image = pa_.type == hipMemoryTypeHost && d->stride == d->width;
+            if (device_image && pa_.device != ctx->device) { set_err(ctx, "track: the image lives on device %d, the context on %d", pa_.device, ctx->device); return fail(DSDTM_ERR_INVALID); }
+        } else (void)hipGetLastError();                // (an ordinary host pointer: not an error)
     }
-    const void* img_dev = nullptr;                     // the image as the device sees it in host memory
-    if (pinned_image && !(((size_t)d->image) & 15)) {
+    const void* img_dev = nullptr;                     // the image as the device sees it
+    if (device_image) {
+        if (d->stride == d->width && !(((size_t)d->image) & 15)) img_dev = d->image;
+    } else if (pinned_image && !(((size_t)d->image) & 15)) {
         void* p_ = nullptr;
         if (hipHostGetDevicePointer(&p_, (void*)d->image, 0) == hipSuccess) img_dev = p_;
         else (void)hipGetLastError();
     }
-    if (!pinned_image) {
+    if (!pinned_image && !device_image) {
         if (d->stride == d->width) memcpy(h + h_img, d->image, img);
         else for (int y = 0; y < d->height; ++y) memcpy(h + h_img + (size_t)y * d->width, d->image + (size_t)y * d->stride, (size_t)d->width);
         img_dev = hd + h_img;
@@ -2002,8 +2009,9 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
     };
     seed_run();
     if (img_dev) TRACK_TRY(ingest_launch(img_dev, f->d, img, hd + h_run, g + g_run, run_bytes, stream));
-    else {      // (a pinned image the device cannot address, or one that is not 16-byte aligned: the copy engine)
-        TRACK_TRY(hipMemcpyAsync(f->d, pinned_image ? (const void*)d->image : (const void*)(h + h_img), img, hipMemcpyHostToDevice, stream));
+    else {      // (a pinned image the device cannot address, or one that is not 16-byte aligned; a strided or odd device image: the copy engine)
+        if (device_image) TRACK_TRY(hipMemcpy2DAsync(f->d, (size_t)d->width, d->image, (size_t)d->stride, (size_t)d->width, (size_t)d->height, hipMemcpyDeviceToDevice, stream));
+        else TRACK_TRY(hipMemcpyAsync(f->d, pinned_image ? (const void*)d->image : (const void*)(h + h_img), img, hipMemcpyHostToDevice, stream));
         TRACK_TRY(ingest_launch(nullptr, nullptr, 0, hd + h_run, g + g_run, run_bytes, stream));
     }
     if (int rc = dsdtm_pyrdown_batch_device(ctx, f->d, f->pitch, 1, pl.levels, pl.w, pl.h, st, pl.off, stream)) return fail(rc);

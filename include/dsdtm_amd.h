@@ -346,9 +346,9 @@ int dsdtm_pose_optimization_batch_device(dsdtm_ctx* ctx, int n_frames, int max_f
  *                       candidate, the cell walk with its order-dependent rules, see below) and
  *                       Optimizer::PoseOptimization (src/Optimizer.cpp:20-79) on the features the search created.
  * Through the entries above that is four synchronous calls with host work between them (0.28 ms wall for 0.18 ms of
- * kernels); here everything is enqueued back to back on the context's stream — copy, pyramid, Run, reprojection + closest
- * observation, FindMatchDirect for all points, the replay of the cell walk ON THE DEVICE, pose refinement — and the host
- * waits ONCE, for a few hundred bytes of results in pinned memory.
+ * kernels); here everything is enqueued back to back on the context's stream — level 0 and Run's inputs into HBM, pyramid, Run,
+ * reprojection + closest observation + FindMatchDirect for all points, the replay of the cell walk ON THE DEVICE, pose
+ * refinement — and the host waits ONCE, for a few hundred bytes of results in pinned memory.
  *
  * The device replay follows src/Feature_alignment.cpp:71-121 exactly: cells in index order (:75; mCellOrder is shuffled
  * but unused), per cell the candidates by Get_FoundNums() descending, stable in ReprojectPoint order (:88, :123-126), bad
@@ -365,7 +365,11 @@ int dsdtm_pose_optimization_batch_device(dsdtm_ctx* ctx, int n_frames, int max_f
  * order of its mObservations map; observation j names keyframe obs_kf[j] (index into kf[]) and carries the observing
  * feature's mpx (obs_px), mlevel (obs_level) and mNormal (obs_bearing).
  * Limits: n_points <= 4096, grid cells <= 4096, cell_size <= 127, max_matches <= 256, n_kf <= 4096 (DSDTM_ERR_INVALID beyond).
- * An image in pinned host memory (hipHostMalloc / hipHostRegister) is copied up straight from there; any other is staged first.
+ * The image: rows of `width` bytes, `stride` bytes apart (stride >= width), in host memory or in the memory of the context's
+ * device. Level 0 enters through a kernel on the compute stream, not through a copy operation in front of it: a contiguous,
+ * 16-byte aligned image in pinned host memory (hipHostMalloc / hipHostRegister) or in device memory is read straight from
+ * where it is; any other host image is staged through the context's pinned block first (a pinned one at an odd address, and a
+ * strided or odd device image, go through the copy engine). Same results on every path.
  */
 typedef struct dsdtm_track_desc {
     /* the new frame (src/Frame.cpp:35-41) */

@@ -370,6 +370,65 @@ static bool track_frame_packing() {
     return true;
 }
 
+// ---- 10b. dsdtm_track_frame when a launch or a copy inside it fails: an error, nothing pending, nothing leaked, and the next frame works ----
+static bool track_frame_failures() {
+    dsdtm_ctx* ctx = nullptr;
+    CHECK(dsdtm_create(0, &ctx) == DSDTM_OK);
+    const dsdtm_camera cam = camera();
+    std::vector<uint8_t> img((size_t)W * H, 5);
+    dsdtm_frame *ref = nullptr, *k0 = nullptr;
+    CHECK(dsdtm_frame_create_from_image(ctx, img.data(), W, H, W, L, &ref) == DSDTM_OK);
+    CHECK(dsdtm_frame_create_from_image(ctx, img.data(), W, H, W, L, &k0) == DSDTM_OK);
+    const dsdtm_frame* kf[1] = {k0};
+    const int n = 40, M = 50;
+    std::vector<float> px(2 * n), opx(2 * M, 1.f);
+    std::vector<double> be(3 * n), pw(3 * n), mpw(3 * M), ob(3 * M, 0.0), Tk(12, 0.0);
+    std::vector<uint8_t> ini(n, 1), bad(M, 0);
+    std::vector<int32_t> found(M, 2), off(M + 1), okf(M, 0), olv(M, 0);
+    for (int i = 0; i <= M; ++i) off[i] = i;
+    double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    dsdtm_track_desc d{};
+    d.image = img.data(); d.width = W; d.height = H; d.stride = W; d.levels = L;
+    d.ref = ref; d.n_ref_features = n; d.ref_px_xy = px.data(); d.ref_bearing = be.data(); d.ref_p_world = pw.data(); d.ref_initial = ini.data();
+    d.T_ref_w = T; d.T_seed = T; d.align = params(); d.min_tracked = 0;
+    d.kf = kf; d.n_kf = 1; d.T_kf_w = Tk.data(); d.n_points = M;
+    d.mp_world = mpw.data(); d.mp_found = found.data(); d.mp_bad = bad.data(); d.obs_offset = off.data();
+    d.obs_kf = okf.data(); d.obs_px = opx.data(); d.obs_level = olv.data(); d.obs_bearing = ob.data();
+    d.cell_size = 8; d.max_pyr_levels = L + 1; d.max_matches = 200; d.align2d_iters = 10; d.pose_opt.max_iterations = 100;
+    dsdtm_track_result r;
+    std::vector<dsdtm_track_match> ms(200);
+    std::vector<double> rn(200);
+    CHECK(dsdtm_track_frame(ctx, &cam, &d, &r, ms.data(), rn.data()) == DSDTM_OK && r.frame && r.n_tracked == n);
+    dsdtm_frame_destroy(ctx, r.frame);
+    const char* points[] = {"ingest_launch", "pyrdown_launch", "sparse_align_launch", "hipMemcpyAsync", "hipStreamSynchronize",
+                            "track_match_launch", "track_replay_launch", "pose_opt_launch"};
+    for (const char* api : points) {
+        fake_hip_fail(api, 1);
+        const int rc = dsdtm_track_frame(ctx, &cam, &d, &r, ms.data(), rn.data());
+        CHECK(rc == DSDTM_ERR_HIP && r.frame == nullptr && fake_hip_pending() == 0);
+        CHECK(dsdtm_track_frame(ctx, &cam, &d, &r, ms.data(), rn.data()) == DSDTM_OK && r.frame && r.n_tracked == n);   // and the context is usable
+        dsdtm_frame_destroy(ctx, r.frame);
+    }
+    {   // an image that lives in device memory: read from there (aligned, contiguous) or copied device to device (strided)
+        uint8_t* dimg = nullptr;
+        CHECK(hipMalloc((void**)&dimg, (size_t)(W + 16) * H) == hipSuccess);
+        memset(dimg, 5, (size_t)(W + 16) * H);
+        dsdtm_track_desc dd = d;
+        dd.image = dimg;
+        CHECK(dsdtm_track_frame(ctx, &cam, &dd, &r, ms.data(), rn.data()) == DSDTM_OK && r.frame && r.n_tracked == n);
+        dsdtm_frame_destroy(ctx, r.frame);
+        dd.stride = W + 16;
+        CHECK(dsdtm_track_frame(ctx, &cam, &dd, &r, ms.data(), rn.data()) == DSDTM_OK && r.frame && r.n_tracked == n);
+        dsdtm_frame_destroy(ctx, r.frame);
+        CHECK(hipFree(dimg) == hipSuccess);
+    }
+    dsdtm_frame_destroy(ctx, ref); dsdtm_frame_destroy(ctx, k0);
+    CHECK(no_fake_errors());
+    dsdtm_destroy(ctx);
+    CHECK(fake_hip_live_allocations() == 0);
+    return true;
+}
+
 // ---- 11. two contexts driven from two threads at once (the ThreadSanitizer build) ----
 static bool two_contexts_two_threads() {
     bool ok[2] = {false, false};
@@ -409,7 +468,7 @@ int main(int argc, char** argv) {
         {"recover_slots_past_64", recover_slots_past_64}, {"team_epoch_wrap_is_cleared", team_epoch_wrap_is_cleared},
         {"team_epoch_wrap_hazard_is_real", team_epoch_wrap_hazard_is_real}, {"sharded_refetches_after_rerun", sharded_refetches_after_rerun},
         {"sharded_error_midway", sharded_error_midway}, {"streamed_entry", streamed_entry}, {"frame_lifetime", frame_lifetime},
-        {"single_call_entries", single_call_entries}, {"track_frame_packing", track_frame_packing},
+        {"single_call_entries", single_call_entries}, {"track_frame_packing", track_frame_packing}, {"track_frame_failures", track_frame_failures},
         {"two_contexts_two_threads", two_contexts_two_threads}};
     int failed = 0;
     for (const auto& sc : all) {

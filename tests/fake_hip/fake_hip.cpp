@@ -153,7 +153,7 @@ hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { FAIL_POIN
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
     Lock l(g_mu);
     for (auto& kv : g_mem)
-        if ((const uint8_t*)p >= (const uint8_t*)kv.first && (const uint8_t*)p < (const uint8_t*)kv.first + kv.second.first) { a->type = (hipMemoryType)kv.second.second; return hipSuccess; }
+        if ((const uint8_t*)p >= (const uint8_t*)kv.first && (const uint8_t*)p < (const uint8_t*)kv.first + kv.second.first) { a->type = (hipMemoryType)kv.second.second; a->device = 0; return hipSuccess; }
     return hipErrorInvalidValue;
 }
 hipError_t hipMemset(void* p, int v, size_t bytes) { FAIL_POINT("hipMemset"); Lock l(g_mu); drain_all_locked(); memset(p, v, bytes); return hipSuccess; }

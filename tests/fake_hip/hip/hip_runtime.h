@@ -20,7 +20,7 @@ enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault
 enum hipDeviceAttribute_t { hipDeviceAttributeNumberOfXccs = 1 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipDeviceProp_t { char gcnArchName[256]; int multiProcessorCount; };
-struct hipPointerAttribute_t { hipMemoryType type; };
+struct hipPointerAttribute_t { hipMemoryType type; int device; };
 
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetLastError();

@@ -18,7 +18,7 @@ import pytest
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_hip")
 SCENARIOS = ["ring_table_past_16_streams", "evicted_timeout_is_reported", "recover_slots_past_64", "team_epoch_wrap_is_cleared",
              "team_epoch_wrap_hazard_is_real", "sharded_refetches_after_rerun", "sharded_error_midway", "streamed_entry", "frame_lifetime",
-             "single_call_entries", "track_frame_packing", "two_contexts_two_threads"]
+             "single_call_entries", "track_frame_packing", "track_frame_failures", "two_contexts_two_threads"]
 
 
 @pytest.fixture(scope="module")

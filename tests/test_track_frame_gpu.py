@@ -193,9 +193,10 @@ def test_tracked_sequence_one_call_per_frame_equals_the_four_call_chain(gpu_ctx)
 
 @pytest.mark.parametrize("width,height", [(640, 480), (636, 478)])
 def test_every_way_the_image_can_arrive_gives_the_same_frame(gpu_ctx, width, height):
-    """Level 0 reaches the device on four paths (api.cpp, dsdtm_track_frame step 1): a pageable image is staged through the context's
+    """Level 0 reaches the device on several paths (api.cpp, dsdtm_track_frame step 1): a pageable image is staged through the context's
     pinned block and read from there by ingest_kernel; a pinned, 16-byte aligned image is read by that kernel straight from the
-    caller's buffer; a pinned image at an odd address goes through the copy engine; a row-strided image is packed row by row first.
+    caller's buffer; a pinned image at an odd address goes through the copy engine; a row-strided image is packed row by row first; an image
+    in device memory is read where it is, or copied device to device when it is strided or at an odd address.
     Same bytes on the device, so the same Run pose, match list and refined pose, bit for bit. 636 x 478: the byte count is not a
     multiple of 16 (the kernel's byte tail) and the level widths are not multiples of 8 (one pyrDown launch per level)."""
     import torch
@@ -228,6 +229,18 @@ def test_every_way_the_image_can_arrive_gives_the_same_frame(gpu_ctx, width, hei
     odd = flat[4:4 + n].reshape(height, width); odd[:] = img           # (shares the buffer with `aligned`, which has been used)
     assert odd.ctypes.data % 16 == 4
     got["pinned, odd address"] = run(odd)
+    # an image that already lives in device memory: read from there (contiguous, aligned), or copied device to device (row-strided; odd address)
+    dev = torch.from_numpy(img).cuda()
+    dev_s = torch.zeros((height, width + 40), dtype=torch.uint8, device="cuda"); dev_s[:, :width] = dev
+    dev_o = torch.zeros(n + 64, dtype=torch.uint8, device="cuda"); dev_o[4:4 + n] = dev.reshape(-1)
+    torch.cuda.synchronize()
+    for name, ptr, stride in (("device, aligned", dev.data_ptr(), width), ("device, row-strided", dev_s.data_ptr(), width + 40),
+                              ("device, odd address", dev_o.data_ptr() + 4, width)):
+        call = tracking.TrackCall(gpu_ctx, cam, img, 5, last, ref.Get_Pose(), (5, 0, 8, 15), 20, kfs, mps)
+        call.desc.image, call.desc.stride = ptr, stride
+        got[name] = call.run()
+        got[name]["frame"].close()
+    assert dev.data_ptr() % 16 == 0
     for name, r in got.items():
         assert r["n_tracked"] == want["n_tracked"] and np.array_equal(r["T_run"], want["T_run"]), name
         assert list(r["stats"]["iters"]) == list(want["stats"]["iters"]), name
