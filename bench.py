@@ -1000,6 +1000,7 @@ def main():
         return
 
     from dsdtm_amd import capi, synth
+    capi.diag_default(False).__enter__()          # every context of this process, explicit or implied: the release library
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -1008,7 +1009,8 @@ def main():
         if rank == 0:
             hip_build.build(verbose=False)
         barrier()
-    ctx = capi.Context(local_rank)          # fails loudly without the HIP library / a gfx950 device
+    ctx = capi.Context(local_rank, diag=False)   # the RELEASE library whatever the environment says (DSDTM_PY_DIAG is for tools/);
+                                                 # fails loudly without the HIP library / a gfx950 device
     cam = synth.Camera.tum(args.width, args.height)
     cam_struct = capi.camera_struct(cam)
     prm = capi.AlignParams(args.levels, 0, args.iters, 15)
