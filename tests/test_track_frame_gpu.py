@@ -275,6 +275,46 @@ def test_run_of_a_large_reference_frame_goes_through_the_team_kernel(gpu_ctx, nf
     r["frame"].close()
 
 
+@pytest.mark.diag
+def test_a_team_timeout_inside_the_one_call_frame_is_re_run_from_the_seed(gpu_ctx_diag):
+    """600 reference features: `Run` inside dsdtm_track_frame is a team of three compute units. With the diagnostic switch that keeps the
+    last member away, the members' bounded waits run out; the call sees the timeout word after its one wait, puts the seed pose, a zero
+    count and cleared statistics back into Run's range ON THE DEVICE (the range lives there since round 6: a second ingest launch), and
+    issues the whole chain again with Run on one compute unit. The caller gets the frame an undisturbed call returns, and no error."""
+    ctx = gpu_ctx_diag
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    cam, kfs, cur, mps = make_world(17, n_points=1800)
+    ref = kfs[0]
+    nf = 600
+    bb = ref.bearing[:nf]
+    last = Frame(cam, ref.mvImg_Pyr, ref.Get_Pose())
+    last.set_features(ref.px[:nf], bb, bb * (2.0 / bb[:, 2:3]), np.ones(nf, np.uint8))
+
+    def run():
+        r = tracking.track_frame(ctx, cam, cur.mvImg_Pyr[0], 5, last, last.Get_Pose(), (5, 0, 8, 15), 20, kfs, mps[:900])
+        r["frame"].close()
+        return r
+    want = run()
+    recovered = ctx.lib.dsdtm_debug_recovered_launches
+    recovered.restype, recovered.argtypes = C.c_longlong, [C.c_void_p]
+    drop = ctx.lib.dsdtm_debug_drop_team_members
+    drop.restype, drop.argtypes = None, [C.c_int]
+    n0 = recovered(ctx.handle)
+    try:
+        drop(1)
+        got = run()
+    finally:
+        drop(0)
+    assert recovered(ctx.handle) == n0 + 1, "the first attempt did not time out: the switch no longer reaches this launch"
+    assert got["n_tracked"] == want["n_tracked"] > nf // 2 and list(got["stats"]["iters"]) == list(want["stats"]["iters"])
+    # (one compute unit sums the same partials in another order than three: the pose agrees to rounding, not to the bit)
+    H.assert_pose_close(got["T_run"], want["T_run"], H.TIGHT_RAD * 10, H.TIGHT_M * 10, what="Run after the re-run")
+    assert [tuple(m)[:2] for m in got["matches"][["cell", "point"]]] == [tuple(m)[:2] for m in want["matches"][["cell", "point"]]]
+    assert got["summary"]["iterations"] == want["summary"]["iterations"]
+    H.assert_pose_close(got["T_opt"], want["T_opt"], H.TIGHT_RAD * 100, H.TIGHT_M * 100, what="refined pose after the re-run")
+    assert np.array_equal(run()["T_run"], want["T_run"])                   # and the next undisturbed frame is the first one again
+
+
 def test_lost_frame_skips_search_and_refinement(gpu_ctx):
     """Run's count below Tracking's threshold (src/Tracking.cpp:208: < 20 => Lost): nothing after Run is computed — no matches,
     T_opt = T_run — and the new frame is still handed over."""
