@@ -30,12 +30,12 @@ def test1():
     return np.ascontiguousarray(img)
 
 
-def _detector_corners(img, levels, ctx, max_fts=600):
+def _detector_corners(img, levels, ctx, max_fts=600, cell=25):
     """Feature_detector::detect (src/Feature_detection.cpp:69-154) on the image's pyramid: level-0 pixels + levels."""
     cam = synth.Camera(**RPG)
     old = {k: Config.Get(k) for k in ("Camera.Max_fts", "Camera.MaxPyraLevels", "Camera.CellSize")}
     try:
-        Config.Set("Camera.Max_fts", max_fts); Config.Set("Camera.MaxPyraLevels", levels); Config.Set("Camera.CellSize", 25)
+        Config.Set("Camera.Max_fts", max_fts); Config.Set("Camera.MaxPyraLevels", levels); Config.Set("Camera.CellSize", cell)
         fr = Frame(cam, synth.build_pyramid(img, levels))
         det = Feature_detector(cam.width, cam.height, ctx=ctx)
         n = det.detect(fr, 20.0)
@@ -176,3 +176,59 @@ def test_find_match_direct_on_corners_and_flat_regions(gpu_ctx, oracle, test1):
     assert sat_pb.min() >= 254 and (sat_pb == 254).any()
     assert np.array_equal(cg[-nf:], co[-nf:]) and np.array_equal(pxg[-nf:], (pxo * (1 << sl_o)[:, None])[-nf:], equal_nan=True)
     assert co[:-nf][lv == 0].mean() > 0.6                                   # level-0 corners: matched (coarser ones cannot be: quirk W1)
+
+
+def test_one_tracked_frame_on_the_reference_image(gpu_ctx, test1):
+    """dsdtm_track_frame (src/Tracking.cpp:199-256 in one submission) on real image statistics: test1 is the texture of the plane, the
+    local map is the product detector's corners on it (clustered on structure, none in the flat regions — cells with several
+    candidates next to empty ones), keyframes and the current frame are plane-warped test1 at the Rpg_uzh intrinsics. Against the four
+    synchronous calls (Run, LocalPointSearch with its host replay of the cell walk, PoseOptimization), each of which the other tests
+    hold to the CPU restatement: Run's pose and count, the match list with its refined pixels, the refined pose — bit for bit."""
+    from dsdtm_amd import search, tracking
+    from dsdtm_amd.optimizer import Optimizer
+    from dsdtm_amd.sparse_align import Sprase_ImgAlign
+    from tests.test_search_gpu import make_world
+    import copy
+    L = 5
+    old = {k: Config.Get(k) for k in ("Camera.MaxPyraLevels", "Camera.CellSize", "Camera.Min_fts")}
+    try:
+        Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", L); Config.Set("Camera.Min_fts", 15)
+        cam, px, lv = _detector_corners(test1, L, gpu_ctx, max_fts=4000, cell=12)      # a denser map than one corner per search cell
+        Config.Set("Camera.CellSize", 25)
+        cam, kfs, cur, mps = make_world(5, n_kf=2, width=752, height=480, tex=test1, cam=cam, uv=px)
+        assert len(mps) == len(px) > 200
+        ref = kfs[0]
+        nf = min(ref.n_features, 300)
+        bb = ref.bearing[:nf]
+        last = Frame(cam, ref.mvImg_Pyr, ref.Get_Pose())
+        last.set_features(ref.px[:nf], bb, bb * (2.0 / bb[:, 2:3]), np.ones(nf, np.uint8))
+        seed = ref.Get_Pose()
+        # ---- four calls ----
+        mps4 = copy.deepcopy(mps)
+        c4 = Frame(cam, cur.mvImg_Pyr, seed)
+        al = Sprase_ImgAlign(L, 0, 8, ctx=gpu_ctx, resident_frames=True)
+        n4 = al.Run(c4, last)
+        T_run4 = c4.Get_Pose().copy()
+        srch = search.LocalPointSearch(cam, ctx=gpu_ctx, resident_frames=True)
+        srch.ResetGrid()
+        for mp in mps4:
+            if not mp.IsBad():
+                srch.ReprojectPoint(c4, mp)
+        idx4 = {id(mp): i for i, mp in enumerate(mps4)}
+        m4 = [(g[0], idx4[id(g[1])], float(g[2][0]), float(g[2][1]), g[3]) for g in srch.SearchLocalPoints(c4, kfs)]
+        sm4 = Optimizer.PoseOptimization(c4, ctx=gpu_ctx)
+        # ---- one call ----
+        r = tracking.track_frame(gpu_ctx, cam, cur.mvImg_Pyr[0], L, last, seed, (L, 0, 8, 15), 20, kfs, mps)
+        m1 = [(int(r["matches"]["cell"][k]), int(r["matches"]["point"][k]), float(r["matches"]["px"][k][0]), float(r["matches"]["px"][k][1]),
+               int(r["matches"]["level"][k])) for k in range(len(r["matches"]))]
+        r["frame"].close()
+        assert r["n_tracked"] == n4 > 80 and np.array_equal(r["T_run"], T_run4) and list(r["stats"]["iters"]) == list(al.last_stats["iters"])
+        assert m1 == m4 and len(m1) >= 40, (len(m1), len(m4))
+        assert np.array_equal(r["T_opt"], c4.Get_Pose()) and r["summary"]["iterations"] == sm4["iterations"]
+        # real corners cluster: some cells of the walk held more than one candidate, and some candidates lost to an earlier match's disc
+        cells = np.array([int(np.floor(c4.World2Pixel(mp.Get_Pose())[1] / 25)) * ((752 + 24) // 25) + int(np.floor(c4.World2Pixel(mp.Get_Pose())[0] / 25))
+                          for mp in mps if not mp.IsBad()])
+        assert (np.bincount(cells[cells >= 0]) > 1).sum() >= 20          # (293 points, 184 tracked, 69 matches, 52 such cells)
+    finally:
+        for k, v in old.items():
+            Config.Set(k, v)

@@ -9,12 +9,13 @@ from dsdtm_amd.frame import Config, Frame
 from tests import search_restatement as SR
 
 
-def make_world(seed, n_points=900, n_kf=3, width=640, height=480, cell=25, obs_margin=12, uv_margin=20):
+def make_world(seed, n_points=900, n_kf=3, width=640, height=480, cell=25, obs_margin=12, uv_margin=20, tex=None, cam=None, uv=None):
     """A textured plane seen by n_kf keyframes and one current frame; map points on the plane with
-    observations in the keyframes."""
+    observations in the keyframes. `tex` (a real image), `cam` and `uv` (where on the first keyframe's image the map points sit,
+    e.g. a detector's corners) replace the seeded texture, the TUM intrinsics and the uniform draw."""
     rng = np.random.default_rng(seed)
-    cam = synth.Camera.tum(width, height)
-    tex = synth.make_texture(height, width, seed)
+    cam = synth.Camera.tum(width, height) if cam is None else cam
+    tex = synth.make_texture(height, width, seed) if tex is None else np.asarray(tex, np.float64)
     depth = 2.0
     frames = []
     poses = [np.eye(4)] + [synth.se3_exp(np.concatenate([rng.uniform(-0.06, 0.06, 3), rng.uniform(-0.03, 0.03, 3)])) for _ in range(n_kf)]
@@ -22,7 +23,10 @@ def make_world(seed, n_points=900, n_kf=3, width=640, height=480, cell=25, obs_m
     kfs = [search.KeyFrame(cam, synth.build_pyramid(imgs[i], 5), poses[i][:3], i) for i in range(n_kf)]
     cur = Frame(cam, synth.build_pyramid(imgs[n_kf], 5), poses[n_kf][:3])
     # map points: plane points (world == first keyframe's camera frame)
-    uv = np.stack([rng.uniform(uv_margin, width - uv_margin, n_points), rng.uniform(uv_margin, height - uv_margin, n_points)], 1)
+    if uv is None:
+        uv = np.stack([rng.uniform(uv_margin, width - uv_margin, n_points), rng.uniform(uv_margin, height - uv_margin, n_points)], 1)
+    else:
+        uv = np.asarray(uv, np.float64); n_points = len(uv)
     ray = np.stack([(uv[:, 0] - cam.cx) / cam.fx, (uv[:, 1] - cam.cy) / cam.fy, np.ones(n_points)], 1)
     P = ray * depth
     feats = [[] for _ in range(n_kf)]
