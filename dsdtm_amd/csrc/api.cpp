@@ -1855,8 +1855,9 @@ extern "C" int dsdtm_pose_optimization(dsdtm_ctx* ctx, const double* bearing, co
 // ---- one tracked frame in ONE submission (src/Tracking.cpp:199-256) ------------------------------
 // new frame -> Run -> ReprojectPoint + Get_ClosetObs for every local map point -> FindMatchDirect for all of them -> the cell
 // walk of SearchLocalPoints replayed on the device -> PoseOptimization, enqueued back to back on the context's stream; the host
-// waits once. Inputs are packed into the context's pinned block while the GPU already works on the earlier stages (the image
-// goes first); the kernels read them from there (host-mapped, each byte once) and write their few results there.
+// waits once. What crosses the link crosses it once and off the kernels' critical paths: level 0 and Run's inputs are read from
+// host-mapped pinned memory by ONE kernel into HBM, the local map goes up on a second stream while Run runs, every later kernel
+// works on device memory and the few results are written (posted) to the pinned block by whichever kernel has them first.
 extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const dsdtm_track_desc* d, dsdtm_track_result* res,
                                  dsdtm_track_match* matches, double* residual_norm) {
     if (!ctx) return DSDTM_ERR_INVALID;
@@ -2102,12 +2103,12 @@ extern "C" int dsdtm_track_frame(dsdtm_ctx* ctx, const dsdtm_camera* cam, const 
         if (!packed_map) {
             // the local map does not depend on Run: it is packed and copied up on a second stream WHILE Run runs (its reads —
             // observation -> keyframe pose -> reference feature — are dependent chains: from host-mapped memory they cost the
-            // reprojection kernel 16 us, from HBM 4)
+            // reprojection 16 us, from HBM 4)
             pack_map();
             if (!ctx->copy_stream[0]) TRACK_TRY(hipStreamCreateWithFlags(&ctx->copy_stream[0], hipStreamNonBlocking));
             TRACK_TRY(hipMemcpyAsync(g + g_map, h + h_map, map_bytes, hipMemcpyHostToDevice, ctx->copy_stream[0]));
             // (waited for by the HOST, while Run runs: a device-side event wait costs the stream a 6-us bubble in front of the
-            // reprojection kernel; the kernels behind Run are still enqueued long before Run ends)
+            // next kernel; the kernels behind Run are still enqueued long before Run ends)
             TRACK_TRY(hipStreamSynchronize(ctx->copy_stream[0]));
         }
         // 4. ReprojectPoint + Get_ClosetObs for every point; FindMatchDirect for every point that passed; the cell walk; the

@@ -1,11 +1,12 @@
 // track.hip — the two kernels dsdtm_track_frame adds between Run, FindMatchDirect and the pose refinement so that one
 // tracked frame (reference src/Tracking.cpp:199-256) is ONE submission:
 //
-//   track_reproject_kernel  UpdateLocalMap's ReprojectPoint for every local map point with the pose Run just produced
+//   track_match_kernel      UpdateLocalMap's ReprojectPoint for every local map point with the pose Run just produced
 //                           (src/Feature_alignment.cpp:54-69, Frame::World2Pixel src/Frame.cpp:318-323, Camera::IsInImage
 //                           src/Camera.cpp:187-193), MapPoint::Get_ClosetObs (src/MapPoint.cpp:133-174) and the reference-
-//                           pixel test of FindMatchDirect (:135-140): thread = map point; writes the candidate columns the
-//                           fused FindMatchDirect kernel (match.hip) reads.
+//                           pixel test of FindMatchDirect (:135-140) — reproject_point(), lane = map point — in front of
+//                           phase 1 of the fused FindMatchDirect kernel (match.hip / match_body.h), which then runs for that
+//                           point; block 0 also forwards Run's results to the caller's pinned block.
 //   track_replay_kernel     the order-dependent part of SearchLocalPoints / ReprojectCell (:71-121) over the results of
 //                           that kernel, ONE workgroup: cells in index order, candidates by found count (stable), bad /
 //                           masked candidates skipped, first success per cell, a disc of radius cell_size around every
