@@ -53,7 +53,7 @@ def test_bench_one_rank_over_rccl():
     device_id, the contract's barrier on both sides of the timed region and the max-over-ranks all-reduce on the GPU
     (DSDTM_BENCH_FORCE_DIST=1 makes bench.py set them up for a world of 1; the two-rank test above has to use gloo because
     RCCL refuses two ranks on one device)."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "DSDTM_BENCH_SHARE_GPU")}
     env.update(DSDTM_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pairs", "64",
