@@ -159,3 +159,13 @@ def test_rank_checks_aggregate_to_one_verdict():
     import bench_line
     line = bench_line.compact({"metric": "m", "value": 1.0, "pose_delta_vs_cpu": pd})
     assert line["pose_delta_vs_cpu"]["ranks_checked"] == 2 and line["pose_delta_vs_cpu"]["pairs_checked"] == 64
+
+
+def test_committed_profiles_describe_the_sources_in_the_tree():
+    """profiles/r06_bench_pmc.json (counter traffic, FP64 mix, kernel durations: what bench.py prints as roofline.traffic / fp64)
+    names the binary it was measured with and the sources + flags that binary was built from. The round's last commit must not
+    leave the two apart: a source edited after the last profile run would silently null those fields in the driver's line."""
+    from dsdtm_amd.csrc import build as hip_build
+    with open(os.path.join(ROOT, "profiles", "r06_bench_pmc.json")) as f:
+        d = json.load(f)
+    assert d["profile_source_sha"] == hip_build.source_sha(), "library sources changed after the committed profile run: re-run tools/profile.sh + merge_profiles.py"
