@@ -241,6 +241,17 @@ def test_every_way_the_image_can_arrive_gives_the_same_frame(gpu_ctx, width, hei
         got[name] = call.run()
         got[name]["frame"].close()
     assert dev.data_ptr() % 16 == 0
+    # an ordinary buffer the caller registered (hipHostRegister: a capture buffer that already exists), page-aligned
+    raw = np.zeros(n + 8192, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    reg = raw[off:off + n].reshape(height, width); reg[:] = img
+    rt = torch.cuda.cudart()
+    nreg = (n + 4095) // 4096 * 4096
+    if int(rt.cudaHostRegister(reg.ctypes.data, nreg, 2)) == 0:                 # 2 = hipHostRegisterMapped
+        try:
+            got["registered host buffer"] = run(reg)
+        finally:
+            rt.cudaHostUnregister(reg.ctypes.data)
     for name, r in got.items():
         assert r["n_tracked"] == want["n_tracked"] and np.array_equal(r["T_run"], want["T_run"]), name
         assert list(r["stats"]["iters"]) == list(want["stats"]["iters"]), name
