@@ -326,6 +326,60 @@ def test_a_team_timeout_inside_the_one_call_frame_is_re_run_from_the_seed(gpu_ct
     assert np.array_equal(run()["T_run"], want["T_run"])                   # and the next undisturbed frame is the first one again
 
 
+def test_degenerate_but_valid_shapes(gpu_ctx):
+    """What a tracker can legitimately hand over at start-up or in a poor scene: an empty local map, no keyframes at all, a mask that
+    blocks the whole image, a cap of ONE match, the largest cell the grid takes. Each call returns OK, the new frame and Run's
+    result; the search part is empty where it must be and equals the host replay where it is not."""
+    Config.Set("Camera.CellSize", 25); Config.Set("Camera.MaxPyraLevels", 5); Config.Set("Camera.Min_fts", 15)
+    cam, kfs, cur, mps = make_world(41, n_points=400, n_kf=2)
+    ref = kfs[0]
+    nf = min(ref.n_features, 150)
+    bb = ref.bearing[:nf]
+    last = Frame(cam, ref.mvImg_Pyr, ref.Get_Pose())
+    last.set_features(ref.px[:nf], bb, bb * (2.0 / bb[:, 2:3]), np.ones(nf, np.uint8))
+    args = (gpu_ctx, cam, cur.mvImg_Pyr[0], 5, last, ref.Get_Pose(), (5, 0, 8, 15), 20)
+    want = tracking.track_frame(*args, kfs, mps)
+    want["frame"].close()
+    assert want["n_tracked"] > 60 and len(want["matches"]) > 30
+
+    def same_run(r):
+        return r["n_tracked"] == want["n_tracked"] and np.array_equal(r["T_run"], want["T_run"]) and not r["lost"]
+    # an empty local map (with and without keyframes): Run's result, no matches, the refinement has no residual block and keeps Run's pose
+    for kf_list in (kfs, []):
+        r = tracking.track_frame(*args, kf_list, [])
+        assert same_run(r) and r["n_in_grid"] == 0 and len(r["matches"]) == 0
+        # (the refinement re-assembles the pose from its parameter block, log then exp, as src/Optimizer.cpp:35-37,78 does: equal to rounding)
+        assert r["summary"]["n_residual_blocks"] == 0 and np.allclose(r["T_opt"], r["T_run"], rtol=0, atol=1e-14)
+        r["frame"].close()
+    # a mask that blocks everything: every candidate is skipped (:96)
+    r = tracking.track_frame(*args, kfs, mps, mask=np.zeros((cam.height, cam.width), np.uint8))
+    assert same_run(r) and r["n_in_grid"] == want["n_in_grid"] and len(r["matches"]) == 0 and np.allclose(r["T_opt"], r["T_run"], rtol=0, atol=1e-14)
+    r["frame"].close()
+    # a cap of one match: the walk's FIRST success, and the refinement on that single feature
+    r = tracking.track_frame(*args, kfs, mps, max_matches=1)
+    assert same_run(r) and len(r["matches"]) == 1 and r["matches"][0] == want["matches"][0] and r["summary"]["n_residual_blocks"] == 1
+    r["frame"].close()
+    # the largest cell (127 px: a 6 x 4 grid, every candidate's neighbourhood is most of the image -> the full scan)
+    mps_h = copy.deepcopy(mps)
+    Config.Set("Camera.CellSize", 127)
+    try:
+        c4 = Frame(cam, cur.mvImg_Pyr, want["T_run"])
+        s = search.LocalPointSearch(cam, ctx=gpu_ctx, resident_frames=True)
+        s.ResetGrid()
+        for mp in mps_h:
+            if not mp.IsBad():
+                s.ReprojectPoint(c4, mp)
+        idx = {id(mp): i for i, mp in enumerate(mps_h)}
+        want127 = [(g[0], idx[id(g[1])], float(g[2][0]), float(g[2][1]), g[3]) for g in s.SearchLocalPoints(c4, kfs)]
+    finally:
+        Config.Set("Camera.CellSize", 25)
+    r = tracking.track_frame(*args, kfs, mps, cell_size=127)
+    m = r["matches"]
+    got127 = [(int(m["cell"][k]), int(m["point"][k]), float(m["px"][k][0]), float(m["px"][k][1]), int(m["level"][k])) for k in range(len(m))]
+    assert same_run(r) and got127 == want127 and 1 <= len(got127) <= 24
+    r["frame"].close()
+
+
 def test_lost_frame_skips_search_and_refinement(gpu_ctx):
     """Run's count below Tracking's threshold (src/Tracking.cpp:208: < 20 => Lost): nothing after Run is computed — no matches,
     T_opt = T_run — and the new frame is still handed over."""
